@@ -1,0 +1,143 @@
+/*
+ * voronoirt.h -- C ABI of libvrt_hip.so, the MI355X (gfx950) formal solver that drops in behind
+ * VoronoiRT's Julia driver surface.
+ *
+ * The reference (meudnaes/VoronoiRT) has no FFI of its own: the boundary is the pair of Julia
+ * methods `Delaunay_upII` / `Delaunay_downII` (src/irregular_ray_tracing.jl:15-82, :96-163),
+ * their caller `J_λ_voronoi` (src/lambda_iteration.jl:60-113, src/lambda_continuum.jl:27-56) and
+ * the grid constructor `read_cell` (src/voronoi_utils.jl:36-85).  A maintainer redefines those
+ * methods to `ccall` the entry points below (INTEGRATION.md shows the Julia shim).
+ *
+ * Conventions (identical to the reference's Julia arrays, so Julia buffers pass unconverted):
+ *   - all arrays column-major as Julia stores them, ids 1-based, int64 (`Int`), float64
+ *   - positions  (3, n): pos[3*i + c], c = 0:z 1:x 2:y                 voronoi_utils.jl:8
+ *   - neighbours (n, D1): nbr[i + n*j], column 0 = count, columns 1.. = ids; ids <= 0 are walls
+ *     (-5 = z_min / bottom, -6 = z_max / top)                          voronoi_utils.jl:9,60-61,97,141
+ *   - S, alpha, J (nlam, n): x[l + ld*i], wavelength fastest, ld >= nlam   lambda_iteration.jl:60-70
+ *   - bounds[6] = z_min, z_max, x_min, x_max, y_min, y_max              io.jl:122-124
+ * Every function returns 0 on success and a negative VRT_E* code on failure; it never throws
+ * or aborts across the boundary.  vrt_last_error() returns a thread-local message.
+ * Host entry points take host pointers and copy through PCIe; *_dev entry points take device
+ * pointers (hipMalloc'ed or torch tensors) and a hipStream_t passed as void*.
+ * There is NO CPU fallback: without a usable HIP device every compute call fails with
+ * VRT_ENODEVICE.
+ */
+#ifndef VORONOIRT_H
+#define VORONOIRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRT_OK 0
+#define VRT_EINVAL (-1)     /* bad argument (null pointer, size mismatch, |k| != 1, ...)      */
+#define VRT_EGRID (-2)      /* malformed grid: id out of range, unreachable site, D >= cap ... */
+#define VRT_ENODEVICE (-3)  /* no HIP device / HIP runtime error                               */
+#define VRT_ENOMEM (-4)
+#define VRT_EIO (-5)        /* neighbour file unreadable / unparsable                          */
+
+typedef struct vrt_grid vrt_grid;   /* replaces struct VoronoiSites, voronoi_utils.jl:7-28 */
+typedef struct vrt_plan vrt_plan;   /* per-(grid, angle set) upwind tables + sweep schedule  */
+
+/* alpha layouts accepted by the batched entry points */
+#define VRT_ALPHA_SITE 0        /* alpha[n]                 same for every wavelength and angle  */
+#define VRT_ALPHA_SITE_LAM 1    /* alpha[n][ld]             same for every angle (continuum)      */
+#define VRT_ALPHA_ANGLE_SITE_LAM 2 /* alpha[n_angles][n][ld] per angle (line: lambda_iteration.jl:89-96) */
+
+const char *vrt_last_error(void);
+int vrt_version(void);
+/* number of visible HIP devices (0 if none); never fails */
+int vrt_device_count(void);
+
+/* ---- grid: replaces read_cell, src/voronoi_utils.jl:36-85 ---------------------------------
+ * Builds BFS layers from the bottom (-5) and top (-6) walls (:93-174), the stable sort
+ * permutations (:72,77), the reduced layer offsets with the reference's r[end] = n quirk
+ * (:253-269), CSR-packs the neighbour lists, uploads, and computes the Delaunay lines (:186-245)
+ * on the device.  `device` is the HIP device ordinal; device < 0 builds a HOST-ONLY handle (layers,
+ * permutations, schedule introspection) on which every compute entry point fails with
+ * VRT_ENODEVICE. */
+int vrt_grid_create(int64_t n, const double *pos_zxy, const int64_t *nbr, int64_t D1,
+                    const double bounds[6], int device, vrt_grid **out);
+/* same, parsing the voro++ "%i %n" neighbour file (rt_preprocessing/output_sites.cc:49) the way
+ * read_cell does (voronoi_utils.jl:42-70; max_guess = 70) */
+int vrt_grid_create_from_file(const char *neighbours_file, int64_t n, const double *pos_zxy,
+                              const double bounds[6], int device, vrt_grid **out);
+void vrt_grid_destroy(vrt_grid *g);
+
+/* introspection (parity tests; all values exactly as the reference's Julia fields, 1-based) */
+int64_t vrt_grid_n(const vrt_grid *g);
+int64_t vrt_grid_max_neighbours(const vrt_grid *g);             /* D = size(neighbours,2)-1   */
+int64_t vrt_grid_num_layer_offsets(const vrt_grid *g, int dir); /* length(layers_up/down)     */
+int vrt_grid_get_layers(const vrt_grid *g, int dir, int64_t *out); /* dir > 0 up, < 0 down   */
+int vrt_grid_get_perm(const vrt_grid *g, int dir, int64_t *out);   /* n entries               */
+/* Delaunay_lines as (3, D, n) column-major; wall slots are filled with 0 */
+int vrt_grid_get_delaunay_lines(const vrt_grid *g, double *out);
+
+/* ---- direction helper: k = [cos θ, cos ϕ sin θ, sin ϕ sin θ], lambda_iteration.jl:87 ------ */
+void vrt_direction(double theta_deg, double phi_deg, double k[3]);
+
+/* ---- plan: per-angle upwind tables (smallest_angle, voronoi_utils.jl:360-396, + weights and
+ * path lengths, irregular_ray_tracing.jl:50-51,66) and the exact Gauss-Seidel dependency
+ * schedule of irregular_ray_tracing.jl:37-80 / :118-161.  k is (3, n_angles) column-major; a
+ * direction with k[0] < 0 is an "up" ray (θ > 90), k[0] > 0 "down"; k[0] == 0 (θ = 90) is
+ * skipped exactly as the reference's callers do (lambda_iteration.jl:98,104). */
+int vrt_plan_create(vrt_grid *g, int64_t n_angles, const double *k, int n_sweeps, vrt_plan **out);
+/* same with an explicit sweep direction per angle (dirs[i] > 0 up / perm_up, < 0 down / perm_down,
+ * 0 = skip), as Delaunay_upII / Delaunay_downII use whatever k they are handed; dirs == NULL
+ * infers the direction from the sign of k[0] */
+int vrt_plan_create_ex(vrt_grid *g, int64_t n_angles, const double *k, const int *dirs,
+                       int n_sweeps, vrt_plan **out);
+void vrt_plan_destroy(vrt_plan *p);
+int64_t vrt_plan_num_levels(const vrt_plan *p);
+int64_t vrt_plan_num_nodes(const vrt_plan *p);   /* live (site, sweep) updates per wavelength */
+/* upwind table of one angle: up (2, n) 1-based ids, dots/w/r (2, n); any pointer may be NULL */
+int vrt_plan_get_upwind(const vrt_plan *p, int64_t angle, int64_t *up, double *dots, double *w,
+                        double *r);
+
+/* ---- formal solve, all angles x all wavelengths: replaces the loop body of J_λ_voronoi ------
+ *   S      (nlam, n) with leading dimension ld
+ *   alpha  see VRT_ALPHA_*
+ *   I0_up  (nlam, n1_up)   boundary intensity for up rays, ordered like perm_up[1:n1_up]
+ *          (lambda_iteration.jl:99-101); NULL = zeros.  I0_down likewise (:105-106).
+ *   weights[n_angles]      quadrature weights
+ *   J      (nlam, n) out:  J = Σ_angles w · I  (lambda_iteration.jl:102,107), may be NULL
+ *   I_out  (nlam, n, n_angles) out: per-angle intensities, may be NULL
+ */
+int vrt_plan_execute(vrt_plan *p, int64_t nlam, int64_t ld, const double *S, const double *alpha,
+                     int alpha_mode, const double *I0_up, const double *I0_down,
+                     const double *weights, double *J, double *I_out);
+/* device-pointer variant; I0 leading dimension is nlam; I_out leading dimension is ld */
+int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS,
+                         const double *dalpha, int alpha_mode, const double *dI0_up,
+                         const double *dI0_down, const double *weights_host, double *dJ,
+                         double *dI_out, void *stream);
+/* time (ms, HIP events on the launch stream) the sweep kernels of the last execute took, and the
+ * number of sweep-kernel launches it made */
+int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches);
+
+/* ---- schedule introspection (host only, works on a device < 0 grid handle) -----------------
+ * The dependency schedule of one direction given an upwind table `up` (2, n), 1-based ids as
+ * returned by vrt_plan_get_upwind (0 = none).  Nodes are the surviving (site, sweep) visits of
+ * irregular_ray_tracing.jl:37-80 sorted by level; zflags bit 0/1 = the read of I[upwind 1/2]
+ * sees the initial zero.  level_off has num_levels + 1 entries. */
+typedef struct vrt_schedule vrt_schedule;
+int vrt_schedule_build(const vrt_grid *g, int dir, const int64_t *up, int n_sweeps, vrt_schedule **out);
+int64_t vrt_schedule_num_nodes(const vrt_schedule *s);
+int64_t vrt_schedule_num_levels(const vrt_schedule *s);
+int vrt_schedule_get(const vrt_schedule *s, int64_t *site, int32_t *zflags, int64_t *level_off);
+void vrt_schedule_destroy(vrt_schedule *s);
+
+/* ---- single solves: drop-in bodies for Delaunay_upII / Delaunay_downII --------------------
+ * (src/irregular_ray_tracing.jl:15-20,96-101).  nI0 must equal layers[2]-1 of the direction.
+ * The plan for k is cached inside the grid. */
+int vrt_delaunay_up(vrt_grid *g, const double k[3], const double *S, const double *I0,
+                    int64_t nI0, const double *alpha, int n_sweeps, double *I_out);
+int vrt_delaunay_down(vrt_grid *g, const double k[3], const double *S, const double *I0,
+                      int64_t nI0, const double *alpha, int n_sweeps, double *I_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VORONOIRT_H */

@@ -1,0 +1,329 @@
+"""Host-side mirror of the reference's interface for the formal-solve path, over the C ABI.
+
+Same names and argument meaning as the Julia originals so that tests read like the reference's
+drivers:
+
+  read_quadrature      src/functions.jl:33-63
+  VoronoiSites         src/voronoi_utils.jl:7-28      (ray-tracing fields; grid lives on the GPU)
+  read_cell            src/voronoi_utils.jl:36-85
+  Delaunay_upII        src/irregular_ray_tracing.jl:15-82
+  Delaunay_downII      src/irregular_ray_tracing.jl:96-163
+  J_lambda_voronoi     src/lambda_iteration.jl:60-113 / src/lambda_continuum.jl:27-56 (J_λ_voronoi)
+
+Arrays are numpy with the reference's memory layout (see voronoirt_amd/synth.py): positions
+(n, 3) [z, x, y], neighbours (D+1, n) with 1-based ids, S / alpha / J (n, nlam) wavelength
+fastest.  Nothing here computes intensities on the CPU: every call goes through libvrt_hip.so
+and raises `VrtError` when no HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from . import _lib
+from ._lib import VrtError, check
+
+QUADRATURE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "quadratures")
+
+
+def _d(a):
+    return a.ctypes.data_as(_lib.p_dbl) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(_lib.p_i64) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def read_quadrature(fname: str):
+    """weights, θ (deg), ϕ (deg), n_points -- src/functions.jl:33-63.
+
+    The reference derives the point count from the digits after the first 'n' of the PATH
+    (functions.jl:36-48), which breaks on directories containing an 'n'; here the rule is applied
+    to the file's base name, and a count that disagrees with the file is an error (the reference
+    would raise BoundsError or silently keep zero weights)."""
+    path = fname
+    if not os.path.exists(path):
+        cand = os.path.join(QUADRATURE_DIR, os.path.basename(fname))
+        if os.path.exists(cand):
+            path = cand
+    base = os.path.basename(path)
+    m = re.search(r"n(\d+)", base)
+    if not m:
+        raise ValueError(f"cannot derive the number of quadrature points from {base!r}")
+    n_points = int(m.group(1))
+    rows = [ln.split() for ln in open(path) if ln.strip()]
+    if len(rows) != n_points:
+        raise ValueError(f"{base}: name says {n_points} points, file has {len(rows)}")
+    arr = np.array([[float(v) for v in r[:3]] for r in rows])
+    return arr[:, 0].copy(), arr[:, 1].copy(), arr[:, 2].copy(), n_points
+
+
+def direction(theta_deg: float, phi_deg: float) -> np.ndarray:
+    """k = [cos θ, cos ϕ sin θ, sin ϕ sin θ] -- src/lambda_iteration.jl:87"""
+    k = np.zeros(3)
+    _lib.load().vrt_direction(float(theta_deg), float(phi_deg), _d(k))
+    return k
+
+
+class VoronoiSites:
+    """The reference's `VoronoiSites` (src/voronoi_utils.jl:7-28) backed by a device-resident
+    grid handle (`vrt_grid`).  `device=-1` builds a host-only handle (layers / permutations /
+    schedule introspection, no compute)."""
+
+    def __init__(self, positions, neighbours, bounds, device: int = 0, _from_file: str | None = None):
+        L = _lib.load()
+        self.positions = _f64(positions)
+        if self.positions.ndim != 2 or self.positions.shape[1] != 3:
+            raise ValueError("positions must have shape (n, 3) with columns (z, x, y)")
+        self.n = self.positions.shape[0]
+        self.bounds = tuple(float(b) for b in bounds)
+        self.z_min, self.z_max, self.x_min, self.x_max, self.y_min, self.y_max = self.bounds
+        self.device = device
+        b = np.array(self.bounds, dtype=np.float64)
+        h = ctypes.c_void_p()
+        if _from_file is not None:
+            check(L.vrt_grid_create_from_file(_from_file.encode(), self.n, _d(self.positions),
+                                              _d(b), device, ctypes.byref(h)))
+            self.neighbours = None
+        else:
+            self.neighbours = np.ascontiguousarray(neighbours, dtype=np.int64)
+            if self.neighbours.ndim != 2 or self.neighbours.shape[1] != self.n:
+                raise ValueError("neighbours must have shape (D+1, n)")
+            check(L.vrt_grid_create(self.n, _d(self.positions), _i(self.neighbours),
+                                    self.neighbours.shape[0], _d(b), device, ctypes.byref(h)))
+        self._h = h
+        self.max_neighbours = int(L.vrt_grid_max_neighbours(h))
+        self.layers_up = self._layers(+1)
+        self.layers_down = self._layers(-1)
+        self.perm_up = self._perm(+1)
+        self.perm_down = self._perm(-1)
+        self._plans = {}
+
+    # -- introspection ------------------------------------------------------------------------
+    def _layers(self, d):
+        L = _lib.load()
+        out = np.zeros(int(L.vrt_grid_num_layer_offsets(self._h, d)), dtype=np.int64)
+        check(L.vrt_grid_get_layers(self._h, d, _i(out)))
+        return out
+
+    def _perm(self, d):
+        out = np.zeros(self.n, dtype=np.int64)
+        check(_lib.load().vrt_grid_get_perm(self._h, d, _i(out)))
+        return out
+
+    @property
+    def Delaunay_lines(self) -> np.ndarray:
+        """(n, D, 3) == Julia (3, D, n); computed on the device at construction."""
+        out = np.zeros((self.n, self.max_neighbours, 3))
+        check(_lib.load().vrt_grid_get_delaunay_lines(self._h, _d(out)))
+        return out
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            for p in self._plans.values():
+                p.close()
+            self._plans = {}
+            _lib.load().vrt_grid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_cell(fname: str, n_sites: int, positions, bounds, device: int = 0) -> VoronoiSites:
+    """read_cell (src/voronoi_utils.jl:36-85): parse the voro++ "%i %n" neighbour file, layer the
+    grid from both walls, sort, and compute the Delaunay lines.  `bounds` =
+    (z_min, z_max, x_min, x_max, y_min, y_max)."""
+    pos = _f64(positions)
+    if pos.shape[0] != n_sites:
+        raise ValueError("positions does not have n_sites rows")
+    return VoronoiSites(pos, None, bounds, device=device, _from_file=fname)
+
+
+class FormalPlan:
+    """Upwind tables + sweep schedule for a set of directions on one grid (`vrt_plan`)."""
+
+    def __init__(self, sites: VoronoiSites, k, n_sweeps: int = 3, dirs=None):
+        L = _lib.load()
+        self.sites = sites
+        self.k = _f64(np.atleast_2d(k))
+        if self.k.shape[1] != 3:
+            raise ValueError("k must have shape (n_angles, 3)")
+        self.n_angles = self.k.shape[0]
+        self.n_sweeps = int(n_sweeps)
+        h = ctypes.c_void_p()
+        if dirs is None:
+            check(L.vrt_plan_create(sites.handle, self.n_angles, _d(self.k), self.n_sweeps,
+                                    ctypes.byref(h)))
+        else:
+            d = np.ascontiguousarray(dirs, dtype=np.int32)
+            check(L.vrt_plan_create_ex(sites.handle, self.n_angles, _d(self.k),
+                                       d.ctypes.data_as(_lib.p_int), self.n_sweeps, ctypes.byref(h)))
+        self._h = h
+
+    @property
+    def num_levels(self) -> int:
+        return int(_lib.load().vrt_plan_num_levels(self._h))
+
+    @property
+    def num_nodes(self) -> int:
+        return int(_lib.load().vrt_plan_num_nodes(self._h))
+
+    def upwind(self, angle: int):
+        """(up (n,2) 1-based ids, dots (n,2), weights (n,2), path lengths (n,2))"""
+        n = self.sites.n
+        up = np.zeros((n, 2), dtype=np.int64)
+        dots = np.zeros((n, 2))
+        w = np.zeros((n, 2))
+        r = np.zeros((n, 2))
+        check(_lib.load().vrt_plan_get_upwind(self._h, angle, _i(up), _d(dots), _d(w), _d(r)))
+        return up, dots, w, r
+
+    def execute(self, S, alpha, weights=None, I0_up=None, I0_down=None, want_J=True,
+                want_I=False, alpha_mode=None):
+        """Host arrays in, host arrays out.  S (n, nlam); alpha (n,), (n, nlam) or
+        (n_angles, n, nlam).  Returns (J or None, I or None) with I of shape
+        (n_angles, n, nlam)."""
+        S = _f64(S)
+        if S.ndim == 1:
+            S = S.reshape(-1, 1)
+        n, nlam = S.shape
+        if n != self.sites.n:
+            raise ValueError("S has the wrong number of sites")
+        alpha = _f64(alpha)
+        if alpha_mode is None:
+            alpha_mode = {1: _lib.ALPHA_SITE, 2: _lib.ALPHA_SITE_LAM,
+                          3: _lib.ALPHA_ANGLE_SITE_LAM}[alpha.ndim]
+        want = {_lib.ALPHA_SITE: n, _lib.ALPHA_SITE_LAM: n * nlam,
+                _lib.ALPHA_ANGLE_SITE_LAM: self.n_angles * n * nlam}[alpha_mode]
+        if alpha.size != want:
+            raise ValueError("alpha has the wrong size for its mode")
+        n1u = int(self.sites.layers_up[1] - 1)
+        n1d = int(self.sites.layers_down[1] - 1)
+        if I0_up is not None:
+            I0_up = _f64(I0_up).reshape(-1, nlam)
+            if I0_up.shape[0] != n1u:
+                raise ValueError(f"I0_up has {I0_up.shape[0]} rows, bottom layer has {n1u} sites")
+        if I0_down is not None:
+            I0_down = _f64(I0_down).reshape(-1, nlam)
+            if I0_down.shape[0] != n1d:
+                raise ValueError(f"I0_down has {I0_down.shape[0]} rows, top layer has {n1d} sites")
+        w = _f64(weights) if weights is not None else np.ones(self.n_angles)
+        if w.size != self.n_angles:
+            raise ValueError("weights has the wrong length")
+        J = np.zeros((n, nlam)) if want_J else None
+        Iout = np.zeros((self.n_angles, n, nlam)) if want_I else None
+        check(_lib.load().vrt_plan_execute(self._h, nlam, nlam, _d(S), _d(alpha), alpha_mode,
+                                           _d(I0_up), _d(I0_down), _d(w), _d(J), _d(Iout)))
+        return J, Iout
+
+    def execute_dev(self, nlam: int, ld: int, dS: int, dalpha: int, alpha_mode: int, weights,
+                    dJ: int = 0, dI0_up: int = 0, dI0_down: int = 0, dI_out: int = 0,
+                    stream: int = 0) -> None:
+        """Device pointers (ints, e.g. torch.Tensor.data_ptr()) and a hipStream_t handle
+        (torch.cuda.current_stream().cuda_stream).  Asynchronous on `stream`."""
+        w = _f64(weights)
+        check(_lib.load().vrt_plan_execute_dev(self._h, nlam, ld, dS, dalpha, alpha_mode,
+                                               dI0_up or None, dI0_down or None, _d(w),
+                                               dJ or None, dI_out or None, stream or None))
+
+    def last_sweep_timing(self):
+        ms = ctypes.c_double()
+        launches = ctypes.c_int64()
+        check(_lib.load().vrt_plan_last_sweep_timing(self._h, ctypes.byref(ms),
+                                                     ctypes.byref(launches)))
+        return ms.value, launches.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.load().vrt_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _single(fn_name, k, S, I_0, alpha, sites: VoronoiSites, n_sweeps: int):
+    L = _lib.load()
+    k = _f64(k)
+    S = _f64(S)
+    I_0 = _f64(I_0)
+    alpha = _f64(alpha)
+    if S.shape != (sites.n,) or alpha.shape != (sites.n,):
+        raise ValueError("S and alpha must be vectors with one entry per site")
+    out = np.zeros(sites.n)
+    check(getattr(L, fn_name)(sites.handle, _d(k), _d(S), _d(I_0), I_0.size, _d(alpha),
+                              int(n_sweeps), _d(out)))
+    return out
+
+
+def Delaunay_upII(k, S, I_0, alpha, sites: VoronoiSites, n_sweeps: int = 3) -> np.ndarray:
+    """Intensity at every site for rays travelling up (src/irregular_ray_tracing.jl:15-82).
+    I_0 is the boundary intensity of perm_up[1 : layers_up[2]-1]."""
+    return _single("vrt_delaunay_up", k, S, I_0, alpha, sites, n_sweeps)
+
+
+def Delaunay_downII(k, S, I_0, alpha, sites: VoronoiSites, n_sweeps: int = 3) -> np.ndarray:
+    """Intensity at every site for rays travelling down (src/irregular_ray_tracing.jl:96-163)."""
+    return _single("vrt_delaunay_down", k, S, I_0, alpha, sites, n_sweeps)
+
+
+def quadrature_directions(theta, phi) -> np.ndarray:
+    return np.stack([direction(t, p) for t, p in zip(theta, phi)])
+
+
+def J_lambda_voronoi(S_lambda, alpha, sites: VoronoiSites, quadrature: str, I0_up=None,
+                     I0_down=None, n_sweeps: int = 3) -> np.ndarray:
+    """J_λ_voronoi: mean intensity J = Σ_angles w · I over a quadrature file
+    (src/lambda_iteration.jl:60-113 for nλ > 1, src/lambda_continuum.jl:27-56 for the continuum).
+    The angle × wavelength loop the reference threads over λ runs as one batched device solve.
+    The opacity / boundary-intensity physics stays with the caller: `alpha` is α_tot (per site,
+    per (site, λ) or per (angle, site, λ)), `I0_up` is B_λ(T) of the bottom layer
+    (lambda_iteration.jl:99-101), `I0_down` defaults to zeros (:105-106)."""
+    weights, theta, phi, _ = read_quadrature(quadrature)
+    key = (os.path.basename(quadrature), int(n_sweeps))
+    plan = sites._plans.get(key)
+    if plan is None:
+        # the reference branches on θ in degrees (lambda_iteration.jl:98,104), not on sign(k_z)
+        dirs = [1 if t > 90 else (-1 if t < 90 else 0) for t in theta]
+        plan = FormalPlan(sites, quadrature_directions(theta, phi), n_sweeps, dirs=dirs)
+        sites._plans[key] = plan
+    J, _ = plan.execute(S_lambda, alpha, weights=weights, I0_up=I0_up, I0_down=I0_down)
+    return J
+
+
+def build_schedule(sites: VoronoiSites, dir: int, up, n_sweeps: int = 3):
+    """Host-side dependency schedule of one direction (introspection; works on a device=-1
+    handle).  `up` is an (n, 2) array of 1-based upwind ids.  Returns (site ids 1-based sorted by
+    level, zero-read flags, level offsets)."""
+    L = _lib.load()
+    up = np.ascontiguousarray(up, dtype=np.int64)
+    h = ctypes.c_void_p()
+    check(L.vrt_schedule_build(sites.handle, int(dir), _i(up), int(n_sweeps), ctypes.byref(h)))
+    try:
+        nn = int(L.vrt_schedule_num_nodes(h))
+        nl = int(L.vrt_schedule_num_levels(h))
+        site = np.zeros(nn, dtype=np.int64)
+        z = np.zeros(nn, dtype=np.int32)
+        off = np.zeros(nl + 1, dtype=np.int64)
+        check(L.vrt_schedule_get(h, _i(site), z.ctypes.data_as(_lib.p_i32), _i(off)))
+    finally:
+        L.vrt_schedule_destroy(h)
+    return site, z, off

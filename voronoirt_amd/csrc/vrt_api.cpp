@@ -1,0 +1,727 @@
+// extern "C" entry points of libvrt_hip.so (declared in include/voronoirt.h).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <thread>
+
+#include "vrt_internal.h"
+
+namespace vrt {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(e == hipErrorOutOfMemory ? VRT_ENOMEM : VRT_ENODEVICE,
+                    std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    return VRT_OK;
+}
+
+template <typename T>
+static void dev_free(T *&p)
+{
+    if (p) (void)hipFree((void *)p);
+    p = nullptr;
+}
+
+static int use_device(int device)
+{
+    if (device < 0)
+        return fail(VRT_ENODEVICE, "host-only grid handle (device < 0): no compute without a HIP device");
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return fail(VRT_ENODEVICE, "no HIP device available (libvrt_hip has no CPU fallback)");
+    if (device < 0 || device >= cnt) return fail(VRT_EINVAL, "device ordinal out of range");
+    VRT_HIP_TRY(hipSetDevice(device));
+    return VRT_OK;
+}
+
+static void free_grid(vrt_grid *g)
+{
+    if (!g) return;
+    for (PlanCacheEntry *c : g->cache) {
+        vrt_plan_destroy(c->plan);
+        delete c;
+    }
+    g->cache.clear();
+    dev_free(g->d_pos);
+    dev_free(g->d_rowptr);
+    dev_free(g->d_col);
+    dev_free(g->d_lz);
+    dev_free(g->d_lx);
+    dev_free(g->d_ly);
+    dev_free(g->up.d_order);
+    dev_free(g->down.d_order);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+static int upload_grid(vrt_grid *g)
+{
+    const int64_t n = g->n;
+    const size_t nnz = g->col.size();
+    int rc;
+    if ((rc = dev_alloc(&g->d_pos, (size_t)3 * n))) return rc;
+    if ((rc = dev_alloc(&g->d_rowptr, (size_t)n + 1))) return rc;
+    if ((rc = dev_alloc(&g->d_col, nnz))) return rc;
+    if ((rc = dev_alloc(&g->d_lz, nnz))) return rc;
+    if ((rc = dev_alloc(&g->d_lx, nnz))) return rc;
+    if ((rc = dev_alloc(&g->d_ly, nnz))) return rc;
+    VRT_HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    VRT_HIP_TRY(hipMemcpy(g->d_pos, g->pos.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+    VRT_HIP_TRY(hipMemcpy(g->d_rowptr, g->rowptr.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+    if (nnz)
+        VRT_HIP_TRY(hipMemcpy(g->d_col, g->col.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    for (int d = 0; d < 2; d++) {
+        Direction &dir = d == 0 ? g->up : g->down;
+        std::vector<int32_t> order((size_t)n);
+        for (int64_t i = 0; i < n; i++) order[(size_t)i] = (int32_t)(dir.perm[(size_t)i] - 1);
+        if ((rc = dev_alloc(&dir.d_order, (size_t)n))) return rc;
+        VRT_HIP_TRY(hipMemcpy(dir.d_order, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    }
+    if ((rc = launch_delaunay_lines(g))) return rc;
+    VRT_HIP_TRY(hipStreamSynchronize(g->stream));
+    return VRT_OK;
+}
+
+static int grid_create_impl(int64_t n, const double *pos, const int64_t *nbr, int64_t D1,
+                            const double bounds[6], int device, vrt_grid **out)
+{
+    if (!out) return fail(VRT_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!pos || !nbr || !bounds) return fail(VRT_EINVAL, "NULL argument");
+    int rc = device >= 0 ? use_device(device) : VRT_OK;   // device < 0: host-only handle
+    if (rc) return rc;
+    vrt_grid *g = new (std::nothrow) vrt_grid();
+    if (!g) return fail(VRT_ENOMEM, "out of host memory");
+    g->device = device;
+    rc = build_grid_host(g, n, pos, nbr, D1, bounds);
+    if (!rc && device >= 0) rc = upload_grid(g);
+    if (rc) {
+        free_grid(g);
+        return rc;
+    }
+    *out = g;
+    return VRT_OK;
+}
+
+static const Direction &direction_of(const vrt_grid *g, int dir) { return dir > 0 ? g->up : g->down; }
+
+static void free_plan(vrt_plan *p)
+{
+    if (!p) return;
+    dev_free(p->d_up1);
+    dev_free(p->d_up2);
+    dev_free(p->d_d1);
+    dev_free(p->d_d2);
+    dev_free(p->d_w1);
+    dev_free(p->d_w2);
+    dev_free(p->d_r1);
+    dev_free(p->d_r2);
+    dev_free(p->d_node_site);
+    dev_free(p->d_node_meta);
+    dev_free(p->d_angles_up);
+    dev_free(p->d_angles_down);
+    dev_free(p->d_I);
+    for (int i = 0; i < 5; i++) dev_free(p->d_stage[i]);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    delete p;
+}
+
+static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, const int *dirs,
+                            int n_sweeps, vrt_plan **out)
+{
+    if (!out) return fail(VRT_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!g || !k) return fail(VRT_EINVAL, "NULL argument");
+    if (n_angles < 1) return fail(VRT_EINVAL, "n_angles must be >= 1");
+    if (n_sweeps < 1) return fail(VRT_EINVAL, "n_sweeps must be >= 1");
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    vrt_plan *p = new (std::nothrow) vrt_plan();
+    if (!p) return fail(VRT_ENOMEM, "out of host memory");
+    p->g = g;
+    p->n_sweeps = n_sweeps;
+    p->n_angles_user = n_angles;
+    for (int64_t a = 0; a < n_angles; a++) {
+        const double *ka = k + 3 * a;
+        const double nrm = std::sqrt(ka[0] * ka[0] + ka[1] * ka[1] + ka[2] * ka[2]);
+        if (!(std::fabs(nrm - 1.0) < 1e-6)) {   // functions.jl:432 asserts norm(k) ≈ 1
+            free_plan(p);
+            return fail(VRT_EINVAL, "direction " + std::to_string(a + 1) + " is not a unit vector");
+        }
+        int d = dirs ? (dirs[a] > 0 ? 1 : (dirs[a] < 0 ? -1 : 0))
+                     : (ka[0] < 0 ? 1 : (ka[0] > 0 ? -1 : 0));   // θ>90 up, θ<90 down, θ=90 skipped
+        if (d == 0) continue;
+        p->user_of_active.push_back((int)a);
+        p->dir_of_active.push_back(d);
+        p->k.insert(p->k.end(), ka, ka + 3);
+    }
+    p->A = (int)p->user_of_active.size();
+    if (p->A > kMaxAngles) {
+        free_plan(p);
+        return fail(VRT_EINVAL, "more than 64 active angles in one plan");
+    }
+    const int64_t n = g->n;
+    const int A = p->A;
+    const size_t tab = (size_t)A * (size_t)n;
+#define VRT_TRY_FREE(expr)      \
+    do {                        \
+        int _rc = (expr);       \
+        if (_rc) {              \
+            free_plan(p);       \
+            return _rc;         \
+        }                       \
+    } while (0)
+#define VRT_HIP_TRY_FREE(expr)                                                             \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            free_plan(p);                                                                  \
+            return fail(VRT_ENODEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+        }                                                                                  \
+    } while (0)
+    VRT_TRY_FREE(dev_alloc(&p->d_up1, tab));
+    VRT_TRY_FREE(dev_alloc(&p->d_up2, tab));
+    VRT_TRY_FREE(dev_alloc(&p->d_d1, tab));
+    VRT_TRY_FREE(dev_alloc(&p->d_d2, tab));
+    VRT_TRY_FREE(dev_alloc(&p->d_w1, tab));
+    VRT_TRY_FREE(dev_alloc(&p->d_w2, tab));
+    VRT_TRY_FREE(dev_alloc(&p->d_r1, tab));
+    VRT_TRY_FREE(dev_alloc(&p->d_r2, tab));
+    VRT_HIP_TRY_FREE(hipEventCreate(&p->ev0));
+    VRT_HIP_TRY_FREE(hipEventCreate(&p->ev1));
+    for (int a = 0; a < A; a++) VRT_TRY_FREE(launch_upwind_table(p, a));
+    std::vector<int32_t> up1(tab), up2(tab);
+    VRT_HIP_TRY_FREE(hipStreamSynchronize(g->stream));
+    if (tab) {
+        VRT_HIP_TRY_FREE(hipMemcpy(up1.data(), p->d_up1, sizeof(int32_t) * tab, hipMemcpyDeviceToHost));
+        VRT_HIP_TRY_FREE(hipMemcpy(up2.data(), p->d_up2, sizeof(int32_t) * tab, hipMemcpyDeviceToHost));
+    }
+
+    // per-angle schedules, built concurrently on the host
+    std::vector<AngleSchedule> sched((size_t)A);
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int nthr = (int)std::min<unsigned>(hw ? hw : 4, 16);
+        nthr = std::max(1, std::min(nthr, A));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; t++)
+            pool.emplace_back([&, t]() {
+                for (int a = t; a < A; a += nthr) {
+                    const bool up = p->dir_of_active[(size_t)a] > 0;
+                    build_angle_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
+                                         up1.data() + (size_t)a * n, up2.data() + (size_t)a * n,
+                                         sched[(size_t)a]);
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    int64_t max_levels = 0, total = 0;
+    for (int a = 0; a < A; a++) {
+        if (sched[(size_t)a].bad_site >= 0) {
+            std::string msg = "site " + std::to_string(sched[(size_t)a].bad_site + 1) +
+                              " has no neighbour with k . line > -1 for angle " +
+                              std::to_string(p->user_of_active[(size_t)a] + 1) +
+                              " (the reference reads an uninitialised index here)";
+            free_plan(p);
+            return fail(VRT_EGRID, msg);
+        }
+        max_levels = std::max<int64_t>(max_levels, (int64_t)sched[(size_t)a].level_off.size() - 1);
+        total += (int64_t)sched[(size_t)a].site.size();
+    }
+    // merge: global level t = union over the angles of their level t
+    std::vector<uint32_t> node_site((size_t)total), node_meta((size_t)total);
+    p->level_off.assign((size_t)max_levels + 1, 0);
+    int64_t at = 0;
+    for (int64_t t = 0; t < max_levels; t++) {
+        p->level_off[(size_t)t] = at;
+        for (int a = 0; a < A; a++) {
+            const AngleSchedule &s = sched[(size_t)a];
+            if (t + 1 >= (int64_t)s.level_off.size()) continue;
+            for (int64_t x = s.level_off[(size_t)t]; x < s.level_off[(size_t)t + 1]; x++) {
+                node_site[(size_t)at] = s.site[(size_t)x];
+                node_meta[(size_t)at] = (uint32_t)a | ((uint32_t)s.zflags[(size_t)x] << 8);
+                at++;
+            }
+        }
+    }
+    p->level_off[(size_t)max_levels] = at;
+    p->n_nodes = total;
+    VRT_TRY_FREE(dev_alloc(&p->d_node_site, (size_t)total));
+    VRT_TRY_FREE(dev_alloc(&p->d_node_meta, (size_t)total));
+    if (total) {
+        VRT_HIP_TRY_FREE(hipMemcpy(p->d_node_site, node_site.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
+        VRT_HIP_TRY_FREE(hipMemcpy(p->d_node_meta, node_meta.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
+    }
+    std::vector<int32_t> ups, downs;
+    for (int a = 0; a < A; a++) (p->dir_of_active[(size_t)a] > 0 ? ups : downs).push_back(a);
+    p->n_up = (int)ups.size();
+    p->n_down = (int)downs.size();
+    VRT_TRY_FREE(dev_alloc(&p->d_angles_up, ups.size()));
+    VRT_TRY_FREE(dev_alloc(&p->d_angles_down, downs.size()));
+    if (!ups.empty())
+        VRT_HIP_TRY_FREE(hipMemcpy(p->d_angles_up, ups.data(), sizeof(int32_t) * ups.size(), hipMemcpyHostToDevice));
+    if (!downs.empty())
+        VRT_HIP_TRY_FREE(hipMemcpy(p->d_angles_down, downs.data(), sizeof(int32_t) * downs.size(), hipMemcpyHostToDevice));
+#undef VRT_TRY_FREE
+#undef VRT_HIP_TRY_FREE
+    *out = p;
+    return VRT_OK;
+}
+
+static int ensure(double *&buf, size_t &cap, size_t count)
+{
+    if (count <= cap && buf) return VRT_OK;
+    dev_free(buf);
+    cap = 0;
+    int rc = dev_alloc(&buf, count);
+    if (rc) return rc;
+    cap = count;
+    return VRT_OK;
+}
+
+static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS,
+                              const double *dalpha, int alpha_mode, const double *dI0_up,
+                              const double *dI0_down, const double *weights, double *dJ,
+                              double *dI_out, hipStream_t st)
+{
+    vrt_grid *g = p->g;
+    if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
+    if (!dS || !dalpha) return fail(VRT_EINVAL, "S and alpha must not be NULL");
+    if (alpha_mode < 0 || alpha_mode > 2) return fail(VRT_EINVAL, "bad alpha_mode");
+    if (dJ && !weights) return fail(VRT_EINVAL, "weights must be given when J is requested");
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    const int64_t n = g->n;
+    const size_t need = (size_t)std::max(1, p->A) * (size_t)n * (size_t)nlam;
+    if ((rc = ensure(p->d_I, p->I_cap, need))) return rc;
+    p->I_ld = nlam;
+    SweepArgs sa;
+    sa.n = n;
+    sa.nlam = nlam;
+    sa.ldS = ld;
+    sa.ldA = alpha_mode == VRT_ALPHA_SITE ? 1 : ld;
+    sa.ldI = nlam;
+    sa.S = dS;
+    sa.alpha = dalpha;
+    sa.alpha_mode = alpha_mode;
+    sa.I = p->d_I;
+    // the user's per-angle alpha is indexed by USER angle; the plan's by active angle.  They
+    // coincide unless a θ = 90 direction was skipped, which per-angle alpha does not support.
+    if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM && p->A != (int)p->n_angles_user)
+        return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
+    if ((rc = launch_boundary(p, sa, dI0_up, dI0_down, st))) return rc;
+    VRT_HIP_TRY(hipEventRecord(p->ev0, st));
+    if ((rc = launch_sweep_levels(p, sa, st, &p->last_launches))) return rc;
+    VRT_HIP_TRY(hipEventRecord(p->ev1, st));
+    p->ev_valid = true;
+    if (dJ) {
+        double wact[kMaxAngles];
+        for (int a = 0; a < p->A; a++) wact[a] = weights[p->user_of_active[(size_t)a]];
+        if ((rc = launch_reduce_J(p, sa, wact, dJ, ld, st))) return rc;
+    }
+    if (dI_out && (rc = launch_copy_I_out(p, sa, dI_out, ld, st))) return rc;
+    return VRT_OK;
+}
+
+}  // namespace vrt
+
+using namespace vrt;
+
+extern "C" {
+
+const char *vrt_last_error(void) { return g_err.c_str(); }
+
+int vrt_version(void) { return 100; }
+
+int vrt_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int vrt_grid_create(int64_t n, const double *pos_zxy, const int64_t *nbr, int64_t D1,
+                    const double bounds[6], int device, vrt_grid **out)
+{
+    try {
+        return grid_create_impl(n, pos_zxy, nbr, D1, bounds, device, out);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_grid_create_from_file(const char *neighbours_file, int64_t n, const double *pos_zxy,
+                              const double bounds[6], int device, vrt_grid **out)
+{
+    try {
+        if (!neighbours_file) return fail(VRT_EINVAL, "NULL file name");
+        if (n < 1) return fail(VRT_EINVAL, "n must be positive");
+        std::vector<int64_t> M;
+        int64_t D1 = 0;
+        int rc = parse_neighbour_file(neighbours_file, n, M, D1);
+        if (rc) return rc;
+        return grid_create_impl(n, pos_zxy, M.data(), D1, bounds, device, out);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+void vrt_grid_destroy(vrt_grid *g)
+{
+    if (g && g->device >= 0) (void)hipSetDevice(g->device);
+    free_grid(g);
+}
+
+int64_t vrt_grid_n(const vrt_grid *g) { return g ? g->n : 0; }
+int64_t vrt_grid_max_neighbours(const vrt_grid *g) { return g ? g->D : 0; }
+int64_t vrt_grid_num_layer_offsets(const vrt_grid *g, int dir)
+{
+    return g ? (int64_t)direction_of(g, dir).reduced.size() : 0;
+}
+
+int vrt_grid_get_layers(const vrt_grid *g, int dir, int64_t *out)
+{
+    if (!g || !out) return fail(VRT_EINVAL, "NULL argument");
+    const Direction &d = direction_of(g, dir);
+    std::copy(d.reduced.begin(), d.reduced.end(), out);
+    return VRT_OK;
+}
+
+int vrt_grid_get_perm(const vrt_grid *g, int dir, int64_t *out)
+{
+    if (!g || !out) return fail(VRT_EINVAL, "NULL argument");
+    const Direction &d = direction_of(g, dir);
+    std::copy(d.perm.begin(), d.perm.end(), out);
+    return VRT_OK;
+}
+
+int vrt_grid_get_delaunay_lines(const vrt_grid *g, double *out)
+{
+    if (!g || !out) return fail(VRT_EINVAL, "NULL argument");
+    try {
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        const size_t nnz = g->col.size();
+        std::vector<double> lz(nnz), lx(nnz), ly(nnz);
+        if (nnz) {
+            VRT_HIP_TRY(hipMemcpy(lz.data(), g->d_lz, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+            VRT_HIP_TRY(hipMemcpy(lx.data(), g->d_lx, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+            VRT_HIP_TRY(hipMemcpy(ly.data(), g->d_ly, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+        }
+        const int64_t D = g->D;
+        std::fill(out, out + (size_t)3 * (size_t)D * (size_t)g->n, 0.0);
+        for (int64_t i = 0; i < g->n; i++)
+            for (int32_t e = g->rowptr[(size_t)i]; e < g->rowptr[(size_t)i + 1]; e++) {
+                const int64_t j = e - g->rowptr[(size_t)i];
+                double *o = out + 3 * ((size_t)j + (size_t)D * (size_t)i);
+                o[0] = lz[(size_t)e];
+                o[1] = lx[(size_t)e];
+                o[2] = ly[(size_t)e];
+            }
+        return VRT_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    }
+}
+
+void vrt_direction(double theta_deg, double phi_deg, double k[3])
+{
+    // lambda_iteration.jl:87: degrees -> radians as θ*π/180
+    const double pi = 3.14159265358979323846;
+    const double th = theta_deg * pi / 180, ph = phi_deg * pi / 180;
+    k[0] = std::cos(th);
+    k[1] = std::cos(ph) * std::sin(th);
+    k[2] = std::sin(ph) * std::sin(th);
+}
+
+int vrt_plan_create_ex(vrt_grid *g, int64_t n_angles, const double *k, const int *dirs,
+                       int n_sweeps, vrt_plan **out)
+{
+    try {
+        return plan_create_impl(g, n_angles, k, dirs, n_sweeps, out);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_plan_create(vrt_grid *g, int64_t n_angles, const double *k, int n_sweeps, vrt_plan **out)
+{
+    return vrt_plan_create_ex(g, n_angles, k, nullptr, n_sweeps, out);
+}
+
+void vrt_plan_destroy(vrt_plan *p)
+{
+    if (p && p->g) (void)hipSetDevice(p->g->device);
+    free_plan(p);
+}
+
+int64_t vrt_plan_num_levels(const vrt_plan *p) { return p ? (int64_t)p->level_off.size() - 1 : 0; }
+int64_t vrt_plan_num_nodes(const vrt_plan *p) { return p ? p->n_nodes : 0; }
+
+int vrt_plan_get_upwind(const vrt_plan *p, int64_t angle, int64_t *up, double *dots, double *w,
+                        double *r)
+{
+    if (!p) return fail(VRT_EINVAL, "NULL plan");
+    if (angle < 0 || angle >= p->n_angles_user) return fail(VRT_EINVAL, "angle out of range");
+    int a = -1;
+    for (int i = 0; i < p->A; i++)
+        if (p->user_of_active[(size_t)i] == (int)angle) a = i;
+    if (a < 0) return fail(VRT_EINVAL, "angle is skipped (θ = 90) and has no table");
+    try {
+        int rc = use_device(p->g->device);
+        if (rc) return rc;
+        const int64_t n = p->g->n;
+        const size_t o = (size_t)a * (size_t)n;
+        std::vector<int32_t> a1((size_t)n), a2((size_t)n);
+        std::vector<double> x1((size_t)n), x2((size_t)n);
+        if (up) {
+            VRT_HIP_TRY(hipMemcpy(a1.data(), p->d_up1 + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            VRT_HIP_TRY(hipMemcpy(a2.data(), p->d_up2 + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; i++) {
+                up[2 * i] = a1[(size_t)i] < 0 ? 0 : (int64_t)a1[(size_t)i] + 1;
+                up[2 * i + 1] = a2[(size_t)i] < 0 ? 0 : (int64_t)a2[(size_t)i] + 1;
+            }
+        }
+        const double *src1[3] = {p->d_d1, p->d_w1, p->d_r1};
+        const double *src2[3] = {p->d_d2, p->d_w2, p->d_r2};
+        double *dst[3] = {dots, w, r};
+        for (int q = 0; q < 3; q++) {
+            if (!dst[q]) continue;
+            VRT_HIP_TRY(hipMemcpy(x1.data(), src1[q] + o, sizeof(double) * n, hipMemcpyDeviceToHost));
+            VRT_HIP_TRY(hipMemcpy(x2.data(), src2[q] + o, sizeof(double) * n, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; i++) {
+                dst[q][2 * i] = x1[(size_t)i];
+                dst[q][2 * i + 1] = x2[(size_t)i];
+            }
+        }
+        return VRT_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    }
+}
+
+struct vrt_schedule {
+    vrt::AngleSchedule s;
+};
+
+int vrt_schedule_build(const vrt_grid *g, int dir, const int64_t *up, int n_sweeps, vrt_schedule **out)
+{
+    if (!g || !up || !out) return fail(VRT_EINVAL, "NULL argument");
+    if (n_sweeps < 1) return fail(VRT_EINVAL, "n_sweeps must be >= 1");
+    *out = nullptr;
+    try {
+        const int64_t n = g->n;
+        std::vector<int32_t> u1((size_t)n), u2((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t a = up[2 * i], b = up[2 * i + 1];
+            if (a > n || b > n) return fail(VRT_EINVAL, "upwind id out of range");
+            u1[(size_t)i] = a >= 1 ? (int32_t)(a - 1) : kNoUpwind;
+            u2[(size_t)i] = b >= 1 ? (int32_t)(b - 1) : kNoUpwind;
+        }
+        vrt_schedule *sc = new vrt_schedule();
+        build_angle_schedule(direction_of(g, dir), dir > 0, n, n_sweeps, u1.data(), u2.data(), sc->s);
+        if (sc->s.bad_site >= 0) {
+            std::string msg = "site " + std::to_string(sc->s.bad_site + 1) + " has no upwind neighbour";
+            delete sc;
+            return fail(VRT_EGRID, msg);
+        }
+        *out = sc;
+        return VRT_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    }
+}
+
+int64_t vrt_schedule_num_nodes(const vrt_schedule *s) { return s ? (int64_t)s->s.site.size() : 0; }
+int64_t vrt_schedule_num_levels(const vrt_schedule *s) { return s ? (int64_t)s->s.level_off.size() - 1 : 0; }
+
+int vrt_schedule_get(const vrt_schedule *s, int64_t *site, int32_t *zflags, int64_t *level_off)
+{
+    if (!s) return fail(VRT_EINVAL, "NULL schedule");
+    if (site)
+        for (size_t i = 0; i < s->s.site.size(); i++) site[i] = (int64_t)s->s.site[i] + 1;
+    if (zflags)
+        for (size_t i = 0; i < s->s.zflags.size(); i++) zflags[i] = s->s.zflags[i];
+    if (level_off) std::copy(s->s.level_off.begin(), s->s.level_off.end(), level_off);
+    return VRT_OK;
+}
+
+void vrt_schedule_destroy(vrt_schedule *s) { delete s; }
+
+int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS,
+                         const double *dalpha, int alpha_mode, const double *dI0_up,
+                         const double *dI0_down, const double *weights_host, double *dJ,
+                         double *dI_out, void *stream)
+{
+    if (!p) return fail(VRT_EINVAL, "NULL plan");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        return execute_dev_locked(p, nlam, ld, dS, dalpha, alpha_mode, dI0_up, dI0_down,
+                                  weights_host, dJ, dI_out, (hipStream_t)stream);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_plan_execute(vrt_plan *p, int64_t nlam, int64_t ld, const double *S, const double *alpha,
+                     int alpha_mode, const double *I0_up, const double *I0_down,
+                     const double *weights, double *J, double *I_out)
+{
+    if (!p) return fail(VRT_EINVAL, "NULL plan");
+    if (!S || !alpha) return fail(VRT_EINVAL, "S and alpha must not be NULL");
+    if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
+    if (alpha_mode < 0 || alpha_mode > 2) return fail(VRT_EINVAL, "bad alpha_mode");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        vrt_grid *g = p->g;
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        const size_t n = (size_t)g->n;
+        const size_t nS = n * (size_t)ld;
+        const size_t nA = alpha_mode == VRT_ALPHA_SITE ? n
+                          : alpha_mode == VRT_ALPHA_SITE_LAM ? nS
+                                                             : nS * (size_t)p->n_angles_user;
+        const size_t nU = (size_t)g->up.n1 * (size_t)nlam, nD = (size_t)g->down.n1 * (size_t)nlam;
+        hipStream_t st = g->stream;
+        if ((rc = ensure(p->d_stage[0], p->stage_cap[0], nS))) return rc;
+        if ((rc = ensure(p->d_stage[1], p->stage_cap[1], nA))) return rc;
+        VRT_HIP_TRY(hipMemcpyAsync(p->d_stage[0], S, sizeof(double) * nS, hipMemcpyHostToDevice, st));
+        VRT_HIP_TRY(hipMemcpyAsync(p->d_stage[1], alpha, sizeof(double) * nA, hipMemcpyHostToDevice, st));
+        double *dU = nullptr, *dD = nullptr, *dJ = nullptr;
+        if (I0_up && nU) {
+            if ((rc = ensure(p->d_stage[2], p->stage_cap[2], nU))) return rc;
+            dU = p->d_stage[2];
+            VRT_HIP_TRY(hipMemcpyAsync(dU, I0_up, sizeof(double) * nU, hipMemcpyHostToDevice, st));
+        }
+        if (I0_down && nD) {
+            if ((rc = ensure(p->d_stage[3], p->stage_cap[3], nD))) return rc;
+            dD = p->d_stage[3];
+            VRT_HIP_TRY(hipMemcpyAsync(dD, I0_down, sizeof(double) * nD, hipMemcpyHostToDevice, st));
+        }
+        if (J) {
+            if ((rc = ensure(p->d_stage[4], p->stage_cap[4], nS))) return rc;
+            dJ = p->d_stage[4];
+        }
+        rc = execute_dev_locked(p, nlam, ld, p->d_stage[0], p->d_stage[1], alpha_mode, dU, dD,
+                                weights, dJ, nullptr, st);
+        if (rc) return rc;
+        if (J) VRT_HIP_TRY(hipMemcpyAsync(J, dJ, sizeof(double) * nS, hipMemcpyDeviceToHost, st));
+        if (I_out) {
+            // (nlam, n, n_angles): the internal array is dense [A][n][nlam]
+            for (int64_t u = 0; u < p->n_angles_user; u++) {
+                int a = -1;
+                for (int i = 0; i < p->A; i++)
+                    if (p->user_of_active[(size_t)i] == (int)u) a = i;
+                double *dst = I_out + (size_t)u * nS;
+                if (a < 0) {
+                    std::fill(dst, dst + nS, 0.0);
+                    continue;
+                }
+                VRT_HIP_TRY(hipMemcpy2DAsync(dst, sizeof(double) * (size_t)ld,
+                                             p->d_I + (size_t)a * n * (size_t)nlam,
+                                             sizeof(double) * (size_t)nlam,
+                                             sizeof(double) * (size_t)nlam, n,
+                                             hipMemcpyDeviceToHost, st));
+            }
+        }
+        VRT_HIP_TRY(hipStreamSynchronize(st));
+        return VRT_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches)
+{
+    if (!p) return fail(VRT_EINVAL, "NULL plan");
+    if (!p->ev_valid) return fail(VRT_EINVAL, "no execute has run on this plan yet");
+    VRT_HIP_TRY(hipEventSynchronize(p->ev1));
+    float t = 0.f;
+    VRT_HIP_TRY(hipEventElapsedTime(&t, p->ev0, p->ev1));
+    if (ms) *ms = (double)t;
+    if (launches) *launches = p->last_launches;
+    return VRT_OK;
+}
+
+static int single_solve(vrt_grid *g, int dir, const double k[3], const double *S, const double *I0,
+                        int64_t nI0, const double *alpha, int n_sweeps, double *I_out)
+{
+    if (!g || !k || !S || !alpha || !I_out) return fail(VRT_EINVAL, "NULL argument");
+    const Direction &d = direction_of(g, dir);
+    if (nI0 != d.n1)   // Julia: DimensionMismatch at irregular_ray_tracing.jl:35 / :116
+        return fail(VRT_EINVAL, "I_0 has " + std::to_string(nI0) + " elements, the boundary layer has " +
+                                    std::to_string(d.n1));
+    if (nI0 > 0 && !I0) return fail(VRT_EINVAL, "I_0 is NULL");
+    try {
+        vrt_plan *plan = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g->mu);
+            for (PlanCacheEntry *c : g->cache)
+                if (c->n_sweeps == n_sweeps * dir && c->k[0] == k[0] && c->k[1] == k[1] && c->k[2] == k[2])
+                    plan = c->plan;
+            if (!plan) {
+                int dirs[1] = {dir};
+                int rc = plan_create_impl(g, 1, k, dirs, n_sweeps, &plan);
+                if (rc) return rc;
+                if (g->cache.size() >= 64) {   // drop the oldest entry
+                    vrt_plan_destroy(g->cache.front()->plan);
+                    delete g->cache.front();
+                    g->cache.erase(g->cache.begin());
+                }
+                PlanCacheEntry *c = new PlanCacheEntry{{k[0], k[1], k[2]}, n_sweeps * dir, plan};
+                g->cache.push_back(c);
+            }
+        }
+        const double one = 1.0;
+        // I_out doubles as J with weight 1: J = 0 + 1*I is exact
+        return vrt_plan_execute(plan, 1, 1, S, alpha, VRT_ALPHA_SITE, dir > 0 ? I0 : nullptr,
+                                dir > 0 ? nullptr : I0, &one, I_out, nullptr);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_delaunay_up(vrt_grid *g, const double k[3], const double *S, const double *I0, int64_t nI0,
+                    const double *alpha, int n_sweeps, double *I_out)
+{
+    return single_solve(g, +1, k, S, I0, nI0, alpha, n_sweeps, I_out);
+}
+
+int vrt_delaunay_down(vrt_grid *g, const double k[3], const double *S, const double *I0,
+                      int64_t nI0, const double *alpha, int n_sweeps, double *I_out)
+{
+    return single_solve(g, -1, k, S, I0, nI0, alpha, n_sweeps, I_out);
+}
+
+}  // extern "C"

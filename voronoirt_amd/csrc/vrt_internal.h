@@ -1,0 +1,135 @@
+// Internal declarations of libvrt_hip.so (not part of the C ABI; see include/voronoirt.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "voronoirt.h"
+
+namespace vrt {
+
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define VRT_HIP_TRY(expr)                                                                  \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return ::vrt::fail(VRT_ENODEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+constexpr int kMaxAngles = 64;          // active angles per plan (kernel-argument weight table)
+constexpr int64_t kMaxGuess = 70;       // read_cell's neighbour cap, voronoi_utils.jl:42
+constexpr int32_t kNoUpwind = -1;
+
+// One sweep direction of the grid (up: from the z_min wall, down: from the z_max wall).
+struct Direction {
+    std::vector<int32_t> layer_of;   // BFS layer per site, 1-based (voronoi_utils.jl:93-174)
+    std::vector<int64_t> perm;       // stable sortperm, 1-based site ids (:72,77)
+    std::vector<int64_t> reduced;    // reduce_layers offsets, 1-based, r[end] = n (:253-269)
+    int64_t n1 = 0;                  // reduced[1] - 1: sites that receive I_0
+    int32_t *d_order = nullptr;      // device copy of perm, 0-based int32
+};
+
+struct PlanCacheEntry;
+
+}  // namespace vrt
+
+struct vrt_grid {
+    int device = 0;
+    int64_t n = 0;
+    int64_t D = 0;                   // maximum(neighbours[:,1])
+    double bounds[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<double> pos;         // (3, n) z,x,y
+    std::vector<int32_t> rowptr;     // CSR over the neighbour lists, n+1
+    std::vector<int32_t> col;        // 1-based ids, walls <= 0, row order preserved
+    vrt::Direction up, down;
+    // device mirrors
+    double *d_pos = nullptr;
+    int32_t *d_rowptr = nullptr;
+    int32_t *d_col = nullptr;
+    double *d_lz = nullptr, *d_lx = nullptr, *d_ly = nullptr;   // Delaunay lines, CSR-packed SoA
+    hipStream_t stream = nullptr;
+    // cache of single-angle plans for vrt_delaunay_up/down
+    std::mutex mu;
+    std::vector<vrt::PlanCacheEntry *> cache;
+};
+
+struct vrt_plan {
+    vrt_grid *g = nullptr;
+    int n_sweeps = 3;
+    int64_t n_angles_user = 0;
+    int A = 0;                          // active angles (k[0] != 0)
+    std::vector<int> user_of_active;    // active index -> user angle index
+    std::vector<int> dir_of_active;     // +1 up, -1 down
+    std::vector<double> k;              // (3, A)
+    // per-angle upwind tables, [A][n]
+    int32_t *d_up1 = nullptr, *d_up2 = nullptr;     // 0-based ids, kNoUpwind if none
+    double *d_d1 = nullptr, *d_d2 = nullptr;         // dot products (smallest_angle's `dots`)
+    double *d_w1 = nullptr, *d_w2 = nullptr;         // dot_weights, irregular_ray_tracing.jl:51
+    double *d_r1 = nullptr, *d_r2 = nullptr;         // euclidean path lengths, :66
+    // level schedule, merged over the active angles
+    uint32_t *d_node_site = nullptr;    // site id (0-based)
+    uint32_t *d_node_meta = nullptr;    // active angle | zero-read flags
+    std::vector<int64_t> level_off;     // nodes of level t are [level_off[t], level_off[t+1])
+    int64_t n_nodes = 0;
+    // per-direction lists of active angle indices (for the boundary kernel)
+    int32_t *d_angles_up = nullptr, *d_angles_down = nullptr;
+    int n_up = 0, n_down = 0;
+    std::vector<int64_t> skip_site;     // per active angle: never-updated site perm[n] (0-based)
+    // workspaces (grow-only)
+    double *d_I = nullptr;
+    size_t I_cap = 0;
+    int64_t I_ld = 0;
+    double *d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // S, alpha, I0up, I0down, J
+    size_t stage_cap[5] = {0, 0, 0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    int64_t last_launches = 0;
+    std::mutex mu;
+};
+
+namespace vrt {
+
+struct PlanCacheEntry {
+    double k[3];
+    int n_sweeps;
+    vrt_plan *plan;
+};
+
+// ---- host-side grid preparation (vrt_grid.cpp) ---------------------------------------------
+int parse_neighbour_file(const char *path, int64_t n, std::vector<int64_t> &matrix, int64_t &D1);
+int build_grid_host(vrt_grid *g, int64_t n, const double *pos, const int64_t *nbr, int64_t D1,
+                    const double bounds[6]);
+
+// ---- schedule (vrt_schedule.cpp) -------------------------------------------------------------
+struct AngleSchedule {
+    std::vector<uint32_t> site;      // live nodes sorted by level
+    std::vector<uint8_t> zflags;     // bit0: I(upwind 1) reads as zero, bit1: upwind 2
+    std::vector<int64_t> level_off;  // per-angle level offsets (level 1 first)
+    int64_t bad_site = -1;           // visited site without an upwind neighbour
+};
+void build_angle_schedule(const Direction &dir, bool ascending, int64_t n, int n_sweeps,
+                          const int32_t *up1, const int32_t *up2, AngleSchedule &out);
+
+// ---- device launchers (vrt_kernels.hip) ------------------------------------------------------
+int launch_delaunay_lines(vrt_grid *g);
+int launch_upwind_table(vrt_plan *p, int a);
+struct SweepArgs {
+    int64_t n, nlam, ldS, ldA, ldI;
+    const double *S, *alpha;
+    int alpha_mode;
+    double *I;
+};
+int launch_boundary(vrt_plan *p, const SweepArgs &sa, const double *dI0_up, const double *dI0_down,
+                    hipStream_t st);
+int launch_sweep_levels(vrt_plan *p, const SweepArgs &sa, hipStream_t st, int64_t *launches);
+int launch_reduce_J(vrt_plan *p, const SweepArgs &sa, const double *weights_active, double *dJ,
+                    int64_t ldJ, hipStream_t st);
+int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, double *dI_out, int64_t ldO, hipStream_t st);
+
+}  // namespace vrt

@@ -1,0 +1,410 @@
+// HIP kernels for gfx950 (CDNA4, wave64) and their launchers.
+//
+// Floating-point contract (shared with oracle/vrt_oracle.c): this file is compiled with
+// -ffp-contract=off, every expression is evaluated left to right as the reference writes it, so
+// the integer results (upwind neighbour ids) agree bit for bit with the CPU oracle; fp64
+// division and sqrt are correctly rounded on the device, exp/pow are within 1 ulp.
+//
+// No MFMA anywhere: the path is gather + exp + a handful of multiplies per (site, wavelength).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "vrt_internal.h"
+
+namespace vrt {
+
+// --------------------------------------------------------------------------------------------
+// Delaunay lines, src/voronoi_utils.jl:186-245: unit vectors site -> neighbour with the
+// reference's periodic-image rule (shift on the right edge :219-220, MIRROR on the left
+// :221-222).  CSR-packed SoA (lz, lx, ly), one entry per neighbour slot; wall slots get 0.
+// One 16-lane group per site so the CSR row is read/written contiguously.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_delaunay_lines(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                 const double *__restrict__ pos, double x_min, double x_max, double y_min,
+                 double y_max, double *__restrict__ lz, double *__restrict__ lx,
+                 double *__restrict__ ly)
+{
+    const int lane16 = threadIdx.x & 15;
+    const int64_t site = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (site >= n) return;
+    const double pz = pos[3 * site + 0], px = pos[3 * site + 1], py = pos[3 * site + 2];
+    const double x_r_r = x_max - px, x_r_l = px - x_min;   // :200-201
+    const double y_r_r = y_max - py, y_r_l = py - y_min;   // :203-204
+    const int beg = rowptr[site], end = rowptr[site + 1];
+    for (int e = beg + lane16; e < end; e += 16) {
+        const int id = col[e];
+        double oz = 0.0, ox = 0.0, oy = 0.0;
+        if (id > 0) {
+            const int64_t q = id - 1;
+            const double qz = pos[3 * q + 0];
+            double qx = pos[3 * q + 1], qy = pos[3 * q + 2];
+            const double x_i_r = fabs(x_max - qx), x_i_l = fabs(qx - x_min);   // :215-216
+            if (x_r_r + x_i_l < px - qx) qx = x_max + qx - x_min;              // :219-220
+            else if (x_r_l + x_i_r < qx - px) qx = x_min + x_max - qx;         // :221-222
+            const double y_i_r = fabs(y_max - qy), y_i_l = fabs(qy - y_min);
+            if (y_r_r + y_i_l < py - qy) qy = y_max + qy - y_min;              // :229-230
+            else if (y_r_l + y_i_r < qy - py) qy = y_min + y_max - qy;         // :231-232
+            const double dz = qz - pz, dx = qx - px, dy = qy - py;             // :235
+            const double nrm = sqrt((dz * dz + dx * dx) + dy * dy);            // :237
+            oz = dz / nrm;
+            ox = dx / nrm;
+            oy = dy / nrm;
+        }
+        lz[e] = oz;
+        lx[e] = ox;
+        ly[e] = oy;
+    }
+}
+
+int launch_delaunay_lines(vrt_grid *g)
+{
+    const int64_t threads = g->n * 16;
+    const int64_t blocks = (threads + 255) / 256;
+    hipLaunchKernelGGL(k_delaunay_lines, dim3((unsigned)blocks), dim3(256), 0, g->stream, g->n,
+                       g->d_rowptr, g->d_col, g->d_pos, g->bounds[2], g->bounds[3], g->bounds[4],
+                       g->bounds[5], g->d_lz, g->d_lx, g->d_ly);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// Upwind ("smallest angle") search, src/voronoi_utils.jl:360-396, hoisted out of the sweep:
+// it depends on (site, direction) only.  One 16-lane group per site (4 sites per wave64); the
+// neighbour row is visited 16 slots at a time IN FILE ORDER and the reference's order-dependent
+// rule is evaluated in closed form per chunk:
+//   running best before slot j:  R_j = max(D1, d_0 .. d_{j-1})          (16-lane prefix max)
+//   slot j is a record  <=>  d_j > R_j   -> the LAST record (= first arg-max, found with a
+//                                           wave ballot) becomes slot 1; earlier records are
+//                                           discarded, not demoted (:379-381)
+//   non-records compete for slot 2 with strict '>', so the FIRST arg-max among them that beats
+//                                           the incoming D2 wins (:382-385)
+// then `dots[2] <= 0 -> 0, indices[2] = indices[1]` (:390-393), the weights
+// dots^7 / sum(dots^7) (irregular_ray_tracing.jl:51) and the un-wrapped path lengths (:66).
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned group_bits(unsigned long long ballot, int group)
+{
+    return (unsigned)((ballot >> (group * 16)) & 0xFFFFull);
+}
+
+__global__ void __launch_bounds__(256)
+k_upwind_table(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+               const double *__restrict__ lz, const double *__restrict__ lx,
+               const double *__restrict__ ly, const double *__restrict__ pos, double k0, double k1,
+               double k2, int32_t *__restrict__ up1, int32_t *__restrict__ up2,
+               double *__restrict__ d1o, double *__restrict__ d2o, double *__restrict__ w1o,
+               double *__restrict__ w2o, double *__restrict__ r1o, double *__restrict__ r2o)
+{
+    const int lane16 = threadIdx.x & 15;
+    const int group = (threadIdx.x & 63) >> 4;
+    const int64_t gsite = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool in_range = gsite < n;
+    const int64_t site = in_range ? gsite : n - 1;   // keep every lane in the shuffles
+    const int beg = rowptr[site], end = rowptr[site + 1];
+    // all four groups of the wave iterate the same number of chunks (wave-uniform loop bound)
+    int chunks = (end - beg + 15) >> 4;
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) chunks = max(chunks, __shfl_xor(chunks, off, 64));
+
+    double D1 = -1.0, D2 = -1.0;   // :365-366
+    int i1 = 0, i2 = 0;            // 1-based ids, 0 = unset (:368 undef)
+    for (int c = 0; c < chunks; c++) {
+        const int e = beg + c * 16 + lane16;
+        int id = 0;
+        double d = -INFINITY;
+        if (e < end) {
+            id = col[e];
+            if (id > 0) {                                                  // :371
+                d = (k0 * lz[e] + k1 * lx[e]) + k2 * ly[e];                // :376, no FMA
+                if (!(d == d)) d = -INFINITY;                              // NaN never passes '>'
+            }
+        }
+        const bool valid = d > -INFINITY;
+        // inclusive prefix max over the 16 lanes of the group
+        double incl = d;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const double t = __shfl_up(incl, off, 16);
+            if (lane16 >= off) incl = fmax(incl, t);
+        }
+        double excl = __shfl_up(incl, 1, 16);
+        if (lane16 == 0) excl = -INFINITY;
+        const double R = fmax(D1, excl);
+        const bool rec = valid && (d > R);
+        const bool nonrec = valid && !rec;
+        const double cmax = __shfl(incl, 15, 16);          // chunk maximum
+        // slot 2 candidates: maximum over the non-records
+        double m2 = nonrec ? d : -INFINITY;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) m2 = fmax(m2, __shfl_xor(m2, off, 16));
+        const unsigned b1 = group_bits(__ballot(valid && d == cmax), group);
+        const unsigned b2 = group_bits(__ballot(nonrec && d == m2), group);
+        // shuffles stay outside the (group-divergent) branches so every lane takes part
+        const int id1 = __shfl(id, b1 ? __ffs(b1) - 1 : 0, 16);   // first arg-max = last record
+        const int id2 = __shfl(id, b2 ? __ffs(b2) - 1 : 0, 16);
+        if (cmax > D1) {                                   // at least one record in this chunk
+            D1 = cmax;
+            i1 = id1;
+        }
+        if (m2 > D2) {                                     // strict: earlier slot-2 holder stays
+            D2 = m2;
+            i2 = id2;
+        }
+    }
+    if (D2 <= 0.0) {        // :390-393
+        D2 = 0.0;
+        i2 = i1;
+    }
+    if (!in_range || lane16 != 0) return;
+    if (i1 <= 0) {          // no neighbour with dot > -1: the reference reads garbage here
+        up1[site] = kNoUpwind;
+        up2[site] = kNoUpwind;
+        d1o[site] = D1; d2o[site] = D2;
+        w1o[site] = 0.0; w2o[site] = 0.0; r1o[site] = 0.0; r2o[site] = 0.0;
+        return;
+    }
+    const double p1 = pow(D1, 7.0), p2 = pow(D2, 7.0);     // irregular_ray_tracing.jl:1,51
+    const double sum = p1 + p2;
+    const double pz = pos[3 * site + 0], px = pos[3 * site + 1], py = pos[3 * site + 2];
+    const int64_t a = i1 - 1, b = i2 - 1;
+    double dz = pz - pos[3 * a + 0], dx = px - pos[3 * a + 1], dy = py - pos[3 * a + 2];
+    const double r1 = sqrt((dz * dz + dx * dx) + dy * dy); // euclidean, no periodic wrap (:66)
+    dz = pz - pos[3 * b + 0]; dx = px - pos[3 * b + 1]; dy = py - pos[3 * b + 2];
+    const double r2 = sqrt((dz * dz + dx * dx) + dy * dy);
+    up1[site] = (int32_t)a;
+    up2[site] = (int32_t)b;
+    d1o[site] = D1;
+    d2o[site] = D2;
+    w1o[site] = p1 / sum;
+    w2o[site] = p2 / sum;
+    r1o[site] = r1;
+    r2o[site] = r2;
+}
+
+int launch_upwind_table(vrt_plan *p, int a)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const int64_t blocks = (n * 16 + 255) / 256;
+    const size_t o = (size_t)a * (size_t)n;
+    hipLaunchKernelGGL(k_upwind_table, dim3((unsigned)blocks), dim3(256), 0, g->stream, n,
+                       g->d_rowptr, g->d_col, g->d_lz, g->d_lx, g->d_ly, g->d_pos,
+                       p->k[3 * a + 0], p->k[3 * a + 1], p->k[3 * a + 2], p->d_up1 + o,
+                       p->d_up2 + o, p->d_d1 + o, p->d_d2 + o, p->d_w1 + o, p->d_w2 + o,
+                       p->d_r1 + o, p->d_r2 + o);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// Boundary: I[perm[1:n1]] = I_0 (irregular_ray_tracing.jl:31-35) and I = 0 for the one site of
+// the last layer the reference never visits (voronoi_utils.jl:266).  blockIdx.y = angle slot.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_boundary(int64_t n, int64_t nlam, int64_t ldI, int64_t n1, const int32_t *__restrict__ order,
+           const int32_t *__restrict__ angles, const double *__restrict__ I0,
+           double *__restrict__ I)
+{
+    const int a = angles[blockIdx.y];
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (n1 + 1) * nlam;
+    if (t >= total) return;
+    const int64_t p = t / nlam;
+    const int64_t l = t - p * nlam;
+    double *Ia = I + (size_t)a * (size_t)n * (size_t)ldI;
+    if (p < n1) {
+        const int64_t site = order[p];
+        Ia[(size_t)site * ldI + l] = I0 ? I0[(size_t)p * nlam + l] : 0.0;
+    } else {
+        const int64_t site = order[n - 1];
+        Ia[(size_t)site * ldI + l] = 0.0;
+    }
+}
+
+int launch_boundary(vrt_plan *p, const SweepArgs &sa, const double *dI0_up, const double *dI0_down,
+                    hipStream_t st)
+{
+    vrt_grid *g = p->g;
+    for (int d = 0; d < 2; d++) {
+        const Direction &dir = d == 0 ? g->up : g->down;
+        const int cnt = d == 0 ? p->n_up : p->n_down;
+        if (cnt == 0) continue;
+        // when the grid has a single layer every site but the last is boundary (n1 = n - 1)
+        const int64_t total = (dir.n1 + 1) * sa.nlam;
+        const int64_t blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(k_boundary, dim3((unsigned)blocks, (unsigned)cnt), dim3(256), 0, st,
+                           sa.n, sa.nlam, sa.ldI, dir.n1, dir.d_order,
+                           d == 0 ? p->d_angles_up : p->d_angles_down,
+                           d == 0 ? dI0_up : dI0_down, sa.I);
+        VRT_HIP_TRY(hipGetLastError());
+    }
+    return VRT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// One level of the sweep schedule: every (node, wavelength) pair of the level is independent.
+// Per pair, irregular_ray_tracing.jl:53-76:
+//   Δτ_r = r_r (α_c + α_u) / 2              trapezoidal, functions.jl:392-395
+//   (a, b, e) = linear_weights(Δτ_r)         functions.jl:484-500
+//   I_c = (0 + ((e I_u1 + a S_u1) + b S_c) w_1) + ((e I_u2 + a S_u2) + b S_c) w_2
+// Wavelength is the fastest index of S, α and I, so consecutive lanes read consecutive doubles
+// of a site row.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void linear_weights(double dtau, double &a, double &b, double &e)
+{
+    if (dtau < 5e-4) {
+        e = 1.0 - dtau + 0.5 * (dtau * dtau);
+        a = dtau * (0.5 - dtau / 3.0);
+        b = dtau * (0.5 - dtau / 6.0);
+    } else if (dtau > 50.0) {
+        e = 0.0;
+        a = 1.0 / dtau;
+        b = 1.0 - a;
+    } else {
+        e = exp(-dtau);
+        a = (1.0 - e) / dtau - e;
+        b = 1.0 - a - e;
+    }
+}
+
+template <int ALPHA_MODE>
+__global__ void __launch_bounds__(256)
+k_sweep_level(int64_t first, int count, int nlam, int64_t n, int64_t ldS, int64_t ldA, int64_t ldI,
+              const uint32_t *__restrict__ node_site, const uint32_t *__restrict__ node_meta,
+              const int32_t *__restrict__ up1, const int32_t *__restrict__ up2,
+              const double *__restrict__ w1, const double *__restrict__ w2,
+              const double *__restrict__ r1, const double *__restrict__ r2,
+              const double *__restrict__ S, const double *__restrict__ alpha, double *I)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned q = nlam == 1 ? t : t / (unsigned)nlam;
+    if (q >= (unsigned)count) return;
+    const unsigned l = nlam == 1 ? 0u : t - q * (unsigned)nlam;
+    const uint32_t site = node_site[first + q];
+    const uint32_t meta = node_meta[first + q];
+    const unsigned a = meta & 0xFFu;
+    const size_t row = (size_t)a * (size_t)n + site;
+    const int32_t u1 = up1[row], u2 = up2[row];
+    const double W1 = w1[row], W2 = w2[row], R1 = r1[row], R2 = r2[row];
+
+    const double *Aa = alpha;
+    if (ALPHA_MODE == VRT_ALPHA_ANGLE_SITE_LAM) Aa += (size_t)a * (size_t)n * (size_t)ldA;
+    double *Ia = I + (size_t)a * (size_t)n * (size_t)ldI;
+
+    double a_c, a_1, a_2;
+    if (ALPHA_MODE == VRT_ALPHA_SITE) {
+        a_c = Aa[site]; a_1 = Aa[u1]; a_2 = Aa[u2];
+    } else {
+        a_c = Aa[(size_t)site * ldA + l];
+        a_1 = Aa[(size_t)u1 * ldA + l];
+        a_2 = Aa[(size_t)u2 * ldA + l];
+    }
+    const double S_c = S[(size_t)site * ldS + l];
+    const double S_1 = S[(size_t)u1 * ldS + l];
+    const double S_2 = S[(size_t)u2 * ldS + l];
+    const double I_1 = (meta & 0x100u) ? 0.0 : Ia[(size_t)u1 * ldI + l];
+    const double I_2 = (meta & 0x200u) ? 0.0 : Ia[(size_t)u2 * ldI + l];
+
+    double ca, cb, ce;
+    linear_weights(R1 * (a_c + a_1) / 2.0, ca, cb, ce);
+    const double t1 = ((ce * I_1 + ca * S_1) + cb * S_c) * W1;
+    linear_weights(R2 * (a_c + a_2) / 2.0, ca, cb, ce);
+    const double t2 = ((ce * I_2 + ca * S_2) + cb * S_c) * W2;
+    Ia[(size_t)site * ldI + l] = (0.0 + t1) + t2;
+}
+
+int launch_sweep_levels(vrt_plan *p, const SweepArgs &sa, hipStream_t st, int64_t *launches)
+{
+    const int64_t nlev = (int64_t)p->level_off.size() - 1;
+    int64_t nl = 0;
+    // keep the flat (node, λ) index of one launch inside 31 bits
+    const int64_t max_nodes = std::max<int64_t>(1, ((int64_t)1 << 30) / sa.nlam);
+    for (int64_t lev = 0; lev < nlev; lev++) {
+        int64_t first = p->level_off[(size_t)lev];
+        const int64_t last = p->level_off[(size_t)lev + 1];
+        while (first < last) {
+            const int64_t cnt = std::min(max_nodes, last - first);
+            const int64_t blocks = (cnt * sa.nlam + 255) / 256;
+#define VRT_LAUNCH_SWEEP(MODE)                                                                     \
+    hipLaunchKernelGGL(k_sweep_level<MODE>, dim3((unsigned)blocks), dim3(256), 0, st, first,       \
+                       (int)cnt, (int)sa.nlam, sa.n, sa.ldS, sa.ldA, sa.ldI, p->d_node_site,       \
+                       p->d_node_meta, p->d_up1, p->d_up2, p->d_w1, p->d_w2, p->d_r1, p->d_r2,     \
+                       sa.S, sa.alpha, sa.I)
+            if (sa.alpha_mode == VRT_ALPHA_SITE) VRT_LAUNCH_SWEEP(VRT_ALPHA_SITE);
+            else if (sa.alpha_mode == VRT_ALPHA_SITE_LAM) VRT_LAUNCH_SWEEP(VRT_ALPHA_SITE_LAM);
+            else VRT_LAUNCH_SWEEP(VRT_ALPHA_ANGLE_SITE_LAM);
+#undef VRT_LAUNCH_SWEEP
+            nl++;
+            first += cnt;
+        }
+    }
+    VRT_HIP_TRY(hipGetLastError());
+    *launches = nl;
+    return VRT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// J = Σ_angles w · I, accumulated in the reference's angle order (lambda_iteration.jl:84,102,107)
+// --------------------------------------------------------------------------------------------
+struct WeightTable {
+    double w[kMaxAngles];
+};
+
+__global__ void __launch_bounds__(256)
+k_reduce_J(int64_t n, int64_t nlam, int64_t ldI, int64_t ldJ, int A, WeightTable wt,
+           const double *__restrict__ I, double *__restrict__ J)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nlam) return;
+    const int64_t site = t / nlam;
+    const int64_t l = t - site * nlam;
+    double acc = 0.0;
+    for (int a = 0; a < A; a++)
+        acc += wt.w[a] * I[((size_t)a * (size_t)n + (size_t)site) * (size_t)ldI + l];
+    J[(size_t)site * ldJ + l] = acc;
+}
+
+int launch_reduce_J(vrt_plan *p, const SweepArgs &sa, const double *weights_active, double *dJ,
+                    int64_t ldJ, hipStream_t st)
+{
+    WeightTable wt;
+    for (int a = 0; a < kMaxAngles; a++) wt.w[a] = a < p->A ? weights_active[a] : 0.0;
+    const int64_t total = sa.n * sa.nlam;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_reduce_J, dim3((unsigned)blocks), dim3(256), 0, st, sa.n, sa.nlam, sa.ldI,
+                       ldJ, p->A, wt, sa.I, dJ);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+// per-angle intensities to the caller's (nlam, n, n_angles) array; skipped (θ = 90) angles -> 0
+__global__ void __launch_bounds__(256)
+k_copy_I(int64_t n, int64_t nlam, int64_t ldI, int64_t ldO, int src_angle,
+         const double *__restrict__ I, double *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nlam) return;
+    const int64_t site = t / nlam;
+    const int64_t l = t - site * nlam;
+    out[(size_t)site * ldO + l] =
+        src_angle < 0 ? 0.0 : I[((size_t)src_angle * (size_t)n + (size_t)site) * (size_t)ldI + l];
+}
+
+int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, double *dI_out, int64_t ldO, hipStream_t st)
+{
+    std::vector<int> active_of_user((size_t)p->n_angles_user, -1);
+    for (int a = 0; a < p->A; a++) active_of_user[(size_t)p->user_of_active[(size_t)a]] = a;
+    const int64_t total = sa.n * sa.nlam;
+    const int64_t blocks = (total + 255) / 256;
+    for (int64_t u = 0; u < p->n_angles_user; u++) {
+        hipLaunchKernelGGL(k_copy_I, dim3((unsigned)blocks), dim3(256), 0, st, sa.n, sa.nlam, sa.ldI,
+                           ldO, active_of_user[(size_t)u], sa.I,
+                           dI_out + (size_t)u * (size_t)sa.n * (size_t)ldO);
+    }
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+}  // namespace vrt

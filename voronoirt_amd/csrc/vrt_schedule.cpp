@@ -1,0 +1,131 @@
+// Exact parallel schedule of the reference's serial Gauss-Seidel sweep.
+//
+// The reference (src/irregular_ray_tracing.jl:37-80, :118-161) visits, per layer, per sweep, the
+// sites of the layer one after the other and overwrites I[site] in place, so a site sees
+//   - the FINAL value of an upwind neighbour in an earlier layer (or I_0 in layer 1),
+//   - THIS sweep's value of an in-layer neighbour that precedes it in the visiting order,
+//   - the PREVIOUS sweep's value (0 on the first sweep) of one that follows it,
+//   - 0 for a neighbour in a later layer, and 0 for the never-visited last site (:23, and the
+//     reduce_layers quirk voronoi_utils.jl:266).
+// That serial trace of 3(n - n1 - 1) read-read-write "instructions" is analysed once per angle:
+//   pass A  drops a visit whose two inputs are unchanged since the site's previous visit (it
+//           would rewrite the identical value),
+//   pass B  drops visits whose result is overwritten before anything reads it,
+//   pass C  assigns each remaining visit the earliest level that respects read-after-write,
+//           write-after-write and write-after-read on the single I array.
+// Visits of one level are independent and run as one kernel launch; executing the levels in
+// order reproduces the serial result bit for bit (same arithmetic on the same values).
+#include <algorithm>
+
+#include "vrt_internal.h"
+
+namespace vrt {
+
+void build_angle_schedule(const Direction &dir, bool ascending, int64_t n, int n_sweeps,
+                          const int32_t *up1, const int32_t *up2, AngleSchedule &out)
+{
+    out.site.clear();
+    out.zflags.clear();
+    out.level_off.assign(1, 0);
+    out.bad_site = -1;
+    const std::vector<int64_t> &r = dir.reduced;
+    const int64_t nl = (int64_t)r.size();
+
+    // ---- pass A: trace generation + redundancy elimination --------------------------------
+    struct Visit { uint32_t site; uint8_t z; };
+    std::vector<Visit> trace;
+    trace.reserve((size_t)std::max<int64_t>(0, (n - dir.n1)) * 2);
+    std::vector<uint32_t> ver((size_t)n, 0);             // number of value-changing writes so far
+    std::vector<uint32_t> seen1((size_t)n, UINT32_MAX);  // input versions at the last kept visit
+    std::vector<uint32_t> seen2((size_t)n, UINT32_MAX);
+    for (int64_t layer = 2; layer <= nl - 1; layer++) {          // irregular_ray_tracing.jl:37
+        const int64_t lo = r[(size_t)layer - 1] - 1;             // 0-based first position
+        const int64_t hi = r[(size_t)layer] - 1;                 // 0-based one-past-last
+        for (int sweep = 0; sweep < n_sweeps; sweep++) {         // :40
+            for (int64_t t = 0; t < hi - lo; t++) {
+                const int64_t posn = ascending ? lo + t : hi - 1 - t;   // :41 / :122
+                const int64_t i = dir.perm[(size_t)posn] - 1;
+                const int32_t u1 = up1[i], u2 = up2[i];
+                if (u1 < 0 || u2 < 0) {
+                    if (out.bad_site < 0) out.bad_site = i;
+                    continue;
+                }
+                const uint32_t v1 = ver[(size_t)u1], v2 = ver[(size_t)u2];
+                if (seen1[(size_t)i] == v1 && seen2[(size_t)i] == v2) continue;  // same inputs
+                seen1[(size_t)i] = v1;
+                seen2[(size_t)i] = v2;
+                ver[(size_t)i]++;
+                // a read of version 0 sees the initial array: I_0 in layer 1, otherwise 0
+                uint8_t z = 0;
+                if (v1 == 0 && dir.layer_of[(size_t)u1] != 1) z |= 1;
+                if (v2 == 0 && dir.layer_of[(size_t)u2] != 1) z |= 2;
+                trace.push_back({(uint32_t)i, z});
+            }
+        }
+    }
+    if (out.bad_site >= 0) return;
+
+    // ---- pass B: liveness, backwards --------------------------------------------------------
+    const size_t T = trace.size();
+    std::vector<uint8_t> live(T, 0);
+    {
+        std::vector<uint8_t> needed((size_t)n, 1);     // final values are outputs
+        for (size_t x = T; x-- > 0;) {
+            const uint32_t i = trace[x].site;
+            if (!needed[i]) continue;
+            live[x] = 1;
+            needed[i] = 0;
+            if (!(trace[x].z & 1)) needed[(size_t)up1[i]] = 1;
+            if (!(trace[x].z & 2)) needed[(size_t)up2[i]] = 1;
+        }
+    }
+
+    // ---- pass C: levels ----------------------------------------------------------------------
+    std::vector<int32_t> lw((size_t)n, 0);    // level of the last write (0: initial / boundary)
+    std::vector<int32_t> lr((size_t)n, 0);    // highest level that read the current value
+    std::vector<int32_t> level(T, 0);
+    int32_t max_level = 0;
+    for (size_t x = 0; x < T; x++) {
+        if (!live[x]) continue;
+        const uint32_t i = trace[x].site;
+        const int32_t u1 = up1[i], u2 = up2[i];
+        int32_t lv = std::max(lw[i], lr[i]);                       // WAW, WAR
+        if (!(trace[x].z & 1)) lv = std::max(lv, lw[(size_t)u1]);  // RAW
+        if (!(trace[x].z & 2)) lv = std::max(lv, lw[(size_t)u2]);
+        lv += 1;
+        level[x] = lv;
+        if (!(trace[x].z & 1)) lr[(size_t)u1] = std::max(lr[(size_t)u1], lv);
+        if (!(trace[x].z & 2)) lr[(size_t)u2] = std::max(lr[(size_t)u2], lv);
+        lw[i] = lv;
+        lr[i] = 0;
+        if (lv > max_level) max_level = lv;
+    }
+
+    // ---- counting sort by level (stable: keeps trace order inside a level) -------------------
+    out.level_off.assign((size_t)max_level + 1, 0);
+    for (size_t x = 0; x < T; x++)
+        if (live[x]) out.level_off[(size_t)level[x]]++;     // count of level l at index l
+    // convert counts (index 1..max) to offsets: level_off[l-1] = start of level l
+    {
+        int64_t run = 0;
+        for (int32_t l = 1; l <= max_level; l++) {
+            int64_t c = out.level_off[(size_t)l];
+            out.level_off[(size_t)l - 1] = run;
+            run += c;
+        }
+        out.level_off[(size_t)max_level] = run;
+        out.site.resize((size_t)run);
+        out.zflags.resize((size_t)run);
+    }
+    {
+        std::vector<int64_t> cur(out.level_off.begin(), out.level_off.end());
+        for (size_t x = 0; x < T; x++) {
+            if (!live[x]) continue;
+            const int64_t at = cur[(size_t)level[x] - 1]++;
+            out.site[(size_t)at] = trace[x].site;
+            out.zflags[(size_t)at] = trace[x].z;
+        }
+    }
+}
+
+}  // namespace vrt
