@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Benchmark of the Voronoi formal solve (BASELINE.json metric: formal-solve cell-updates/s and
+achieved HBM GB/s on a ~1M-site Voronoi grid with the 12 angles of ul7n12).
+
+A "step" is one evaluation of the angle x wavelength loop of J_λ_voronoi
+(src/lambda_iteration.jl:84-111 of the reference): every site x angle x wavelength intensity
+(each including its 3 Gauss-Seidel sweeps) plus the J = Σ w·I reduction, with S, α and I_0
+already resident in HBM and the per-angle upwind tables / sweep schedule built beforehand (they
+depend on the grid and the quadrature only; their one-time cost is reported separately).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C4|C2|C3|tiny] [--nlam L]
+
+N > 1 is launched by torchrun (one rank per GPU, RCCL).  Default sharding is by wavelength
+block (each rank owns whole rows of J: no data-path collective, weak scaling: every rank solves
+`nlam` wavelengths of a global N*nlam problem).  `--shard angle` splits the angles instead and
+all-reduces J over RCCL each step (strong scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E vendor peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (a, c, quadrature, nlam, alpha per angle, seed)   -- SURVEY.md 8d, BASELINE.md sec. 3
+    "C4": (59, 143, "ul7n12.dat", 51, True, 2022),    # ~1M sites, 12 angles x 51 λ (line)
+    "C3": (59, 143, "ul9n20.dat", 20, False, 1998),   # ~1M sites, 20 angles x 20 λ (continuum)
+    "C2": (37, 90, "ul7n12.dat", 1, False, 1998),     # ~250k sites, 12 angles x 1 λ
+    "tiny": (8, 12, "ul7n12.dat", 4, True, 7),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--nlam", type=int, default=0, help="override wavelengths per rank")
+    ap.add_argument("--shard", default="lambda", choices=["lambda", "angle"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-lam", type=int, default=0, help="wavelengths in the CPU sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import voronoirt_amd as vrt
+    from voronoirt_amd import _lib, distributed, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    rank, world = distributed.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    a, c, quad, nlam, per_angle, seed = WORKLOADS[args.workload]
+    if args.nlam > 0:
+        nlam = args.nlam
+    weights, theta, phi, n_angles = vrt.read_quadrature(quad)
+
+    # ---- one-time setup (untimed; reported) --------------------------------------------------
+    t0 = time.time()
+    pos, nbr, bounds = synth.bcc_grid(a, c, seed=seed)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    sites = vrt.VoronoiSites(pos, nbr, bounds, device=local)
+    t_grid = time.time() - t0
+    n = sites.n
+
+    my_angles = np.arange(n_angles)
+    if args.shard == "angle" and world > 1:
+        my_angles = distributed.angle_assignment(theta, world)[rank]
+    k_all = vrt.quadrature_directions(theta, phi)
+    dirs_all = np.array([1 if t > 90 else (-1 if t < 90 else 0) for t in theta])
+    t0 = time.time()
+    plan = vrt.FormalPlan(sites, k_all[my_angles], 3, dirs=dirs_all[my_angles])
+    t_plan = time.time() - t0
+    A = len(my_angles)
+
+    # ---- synthetic fields, generated on the device (SURVEY 8d shapes) -------------------------
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 1000 * rank)
+    z = torch.as_tensor(pos[:, 0], device=dev)
+    z_min, z_max = bounds[0], bounds[1]
+    lam = torch.arange(nlam, device=dev, dtype=torch.float64)
+    centre, sigma = 0.5 * (nlam - 1), max(nlam / 6.0, 1.0)
+    S = 1.0 + 0.5 * torch.sin(2 * np.pi * (z - z_min) / (z_max - z_min))[:, None] \
+        + 0.1 * torch.rand((n, nlam), generator=gen, device=dev, dtype=torch.float64)
+    strat = 1.0e-2 * torch.exp(-(z - z_min) / 0.7e6)
+    if per_angle:
+        alpha = torch.empty((A, n, nlam), device=dev, dtype=torch.float64)
+        for j, ai in enumerate(my_angles):
+            shift = 0.15 * sigma * np.cos(2 * np.pi * ai / n_angles)
+            psi = 1.0 + 9.0 * torch.exp(-((lam - centre - shift) / sigma) ** 2)
+            alpha[j] = strat[:, None] * (1.0 + 0.1 * torch.rand((n, nlam), generator=gen, device=dev,
+                                                                 dtype=torch.float64)) * psi[None, :]
+        alpha_mode = _lib.ALPHA_ANGLE_SITE_LAM
+    else:
+        psi = 1.0 + 9.0 * torch.exp(-((lam - centre) / sigma) ** 2)
+        alpha = strat[:, None] * (1.0 + 0.1 * torch.rand((n, nlam), generator=gen, device=dev,
+                                                         dtype=torch.float64)) * psi[None, :]
+        alpha_mode = _lib.ALPHA_SITE_LAM
+    n1_up = int(sites.layers_up[1] - 1)
+    bottom = torch.as_tensor(sites.perm_up[:n1_up] - 1, device=dev)
+    I0_up = S[bottom].contiguous()          # I_0 = S at the bottom layer for up rays; down: zeros
+    J = torch.zeros((n, nlam), device=dev, dtype=torch.float64)
+    w_mine = weights[my_angles]
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        plan.execute_dev(nlam, nlam, S.data_ptr(), alpha.data_ptr(), alpha_mode, w_mine,
+                         dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream)
+        if args.shard == "angle" and world > 1:
+            distributed.allreduce_J(J)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    sweep_ms, launches = plan.last_sweep_timing()    # HIP events on the launch stream, last step
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # cell-updates: one (site, direction, wavelength) intensity incl. its 3 sweeps
+    if args.shard == "angle":
+        updates_per_step = n * n_angles * nlam            # strong: the whole job, split by angle
+    else:
+        updates_per_step = n * n_angles * nlam * world    # weak: every rank adds a λ block
+    ms_per_step = elapsed / args.steps * 1e3
+    value = updates_per_step / (elapsed / args.steps)
+
+    out = {
+        "metric": "formal-solve cell-updates/sec", "value": value, "unit": "cell-updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong" if args.shard == "angle" else "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: jittered-BCC Voronoi grid a={a} c={c} ({n} sites, "
+                        f"L_up={len(sites.layers_up) - 1} layers), {quad} ({n_angles} angles), "
+                        f"nlam={nlam} per rank, alpha per "
+                        f"{'angle,site,lambda' if per_angle else 'site,lambda'}, n_sweeps=3",
+            "sites": n, "angles": n_angles, "nlam_per_rank": nlam, "shard": args.shard,
+            "schedule_levels": plan.num_levels, "live_visits_per_site_angle": plan.num_nodes / (n * A),
+        },
+        "setup_s": {"grid_generate": t_gen, "grid_create": t_grid, "plan_create": t_plan},
+    }
+    # roofline of the dominant kernel (k_sweep_level): algorithmic bytes / event-timed duration
+    bytes_per_update = 40.0 + 40.0 / nlam
+    local_updates = n * A * nlam
+    alg_bytes = local_updates * bytes_per_update
+    achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+    out["roofline"] = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "kernel": "k_sweep_level", "launches_per_step": launches,
+        "sweep_ms_per_step": sweep_ms, "avg_launch_us": sweep_ms * 1e3 / max(launches, 1),
+        "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
+        "bytes_per_cell_update": bytes_per_update,
+        "note": "duration = HIP events around the whole sequence of level launches of one step "
+                "(inter-kernel gaps included)",
+    }
+
+    # ---- CPU baseline: the oracle, threaded the way the reference is (angles serial, λ split
+    # over threads), on a bounded sample of the same workload; also a full-size parity check ----
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        lam_s = args.cpu_lam if args.cpu_lam > 0 else min(nlam, cores)
+        t0 = time.time()
+        so = orc.make_sites(pos, nbr, bounds)
+        t_osites = time.time() - t0
+        S_h = S[:, :lam_s].contiguous().cpu().numpy()
+        if per_angle:
+            al_h = alpha[:, :, :lam_s].contiguous().cpu().numpy()
+        else:
+            al_h = alpha[:, :lam_s].contiguous().cpu().numpy()
+        I0_h = I0_up[:, :lam_s].contiguous().cpu().numpy()
+        t0 = time.time()
+        J_ref = orc.J_voronoi(w_mine, theta[my_angles], phi[my_angles], S_h, al_h, so, I0_up=I0_h,
+                              nthreads=cores)
+        t_cpu = time.time() - t0
+        cpu_updates = n * A * lam_s
+        J_gpu = J[:, :lam_s].cpu().numpy()
+        if args.shard == "angle" and world > 1:
+            parity = None    # J holds the all-reduced sum of every rank's angles
+        else:
+            parity = float(np.abs(J_gpu - J_ref).max() / np.abs(J_ref).max())
+        out["cpu_baseline"] = {
+            "value": cpu_updates / t_cpu, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "sample": f"same grid and fields, all {A} angles x the first {lam_s} of {nlam} "
+                      f"wavelengths ({cpu_updates} cell-updates in {t_cpu:.1f} s wall); oracle "
+                      f"restatement threaded over wavelengths like Threads.@threads; its grid "
+                      f"prep (read_cell equivalent) took {t_osites:.1f} s and is not counted",
+            "seconds": t_cpu,
+        }
+        out["parity_vs_oracle_max_rel_err"] = parity
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
