@@ -1,0 +1,408 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full
+size -- through size-independent properties.
+
+Bars (BASELINE.json north_star): neighbour indices (and everything integer: layers, permutations,
+upwind ids) bit-exact; intensities within 1e-10 relative in fp64 (RTOL below).  The Delaunay
+lines, dot products and path lengths are also bit-exact because fp64 +,*,/,sqrt are correctly
+rounded on the device and the build disables FMA contraction on both sides."""
+import numpy as np
+import pytest
+
+import voronoirt_amd as vrt
+from oracle import oracle as orc
+from voronoirt_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10     # fp64 tolerance of the north star
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _valid_line_mask(so):
+    m = np.zeros(so.delaunay_lines.shape[:2], dtype=bool)
+    for j in range(so.D):
+        m[:, j] = (j < so.neighbours[0]) & (so.neighbours[j + 1] > 0)
+    return m
+
+
+@pytest.fixture(scope="module")
+def grids(bcc_small, voro_small):
+    out = {}
+    for name, (pos, nbr, bounds) in (("bcc", bcc_small), ("voronoi", voro_small)):
+        out[name] = (vrt.VoronoiSites(pos, nbr, bounds, device=0), orc.make_sites(pos, nbr, bounds))
+    return out
+
+
+def test_native_library_is_the_compute_path():
+    L = _lib.load()
+    assert L.vrt_device_count() >= 1
+    assert _lib.LIB_PATH.endswith("voronoirt_amd/libvrt_hip.so")
+
+
+@pytest.mark.parametrize("name", ["bcc", "voronoi"])
+def test_grid_and_delaunay_lines_bit_exact(grids, name):
+    hs, so = grids[name]
+    for key in ("layers_up", "layers_down", "perm_up", "perm_down"):
+        assert np.array_equal(getattr(hs, key), getattr(so, key)), key
+    m = _valid_line_mask(so)
+    lines = hs.Delaunay_lines
+    assert np.array_equal(lines[m], so.delaunay_lines[m])
+    assert (lines[~m] == 0).all()
+
+
+@pytest.mark.parametrize("name", ["bcc", "voronoi"])
+@pytest.mark.parametrize("quad", ["ul7n12.dat", "ul9n20.dat", "n1.dat"])
+def test_upwind_table_bit_exact(grids, name, quad):
+    hs, so = grids[name]
+    w, th, ph, nq = vrt.read_quadrature(quad)
+    ks = vrt.quadrature_directions(th, ph)
+    plan = vrt.FormalPlan(hs, ks, 3, dirs=[1 if t > 90 else -1 for t in th])
+    for a in range(nq):
+        assert np.array_equal(ks[a], orc.direction(th[a], ph[a]))
+        up, dots, wt, r, st = orc.upwind_table(so, ks[a])
+        gup, gd, gw, gr = plan.upwind(a)
+        ok = st == 0
+        assert np.array_equal(gup[ok], up[ok]), "upwind neighbour ids must be bit-exact"
+        assert (gup[~ok] == 0).all()
+        assert np.array_equal(gd[ok], dots[ok])
+        assert np.array_equal(gr[ok], r[ok])
+        assert np.allclose(gw[ok], wt[ok], rtol=4e-16, atol=1e-300)      # pow(): <= 2 ulp
+    plan.close()
+
+
+def test_upwind_rows_longer_than_16_and_order_dependence():
+    """Rows with more than 16 neighbours span several 16-lane chunks; permuting a row changes
+    the reference's order-dependent choice and the kernel must follow it."""
+    pos, nbr, bounds = synth.voronoi_grid(1200, seed=8, bounds=(0.0, 1.0, 0.0, 1.0, 0.0, 1.0))
+    assert nbr[0].max() > 16
+    rng = np.random.default_rng(0)
+    for trial in range(3):
+        nb = nbr.copy()
+        for i in range(nb.shape[1]):
+            c = nb[0, i]
+            nb[1:c + 1, i] = rng.permutation(nb[1:c + 1, i])
+        hs = vrt.VoronoiSites(pos, nb, bounds, device=0)
+        so = orc.make_sites(pos, nb, bounds)
+        k = orc.direction(112.824260481870382, 335.790538127899197)
+        plan = vrt.FormalPlan(hs, [k], 3)
+        up, dots, wt, r, st = orc.upwind_table(so, k)
+        gup, gd, gw, gr = plan.upwind(0)
+        ok = st == 0
+        assert np.array_equal(gup[ok], up[ok]) and np.array_equal(gd[ok], dots[ok])
+        plan.close()
+        hs.close()
+
+
+@pytest.mark.parametrize("name", ["bcc", "voronoi"])
+def test_single_solves_match_oracle(grids, name):
+    """Delaunay_upII / Delaunay_downII for the 12 directions of ul7n12, random S, α spanning all
+    three linear_weights branches, random boundary intensity (also for the down rays)."""
+    hs, so = grids[name]
+    n = so.n
+    rng = np.random.default_rng(11)
+    S = 1 + rng.random(n)
+    alpha = 10 ** rng.uniform(-3, 3, n) / (so.bounds[3] - so.bounds[2]) * 10
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    for t, p in zip(th, ph):
+        k = vrt.direction(t, p)
+        if t > 90:
+            I0 = rng.random(so.layers_up[1] - 1)
+            ref = orc.Delaunay_upII(k, S, I0, alpha, so, 3)
+            got = vrt.Delaunay_upII(k, S, I0, alpha, hs, 3)
+        else:
+            I0 = rng.random(so.layers_down[1] - 1)
+            ref = orc.Delaunay_downII(k, S, I0, alpha, so, 3)
+            got = vrt.Delaunay_downII(k, S, I0, alpha, hs, 3)
+        assert _rel(got, ref) < RTOL
+        assert got[(so.perm_up if t > 90 else so.perm_down)[-1] - 1] == 0.0   # never-visited site
+    # second call with the same k hits the plan cache and must give the same bits
+    k = vrt.direction(th[0], ph[0])
+    I0 = np.zeros(so.layers_down[1] - 1)
+    a = vrt.Delaunay_downII(k, S, I0, alpha, hs, 3)
+    b = vrt.Delaunay_downII(k, S, I0, alpha, hs, 3)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n_sweeps", [1, 2, 4])
+def test_other_sweep_counts(grids, n_sweeps):
+    hs, so = grids["voronoi"]
+    n = so.n
+    rng = np.random.default_rng(5)
+    S = 1 + rng.random(n)
+    alpha = 10 ** rng.uniform(-2, 2, n) * 5
+    k = vrt.direction(101.810709392034880, 235.428463450411130)
+    I0 = rng.random(so.layers_up[1] - 1)
+    assert _rel(vrt.Delaunay_upII(k, S, I0, alpha, hs, n_sweeps),
+                orc.Delaunay_upII(k, S, I0, alpha, so, n_sweeps)) < RTOL
+
+
+def test_up_solver_with_down_pointing_k(grids):
+    """The reference's Delaunay_upII uses perm_up with whatever k it is handed; so does the
+    drop-in (vrt_plan_create_ex with an explicit direction)."""
+    hs, so = grids["bcc"]
+    n = so.n
+    rng = np.random.default_rng(2)
+    S, alpha = 1 + rng.random(n), np.full(n, 1e-6)
+    k = vrt.direction(60.0, 20.0)                 # θ < 90 handed to the "up" solver
+    I0 = rng.random(so.layers_up[1] - 1)
+    assert _rel(vrt.Delaunay_upII(k, S, I0, alpha, hs, 3), orc.Delaunay_upII(k, S, I0, alpha, so, 3)) < RTOL
+
+
+def test_golden_vectors(golden):
+    g = golden
+    exp = g["exp"]
+    n = g["meta"]["n"]
+    hs = vrt.read_cell(g["nbr_file"], n, g["pos"], g["bounds"], device=0)
+    for key in ("layers_up", "layers_down", "perm_up", "perm_down"):
+        assert np.array_equal(getattr(hs, key), exp[key]), key
+    w, th, ph, _ = vrt.read_quadrature(g["meta"]["quadrature"])
+    S, al = exp["S"], exp["alpha"]
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    for a in g["meta"]["angles"]:
+        gup, *_ = plan.upwind(a)
+        ok = exp[f"status_{a}"] == 0
+        assert np.array_equal(gup[ok], exp[f"up_{a}"][ok])
+        k = vrt.direction(th[a], ph[a])
+        if th[a] > 90:
+            I = vrt.Delaunay_upII(k, S[:, 0].copy(), exp["I0_up"][:, 0].copy(), al[:, 0].copy(), hs, 3)
+        else:
+            I = vrt.Delaunay_downII(k, S[:, 0].copy(), exp["I0_down"][:, 0].copy(), al[:, 0].copy(), hs, 3)
+        assert _rel(I, exp[f"I_{a}"]) < RTOL
+    J, _ = plan.execute(S, al, weights=w, I0_up=exp["I0_up"], I0_down=exp["I0_down"])
+    assert _rel(J, exp["J"]) < RTOL
+    plan.close()
+
+
+@pytest.mark.parametrize("nlam", [1, 3, 51, 64, 70])
+def test_J_all_alpha_layouts(grids, nlam):
+    """J_λ_voronoi with α per site, per (site, λ) and per (angle, site, λ); ragged λ counts."""
+    hs, so = grids["voronoi"]
+    n = so.n
+    rng = np.random.default_rng(100 + nlam)
+    S = 1 + rng.random((n, nlam))
+    base = 10 ** rng.uniform(-3, 3, n) * 5
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    I0 = rng.random((so.layers_up[1] - 1, nlam))
+    variants = [base, base[:, None] * (1 + rng.random((n, nlam)))]
+    if nlam <= 51:
+        variants.append(np.stack([base[:, None] * (1 + rng.random((n, nlam))) for _ in range(nq)]))
+    for al in variants:
+        if al.ndim == 1 and nlam > 1:
+            ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
+        else:
+            ref = orc.J_voronoi(w, th, ph, S, al if al.ndim > 1 else al.reshape(n, 1), so,
+                                I0_up=I0, nthreads=8, alpha_mode=None if al.ndim > 1 else 1)
+        got = vrt.J_lambda_voronoi(S, al, hs, "ul7n12.dat", I0_up=I0)
+        assert got.shape == (n, nlam) and _rel(got, ref) < RTOL
+
+
+def test_per_angle_intensities_and_theta90_skipped(grids):
+    hs, so = grids["bcc"]
+    n = so.n
+    rng = np.random.default_rng(3)
+    nlam = 4
+    S = 1 + rng.random((n, nlam))
+    al = 10 ** rng.uniform(-3, 3, (n, 1)) * (1 + rng.random((n, nlam))) / 6e6 * 10
+    theta = np.array([150.0, 90.0, 35.0])
+    phi = np.array([10.0, 0.0, 200.0])
+    w = np.array([0.3, 0.4, 0.3])
+    ks = vrt.quadrature_directions(theta, phi)
+    plan = vrt.FormalPlan(hs, ks, 3, dirs=[1, 0, -1])
+    I0u = rng.random((so.layers_up[1] - 1, nlam))
+    I0d = rng.random((so.layers_down[1] - 1, nlam))
+    J, I = plan.execute(S, al, weights=w, I0_up=I0u, I0_down=I0d, want_I=True)
+    assert (I[1] == 0).all()                                  # θ = 90: no solve, no contribution
+    for l in range(nlam):
+        ref_u = orc.Delaunay_upII(ks[0], S[:, l], I0u[:, l], al[:, l], so, 3)
+        ref_d = orc.Delaunay_downII(ks[2], S[:, l], I0d[:, l], al[:, l], so, 3)
+        assert _rel(I[0][:, l], ref_u) < RTOL and _rel(I[2][:, l], ref_d) < RTOL
+    ref = orc.J_voronoi(w, theta, phi, S, al, so, I0_up=I0u, I0_down=I0d)
+    assert _rel(J, ref) < RTOL
+    assert np.array_equal(J, w[0] * I[0] + w[2] * I[2])        # J accumulates in angle order
+    plan.close()
+
+
+def test_searchlight_transparent_grid(grids):
+    """The reference's searchlight test (src/compare_searchlight.jl:10-152): α = S = 0, a disk of
+    radius 0.1 lit on the boundary layer, all 12 directions.  The beam must arrive unattenuated
+    in total no larger than it started and match the oracle."""
+    pos, nbr, bounds = synth.voronoi_grid(4000, seed=21)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    n = so.n
+    S = np.zeros(n)
+    al = np.zeros(n)
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    for t, p in zip(th, ph):
+        up = t > 90
+        perm, lay = (so.perm_up, so.layers_up) if up else (so.perm_down, so.layers_down)
+        idx = perm[: lay[1] - 1] - 1
+        lit = np.sqrt((pos[idx, 1] - 0.5) ** 2 + (pos[idx, 2] - 0.5) ** 2) < 0.1   # :77-82
+        I0 = lit.astype(float)
+        k = vrt.direction(t, p)
+        got = (vrt.Delaunay_upII if up else vrt.Delaunay_downII)(k, S, I0, al, hs, 3)
+        ref = (orc.Delaunay_upII if up else orc.Delaunay_downII)(k, S, I0, al, so, 3)
+        assert _rel(got, ref) < RTOL
+        assert got.min() >= 0.0 and got.max() <= 1.0 + 1e-14
+    hs.close()
+
+
+def test_error_behaviour(grids):
+    hs, so = grids["bcc"]
+    n = so.n
+    k = vrt.direction(150.0, 0.0)
+    with pytest.raises(vrt.VrtError) as e:      # Julia: DimensionMismatch at I[perm[1:n1]] = I_0
+        vrt.Delaunay_upII(k, np.zeros(n), np.zeros(3), np.zeros(n), hs, 3)
+    assert e.value.code == _lib.VRT_EINVAL
+    with pytest.raises(vrt.VrtError) as e:
+        vrt.FormalPlan(hs, [[0.5, 0.5, 0.5]])               # not a unit vector
+    assert e.value.code == _lib.VRT_EINVAL
+    with pytest.raises(vrt.VrtError):
+        vrt.FormalPlan(hs, [[-1.0, 0.0, 0.0]], n_sweeps=0)
+    with pytest.raises(ValueError):
+        vrt.Delaunay_upII(k, np.zeros(n - 1), np.zeros(so.layers_up[1] - 1), np.zeros(n), hs, 3)
+    with pytest.raises(vrt.VrtError) as e:
+        vrt.VoronoiSites(so.positions, so.neighbours, so.bounds, device=99)
+    assert e.value.code == _lib.VRT_EINVAL
+
+
+def test_site_without_upwind_is_reported():
+    """A visited site all of whose neighbours are walls has no upwind neighbour; the reference
+    would index with an uninitialised value, the library reports VRT_EGRID."""
+    pos, nbr, bounds = synth.regular_lattice_grid(3, 3, 4)
+    nbr = nbr.copy()
+    n = nbr.shape[1]
+    victim = int(np.argmax(pos[:, 0] > 0.5))            # a site above the bottom layer
+    c = nbr[0, victim]
+    ids = nbr[1:c + 1, victim]
+    keep = ids[ids > 0][:1]
+    # keep one neighbour so the layering still reaches it, but place it straight ABOVE (dot = -1)
+    above = [v for v in ids if v > 0 and pos[v - 1, 0] > pos[victim, 0]]
+    if not above:
+        pytest.skip("victim is in the top layer")
+    nbr[1:, victim] = 0
+    nbr[1, victim] = above[0]
+    nbr[0, victim] = 1
+    so = orc.make_sites(pos, nbr, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    k = np.array([-1.0, 0.0, 0.0])
+    rc, dots, idx = orc.smallest_angle(victim, so, k)
+    assert rc == -1                                      # d = -1 is not > -1: nothing selected
+    with pytest.raises(vrt.VrtError) as e:
+        vrt.FormalPlan(hs, [k], 3)
+    assert e.value.code == _lib.VRT_EGRID
+    hs.close()
+
+
+def test_execute_dev_with_torch_tensors_and_padding(grids):
+    """Device-pointer entry point on a torch stream, with a padded leading dimension."""
+    import torch
+    hs, so = grids["voronoi"]
+    n = so.n
+    nlam, ld = 5, 8
+    rng = np.random.default_rng(9)
+    S = 1 + rng.random((n, nlam))
+    al = 10 ** rng.uniform(-3, 3, (n, 1)) * (1 + rng.random((n, nlam))) * 5
+    I0 = rng.random((so.layers_up[1] - 1, nlam))
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    dev = torch.device("cuda", 0)
+    Sd = torch.full((n, ld), float("nan"), dtype=torch.float64, device=dev)
+    Ad = torch.full((n, ld), float("nan"), dtype=torch.float64, device=dev)
+    Sd[:, :nlam] = torch.from_numpy(S).to(dev)
+    Ad[:, :nlam] = torch.from_numpy(al).to(dev)
+    I0d = torch.from_numpy(I0).to(dev).contiguous()
+    Jd = torch.full((n, ld), -7.0, dtype=torch.float64, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        plan.execute_dev(nlam, ld, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w,
+                         dJ=Jd.data_ptr(), dI0_up=I0d.data_ptr(), stream=st.cuda_stream)
+    st.synchronize()
+    ms, launches = plan.last_sweep_timing()
+    assert ms > 0 and launches == plan.num_levels
+    J = Jd.cpu().numpy()
+    ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=4)
+    assert _rel(J[:, :nlam], ref) < RTOL
+    assert (J[:, nlam:] == -7.0).all()                    # padding columns untouched
+    plan.close()
+
+
+# ---- BASELINE.json full size: properties that need no oracle run ---------------------------------
+@pytest.fixture(scope="module")
+def full_grid():
+    a, c = synth.BCC_CONFIGS["C4"]
+    pos, nbr, bounds = synth.bcc_grid(a, c, seed=2022)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    return hs, pos, bounds
+
+
+def test_full_size_properties(full_grid):
+    """~1M sites (995 566), ul7n12: (1) linearity of the formal solution in (S, I_0) at fixed α,
+    (2) a constant source function with I_0 = S reproduces itself wherever the sweep converged
+    and never overshoots, (3) J of a unit field is bounded by Σw = 1, (4) determinism."""
+    import torch
+    hs, pos, bounds = full_grid
+    n = hs.n
+    assert n == 995566
+    nlam = 2
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    assert plan.num_nodes <= 3 * n * nq
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    z = torch.as_tensor(pos[:, 0], device=dev)
+    al = (1e-2 * torch.exp(-(z - bounds[0]) / 0.7e6))[:, None] * \
+        (1 + torch.rand((n, nlam), generator=g, device=dev, dtype=torch.float64))
+    n1 = int(hs.layers_up[1] - 1)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def solve(S, I0):
+        J = torch.empty((n, nlam), dtype=torch.float64, device=dev)
+        plan.execute_dev(nlam, nlam, S.data_ptr(), al.data_ptr(), _lib.ALPHA_SITE_LAM, w,
+                         dJ=J.data_ptr(), dI0_up=I0.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        return J
+
+    S1 = 1 + torch.rand((n, nlam), generator=g, device=dev, dtype=torch.float64)
+    S2 = 1 + torch.rand((n, nlam), generator=g, device=dev, dtype=torch.float64)
+    A1 = torch.rand((n1, nlam), generator=g, device=dev, dtype=torch.float64)
+    A2 = torch.rand((n1, nlam), generator=g, device=dev, dtype=torch.float64)
+    J1, J2 = solve(S1, A1), solve(S2, A2)
+    J12 = solve(S1 + 2.0 * S2, A1 + 2.0 * A2)
+    lin = (J12 - (J1 + 2.0 * J2)).abs().max().item() / J12.abs().max().item()
+    assert lin < 1e-12
+    assert torch.equal(solve(S1, A1), J1)                          # bitwise reproducible
+    ones = torch.ones((n, nlam), dtype=torch.float64, device=dev)
+    Jc = solve(ones, torch.ones((n1, nlam), dtype=torch.float64, device=dev))
+    assert Jc.max().item() <= 1.0 + 1e-12 and Jc.min().item() >= 0.0
+    plan.close()
+
+
+def test_full_size_sample_against_oracle(full_grid):
+    """One up and one down direction at full size against the oracle (a few seconds of CPU)."""
+    hs, pos, bounds = full_grid
+    rng = np.random.default_rng(4)
+    n = hs.n
+    nbr = hs.neighbours
+    so = orc.make_sites(pos, nbr, bounds)
+    for key in ("layers_up", "layers_down", "perm_up", "perm_down"):
+        assert np.array_equal(getattr(hs, key), getattr(so, key)), key
+    S = 1 + rng.random(n)
+    al = 1e-2 * np.exp(-(pos[:, 0] - bounds[0]) / 0.7e6) * (1 + rng.random(n))
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    for a in (1, 0):
+        k = vrt.direction(th[a], ph[a])
+        if th[a] > 90:
+            I0 = rng.random(so.layers_up[1] - 1)
+            ref = orc.Delaunay_upII(k, S, I0, al, so, 3)
+            got = vrt.Delaunay_upII(k, S, I0, al, hs, 3)
+        else:
+            I0 = np.zeros(so.layers_down[1] - 1)
+            ref = orc.Delaunay_downII(k, S, I0, al, so, 3)
+            got = vrt.Delaunay_downII(k, S, I0, al, hs, 3)
+        assert _rel(got, ref) < RTOL

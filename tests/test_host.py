@@ -1,0 +1,372 @@
+"""CPU tests (-m "not gpu") of the product's host side: the C-ABI library loads and exports every
+symbol include/voronoirt.h declares, the host grid preparation (layers, stable permutation,
+reduced offsets, neighbour-file parsing) equals the oracle's literal restatement, the
+dependency schedule reproduces the serial Gauss-Seidel sweep exactly, error behaviour, and the
+multi-rank sharding logic under gloo.  No compute call is made: there is no GPU here and the
+library has no CPU fallback (that is asserted too)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import voronoirt_amd as vrt
+from oracle import oracle as orc
+from voronoirt_amd import _lib, distributed, synth
+from voronoirt_amd.api import build_schedule
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI ---------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "voronoirt.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(vrt_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in voronoirt.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert _lib.load().vrt_version() >= 100
+
+
+def test_no_cpu_fallback(bcc_small):
+    """Without a HIP device every compute entry point fails loudly."""
+    L = _lib.load()
+    if L.vrt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    pos, nbr, bounds = bcc_small
+    with pytest.raises(vrt.VrtError) as e:
+        vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    assert e.value.code == _lib.VRT_ENODEVICE
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)       # host-only handle
+    with pytest.raises(vrt.VrtError) as e:
+        vrt.FormalPlan(hs, [[-1.0, 0.0, 0.0]])
+    assert e.value.code == _lib.VRT_ENODEVICE
+    with pytest.raises(vrt.VrtError) as e:
+        vrt.Delaunay_upII([-1.0, 0, 0], np.zeros(hs.n), np.zeros(hs.layers_up[1] - 1),
+                          np.zeros(hs.n), hs)
+    assert e.value.code == _lib.VRT_ENODEVICE
+    with pytest.raises(vrt.VrtError):
+        hs.Delaunay_lines
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under voronoirt_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "voronoirt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "libvrt_oracle" not in txt and "orc_" not in txt, f
+
+
+# ---- grid preparation == oracle -----------------------------------------------------------
+def _check_grid(hs, so):
+    for key in ("layers_up", "layers_down", "perm_up", "perm_down"):
+        assert np.array_equal(getattr(hs, key), getattr(so, key)), key
+    assert hs.max_neighbours == so.D
+
+
+def test_layers_perm_match_oracle_bcc(bcc_small):
+    pos, nbr, bounds = bcc_small
+    _check_grid(vrt.VoronoiSites(pos, nbr, bounds, device=-1), orc.make_sites(pos, nbr, bounds))
+
+
+def test_layers_perm_match_oracle_voronoi(voro_small):
+    pos, nbr, bounds = voro_small
+    _check_grid(vrt.VoronoiSites(pos, nbr, bounds, device=-1), orc.make_sites(pos, nbr, bounds))
+
+
+def test_layers_match_oracle_asymmetric_lists(voro_small):
+    """The reference layers a cell by ITS OWN list (voronoi_utils.jl:113-114); drop one direction
+    of some edges and the product's transposed-graph BFS must still agree with the literal scan."""
+    pos, nbr, bounds = voro_small
+    nbr = nbr.copy()
+    rng = np.random.default_rng(0)
+    n = nbr.shape[1]
+    for i in rng.choice(n, 150, replace=False):
+        c = nbr[0, i]
+        ids = nbr[1:c + 1, i]
+        keep = np.ones(c, dtype=bool)
+        cand = np.nonzero(ids > 0)[0]
+        if cand.size > 4:
+            keep[rng.choice(cand)] = False
+        new = ids[keep]
+        nbr[1:, i] = 0
+        nbr[1:new.size + 1, i] = new
+        nbr[0, i] = new.size
+    _check_grid(vrt.VoronoiSites(pos, nbr, bounds, device=-1), orc.make_sites(pos, nbr, bounds))
+
+
+def test_read_cell_from_file_matches_oracle(golden):
+    g = golden
+    n = g["meta"]["n"]
+    hs = vrt.read_cell(g["nbr_file"], n, g["pos"], g["bounds"], device=-1)
+    exp = g["exp"]
+    for key in ("layers_up", "layers_down", "perm_up", "perm_down"):
+        assert np.array_equal(getattr(hs, key), exp[key]), key
+    so = orc.read_cell(g["nbr_file"], n, g["pos"], g["bounds"])
+    assert hs.max_neighbours == so.D
+
+
+def test_single_layer_grid():
+    """Every cell touches the bottom wall: one layer, reduced offsets [1, n] (reduce_layers with
+    max = 1), n1 = n - 1 and no sweep at all."""
+    pos, nbr, bounds = synth.regular_lattice_grid(3, 3, 1)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)
+    so = orc.make_sites(pos, nbr, bounds)
+    assert hs.layers_up.tolist() == [1, 9] == so.layers_up.tolist()
+
+
+def test_grid_errors(bcc_small, tmp_path):
+    pos, nbr, bounds = bcc_small
+    n = pos.shape[0]
+    bad = nbr.copy()
+    bad[1, 0] = n + 5                                   # id out of range
+    with pytest.raises(vrt.VrtError) as e:
+        vrt.VoronoiSites(pos, bad, bounds, device=-1)
+    assert e.value.code == _lib.VRT_EGRID
+    bad = nbr.copy()
+    bad[bad == synth.TOP_WALL] = -1                     # no cell touches the top wall
+    with pytest.raises(vrt.VrtError) as e:
+        vrt.VoronoiSites(pos, bad, bounds, device=-1)
+    assert e.value.code == _lib.VRT_EGRID and "not connected" in e.value.message
+    bad = nbr.copy()
+    bad[0, 3] = 99                                      # count beyond the matrix
+    with pytest.raises(vrt.VrtError):
+        vrt.VoronoiSites(pos, bad, bounds, device=-1)
+    with pytest.raises(vrt.VrtError) as e:
+        vrt.read_cell(str(tmp_path / "missing.txt"), n, pos, bounds, device=-1)
+    assert e.value.code == _lib.VRT_EIO
+    f = tmp_path / "garbage.txt"
+    f.write_text("1 2 x 3\n")
+    with pytest.raises(vrt.VrtError) as e:
+        vrt.read_cell(str(f), n, pos, bounds, device=-1)
+    assert e.value.code == _lib.VRT_EIO
+    with pytest.raises(ValueError):
+        vrt.VoronoiSites(pos[:, :2], nbr, bounds, device=-1)
+
+
+def test_read_quadrature():
+    w, th, ph, n = vrt.read_quadrature("ul7n12.dat")
+    assert n == 12 and abs(w.sum() - 1.0) < 1e-12
+    assert (th > 90).sum() == 6 and (th < 90).sum() == 6
+    w, th, ph, n = vrt.read_quadrature(os.path.join(vrt.QUADRATURE_DIR, "ul9n20.dat"))
+    assert n == 20 and abs(w.sum() - 1.0) < 1e-12
+    w, th, ph, n = vrt.read_quadrature("n1.dat")
+    assert (w.tolist(), th.tolist(), ph.tolist()) == ([1.0], [180.0], [0.0])
+    assert np.array_equal(vrt.direction(180.0, 0.0), orc.direction(180.0, 0.0))
+
+
+# ---- the schedule reproduces the serial sweep ----------------------------------------------------
+def _lw(dt):
+    safe = np.where(dt == 0, 1.0, dt)
+    e = np.where(dt < 5e-4, 1 - dt + 0.5 * (dt * dt), np.where(dt > 50, 0.0, np.exp(-dt)))
+    a = np.where(dt < 5e-4, dt * (0.5 - dt / 3), np.where(dt > 50, 1 / safe, (1 - e) / safe - e))
+    b = np.where(dt < 5e-4, dt * (0.5 - dt / 6), np.where(dt > 50, 1 - a, 1 - a - e))
+    return a, b, e
+
+
+def _run_schedule(so, hs, k, S, I0, alpha, dirn, n_sweeps):
+    """Executes the product's level schedule with numpy: within a level all nodes are evaluated
+    from the state before the level (they must be independent), levels in order."""
+    up, dots, w, r, st = orc.upwind_table(so, k)
+    site, z, off = build_schedule(hs, dirn, up, n_sweeps)
+    perm = so.perm_up if dirn > 0 else so.perm_down
+    lay = so.layers_up if dirn > 0 else so.layers_down
+    I = np.full(so.n, np.nan)                    # NaN = never written: reading it is a bug
+    I[perm[: lay[1] - 1] - 1] = I0
+    I[perm[-1] - 1] = 0.0
+    for t in range(len(off) - 1):
+        s = site[off[t]:off[t + 1]] - 1
+        zz = z[off[t]:off[t + 1]]
+        assert np.unique(s).size == s.size       # one write per site per level
+        u1, u2 = up[s, 0] - 1, up[s, 1] - 1
+        I1 = np.where(zz & 1, 0.0, I[u1])
+        I2 = np.where(zz & 2, 0.0, I[u2])
+        assert not np.isnan(I1).any() and not np.isnan(I2).any()
+        # no node of this level may read a site another node of this level writes
+        written = np.zeros(so.n, dtype=bool)
+        written[s] = True
+        assert not (written[u1] & ~(zz & 1).astype(bool)).any()
+        assert not (written[u2] & ~(zz & 2).astype(bool)).any()
+        a1, b1, e1 = _lw(r[s, 0] * (alpha[s] + alpha[u1]) / 2)
+        a2, b2, e2 = _lw(r[s, 1] * (alpha[s] + alpha[u2]) / 2)
+        t1 = ((e1 * I1 + a1 * S[u1]) + b1 * S[s]) * w[s, 0]
+        t2 = ((e2 * I2 + a2 * S[u2]) + b2 * S[s]) * w[s, 1]
+        I[s] = (0.0 + t1) + t2
+    assert not np.isnan(I).any()
+    return I, site.size, len(off) - 1
+
+
+@pytest.mark.parametrize("grid", ["bcc", "voronoi"])
+@pytest.mark.parametrize("n_sweeps", [1, 2, 3, 5])
+def test_schedule_equals_serial_gauss_seidel(grid, n_sweeps, bcc_small, voro_small):
+    pos, nbr, bounds = bcc_small if grid == "bcc" else voro_small
+    so = orc.make_sites(pos, nbr, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)
+    n = so.n
+    rng = np.random.default_rng(7)
+    S = 1 + rng.random(n)
+    alpha = 10 ** rng.uniform(-3, 3, n) / (bounds[3] - bounds[2]) * 10
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    for t, p in list(zip(th, ph))[:: 1 if n_sweeps == 3 else 4]:
+        k = orc.direction(t, p)
+        dirn = 1 if t > 90 else -1
+        lay = so.layers_up if dirn > 0 else so.layers_down
+        I0 = rng.random(lay[1] - 1)
+        ref = (orc.Delaunay_upII if dirn > 0 else orc.Delaunay_downII)(k, S, I0, alpha, so, n_sweeps)
+        got, n_nodes, n_levels = _run_schedule(so, hs, k, S, I0, alpha, dirn, n_sweeps)
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-300)
+        assert n_nodes <= n_sweeps * n          # never more visits than the reference makes
+
+
+def test_schedule_lattice_ordered_ids_deep_chains():
+    """Sites numbered in lattice order give long in-sweep dependency chains (worst case for the
+    level count); the schedule must still be exact."""
+    pos, nbr, bounds = synth.bcc_grid(6, 6, seed=3, permute_ids=False)
+    so = orc.make_sites(pos, nbr, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)
+    rng = np.random.default_rng(1)
+    S = 1 + rng.random(so.n)
+    alpha = 10 ** rng.uniform(-3, 2, so.n) / 6e6 * 10
+    for t, p, dirn in ((109.7, 193.6, 1), (70.3, 346.4, -1)):
+        k = orc.direction(t, p)
+        lay = so.layers_up if dirn > 0 else so.layers_down
+        I0 = rng.random(lay[1] - 1)
+        ref = (orc.Delaunay_upII if dirn > 0 else orc.Delaunay_downII)(k, S, I0, alpha, so, 3)
+        got, _, _ = _run_schedule(so, hs, k, S, I0, alpha, dirn, 3)
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-300)
+
+
+def test_schedule_rejects_site_without_upwind(bcc_small):
+    pos, nbr, bounds = bcc_small
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)
+    so = orc.make_sites(pos, nbr, bounds)
+    up, *_ = orc.upwind_table(so, orc.direction(150.0, 10.0))
+    up = up.copy()
+    victim = so.perm_up[so.layers_up[2]] - 1      # a site of layer 3
+    up[victim] = 0
+    with pytest.raises(vrt.VrtError) as e:
+        build_schedule(hs, +1, up, 3)
+    assert e.value.code == _lib.VRT_EGRID
+
+
+# ---- synthetic grids -----------------------------------------------------------------------------
+def _symmetric(nbr):
+    n = nbr.shape[1]
+    pairs = set()
+    for i in range(n):
+        for v in nbr[1:nbr[0, i] + 1, i]:
+            if v > 0:
+                pairs.add((i + 1, int(v)))
+    return all((b, a) in pairs for a, b in pairs)
+
+
+def test_synthetic_grids_are_valid(bcc_small, voro_small):
+    for pos, nbr, bounds in (bcc_small, voro_small):
+        n = pos.shape[0]
+        assert _symmetric(nbr)
+        assert (nbr[1:] <= n).all() and (nbr[0] >= 4).all()
+        z_min, z_max, x_min, x_max, y_min, y_max = bounds
+        assert (pos[:, 0] > z_min).all() and (pos[:, 0] < z_max).all()
+        assert (pos[:, 1] >= x_min).all() and (pos[:, 1] <= x_max).all()
+    pos, nbr, _ = bcc_small
+    assert pos.shape[0] == 2 * 8 * 8 * 12 and (nbr[0] >= 10).all() and nbr[0].max() == 14
+    assert synth.bcc_grid(8, 12, seed=2)[0].tobytes() == pos.tobytes()      # seeded
+    pos, nbr, _ = voro_small
+    assert 14.0 < nbr[0].mean() < 17.0            # Poisson-Voronoi: 15.54 faces on average
+
+
+def test_counter_rng_is_reproducible():
+    idx = np.arange(1000, dtype=np.uint64)
+    u = synth.counter_uniform(5, 1, idx)
+    assert np.array_equal(u, synth.counter_uniform(5, 1, idx))
+    assert not np.array_equal(u, synth.counter_uniform(6, 1, idx))
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.05
+    pos, _, bounds = synth.bcc_grid(4, 4, seed=1)
+    S, al = synth.synthetic_fields(pos, bounds, 7, seed=3)
+    assert S.shape == (pos.shape[0], 7) and (S > 0).all() and (al > 0).all()
+    S2, al3 = synth.synthetic_fields(pos, bounds, 7, seed=3, n_angles=3)
+    assert np.array_equal(S, S2) and al3.shape == (3, pos.shape[0], 7)
+
+
+# ---- sharding across ranks ---------------------------------------------------------------------------
+def test_partition_covers_all_units():
+    for n_units in (1, 7, 12, 20, 51, 100):
+        for world in (1, 2, 3, 4, 8):
+            blocks = [distributed.partition(n_units, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n_units
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    assert [b - a for a, b in (distributed.partition(51, 8, r) for r in range(8))] == [7, 7, 7, 6, 6, 6, 6, 6]
+
+
+def test_angle_assignment_balanced():
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    for world in (1, 2, 4, 8):
+        parts = distributed.angle_assignment(th, world)
+        allidx = np.sort(np.concatenate(parts))
+        assert allidx.tolist() == list(range(12))
+        sizes = [p.size for p in parts]
+        assert max(sizes) - min(sizes) <= 1
+    parts = distributed.angle_assignment([100.0, 90.0, 80.0], 2)      # θ = 90 is skipped
+    assert sorted(np.concatenate(parts).tolist()) == [0, 2]
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from voronoirt_amd import distributed
+rank, world = distributed.init_process_group("gloo")
+assert world == 2
+n, nlam, n_angles = 500, 7, 12
+rng = np.random.default_rng(0)
+I = rng.random((n_angles, n, nlam))            # stand-in per-angle intensities (same on all ranks)
+w = rng.random(n_angles)
+J_full = np.tensordot(w, I, axes=1)
+# "angle" mode: partial sums over the rank's angles, then the J all-reduce
+theta = np.where(np.arange(n_angles) % 2 == 0, 120.0, 60.0)
+mine = distributed.angle_assignment(theta, world)[rank]
+Jp = torch.from_numpy(np.tensordot(w[mine], I[mine], axes=1).copy())
+distributed.allreduce_J(Jp)
+assert np.allclose(Jp.numpy(), J_full, rtol=1e-13)
+# "lambda" mode: every rank owns a wavelength block of J; all-gather replicates it
+a, b = distributed.partition(nlam, world, rank)
+Jb = torch.from_numpy(J_full[:, a:b].copy())
+Jg = distributed.allgather_J_lambda(Jb, nlam)
+assert np.array_equal(Jg.numpy(), J_full)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_gloo_world2_reduce_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out.decode())
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"rank {r} ok" in out

@@ -258,7 +258,7 @@ def write_sites_file(path: str, positions: np.ndarray) -> None:
     positions[2,:], positions[3,:], positions[1,:] because rows are (z, x, y))."""
     with open(path, "w") as f:
         for i, (z, x, y) in enumerate(positions, start=1):
-            f.write(f"{i}\t{x!r}\t{y!r}\t{z!r}\n")
+            f.write(f"{i}\t{float(x)!r}\t{float(y)!r}\t{float(z)!r}\n")
 
 
 def write_neighbours_file(path: str, neighbours: np.ndarray, seed: int | None = 0) -> None:
