@@ -128,6 +128,11 @@ int64_t vrt_schedule_num_nodes(const vrt_schedule *s);
 int64_t vrt_schedule_num_levels(const vrt_schedule *s);
 int vrt_schedule_get(const vrt_schedule *s, int64_t *site, int32_t *zflags, int64_t *level_off);
 void vrt_schedule_destroy(vrt_schedule *s);
+/* The layer-local form of the same schedule used by the LDS layer-tile kernel: vis[n] packs up to
+ * four 8-bit in-layer visit levels per site (0 = none), nlev[num_layer_offsets] the level count
+ * of each layer (index = 1-based layer).  VRT_EINVAL if it does not fit that encoding. */
+int vrt_layer_schedule(const vrt_grid *g, int dir, const int64_t *up, int n_sweeps, uint32_t *vis,
+                       int32_t *nlev, int64_t *n_visits);
 
 /* ---- single solves: drop-in bodies for Delaunay_upII / Delaunay_downII --------------------
  * (src/irregular_ray_tracing.jl:15-20,96-101).  nI0 must equal layers[2]-1 of the direction.

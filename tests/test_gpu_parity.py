@@ -29,6 +29,14 @@ def _valid_line_mask(so):
     return m
 
 
+@pytest.fixture(params=["tiles", "levels"])
+def path(request, monkeypatch):
+    """Both device paths: the LDS layer-tile kernel (default when the grid fits) and the
+    one-launch-per-level kernels (general fallback)."""
+    monkeypatch.setenv("VRT_PATH", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def grids(bcc_small, voro_small):
     out = {}
@@ -98,7 +106,7 @@ def test_upwind_rows_longer_than_16_and_order_dependence():
 
 
 @pytest.mark.parametrize("name", ["bcc", "voronoi"])
-def test_single_solves_match_oracle(grids, name):
+def test_single_solves_match_oracle(grids, name, path):
     """Delaunay_upII / Delaunay_downII for the 12 directions of ul7n12, random S, α spanning all
     three linear_weights branches, random boundary intensity (also for the down rays)."""
     hs, so = grids[name]
@@ -128,7 +136,7 @@ def test_single_solves_match_oracle(grids, name):
 
 
 @pytest.mark.parametrize("n_sweeps", [1, 2, 4])
-def test_other_sweep_counts(grids, n_sweeps):
+def test_other_sweep_counts(grids, n_sweeps, path):
     hs, so = grids["voronoi"]
     n = so.n
     rng = np.random.default_rng(5)
@@ -152,7 +160,7 @@ def test_up_solver_with_down_pointing_k(grids):
     assert _rel(vrt.Delaunay_upII(k, S, I0, alpha, hs, 3), orc.Delaunay_upII(k, S, I0, alpha, so, 3)) < RTOL
 
 
-def test_golden_vectors(golden):
+def test_golden_vectors(golden, path):
     g = golden
     exp = g["exp"]
     n = g["meta"]["n"]
@@ -178,7 +186,7 @@ def test_golden_vectors(golden):
 
 
 @pytest.mark.parametrize("nlam", [1, 3, 51, 64, 70])
-def test_J_all_alpha_layouts(grids, nlam):
+def test_J_all_alpha_layouts(grids, nlam, path):
     """J_λ_voronoi with α per site, per (site, λ) and per (angle, site, λ); ragged λ counts."""
     hs, so = grids["voronoi"]
     n = so.n
@@ -200,7 +208,7 @@ def test_J_all_alpha_layouts(grids, nlam):
         assert got.shape == (n, nlam) and _rel(got, ref) < RTOL
 
 
-def test_per_angle_intensities_and_theta90_skipped(grids):
+def test_per_angle_intensities_and_theta90_skipped(grids, path):
     hs, so = grids["bcc"]
     n = so.n
     rng = np.random.default_rng(3)
@@ -222,7 +230,7 @@ def test_per_angle_intensities_and_theta90_skipped(grids):
         assert _rel(I[0][:, l], ref_u) < RTOL and _rel(I[2][:, l], ref_d) < RTOL
     ref = orc.J_voronoi(w, theta, phi, S, al, so, I0_up=I0u, I0_down=I0d)
     assert _rel(J, ref) < RTOL
-    assert np.array_equal(J, w[0] * I[0] + w[2] * I[2])        # J accumulates in angle order
+    assert _rel(J, w[0] * I[0] + w[2] * I[2]) < 1e-15
     plan.close()
 
 
@@ -298,7 +306,7 @@ def test_site_without_upwind_is_reported():
     hs.close()
 
 
-def test_execute_dev_with_torch_tensors_and_padding(grids):
+def test_execute_dev_with_torch_tensors_and_padding(grids, path):
     """Device-pointer entry point on a torch stream, with a padded leading dimension."""
     import torch
     hs, so = grids["voronoi"]
@@ -323,7 +331,7 @@ def test_execute_dev_with_torch_tensors_and_padding(grids):
                          dJ=Jd.data_ptr(), dI0_up=I0d.data_ptr(), stream=st.cuda_stream)
     st.synchronize()
     ms, launches = plan.last_sweep_timing()
-    assert ms > 0 and launches == plan.num_levels
+    assert ms > 0 and launches == (plan.num_levels if path == "levels" else 1)
     J = Jd.cpu().numpy()
     ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=4)
     assert _rel(J[:, :nlam], ref) < RTOL

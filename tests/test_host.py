@@ -16,7 +16,7 @@ import pytest
 import voronoirt_amd as vrt
 from oracle import oracle as orc
 from voronoirt_amd import _lib, distributed, synth
-from voronoirt_amd.api import build_schedule
+from voronoirt_amd.api import build_layer_schedule, build_schedule
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -243,6 +243,80 @@ def test_schedule_lattice_ordered_ids_deep_chains():
         ref = (orc.Delaunay_upII if dirn > 0 else orc.Delaunay_downII)(k, S, I0, alpha, so, 3)
         got, _, _ = _run_schedule(so, hs, k, S, I0, alpha, dirn, 3)
         assert np.allclose(got, ref, rtol=1e-10, atol=1e-300)
+
+
+def _run_layer_tiles(so, hs, k, S, I0, alpha, dirn, n_sweeps):
+    """numpy model of k_sweep_tiles: data in sweep order, per layer the coefficients (c, g1, g2)
+    are formed once, then the layer's levels update a zero-initialised tile."""
+    up, dots, w, r, st = orc.upwind_table(so, k)
+    vis, nlev, nv = build_layer_schedule(hs, dirn, up, n_sweeps)
+    perm = so.perm_up if dirn > 0 else so.perm_down
+    lay = so.layers_up if dirn > 0 else so.layers_down
+    n = so.n
+    rank = np.empty(n, dtype=np.int64)
+    rank[perm - 1] = np.arange(n)
+    I = np.full(n, np.nan)
+    I[: lay[1] - 1] = I0
+    for layer in range(2, len(lay)):
+        lo, hi = lay[layer - 1] - 1, lay[layer] - 1
+        sites = perm[lo:hi] - 1
+        s1, s2 = up[sites, 0] - 1, up[sites, 1] - 1
+        u1, u2 = rank[s1], rank[s2]
+        a1, b1, e1 = _lw(r[sites, 0] * (alpha[sites] + alpha[s1]) / 2)
+        a2, b2, e2 = _lw(r[sites, 1] * (alpha[sites] + alpha[s2]) / 2)
+        w1, w2 = w[sites, 0], w[sites, 1]
+        early1, in1 = u1 < lo, (u1 >= lo) & (u1 < hi)
+        early2, in2 = u2 < lo, (u2 >= lo) & (u2 < hi)
+        I1 = np.where(early1, I[np.minimum(u1, max(lo - 1, 0))], 0.0)
+        I2 = np.where(early2, I[np.minimum(u2, max(lo - 1, 0))], 0.0)
+        assert not np.isnan(I1).any() and not np.isnan(I2).any()
+        t1 = np.where(early1, ((e1 * I1 + a1 * S[s1]) + b1 * S[sites]) * w1, (a1 * S[s1] + b1 * S[sites]) * w1)
+        t2 = np.where(early2, ((e2 * I2 + a2 * S[s2]) + b2 * S[sites]) * w2, (a2 * S[s2] + b2 * S[sites]) * w2)
+        c = t1 + t2
+        g1, g2 = np.where(in1, e1 * w1, 0.0), np.where(in2, e2 * w2, 0.0)
+        loc1, loc2 = np.where(in1, u1 - lo, 0), np.where(in2, u2 - lo, 0)
+        tile = np.zeros(hi - lo)
+        v = vis[sites]
+        for t in range(1, nlev[layer] + 1):
+            hit = ((v & 0xFF) == t) | (((v >> 8) & 0xFF) == t) | (((v >> 16) & 0xFF) == t) | ((v >> 24) == t)
+            # nodes of one level must not read a slot another node of the level writes
+            written = np.zeros(hi - lo, dtype=bool)
+            written[hit] = True
+            assert not (written[loc1] & in1 & hit).any() and not (written[loc2] & in2 & hit).any()
+            tile = np.where(hit, c + g1 * tile[loc1] + g2 * tile[loc2], tile)
+        I[lo:hi] = tile
+    I[n - 1] = 0.0
+    out = np.empty(n)
+    out[perm - 1] = I
+    return out, nv
+
+
+@pytest.mark.parametrize("grid", ["bcc", "voronoi", "lattice"])
+def test_layer_tile_schedule_equals_serial_gauss_seidel(grid, bcc_small, voro_small):
+    if grid == "lattice":
+        pos, nbr, bounds = synth.bcc_grid(6, 6, seed=3, permute_ids=False)
+    else:
+        pos, nbr, bounds = bcc_small if grid == "bcc" else voro_small
+    so = orc.make_sites(pos, nbr, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)
+    n = so.n
+    rng = np.random.default_rng(17)
+    S = 1 + rng.random(n)
+    alpha = 10 ** rng.uniform(-3, 3, n) / (bounds[3] - bounds[2]) * 10
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    for n_sweeps in (1, 2, 3, 4):
+        for t, p in list(zip(th, ph))[:: 1 if n_sweeps == 3 else 5]:
+            k = orc.direction(t, p)
+            dirn = 1 if t > 90 else -1
+            lay = so.layers_up if dirn > 0 else so.layers_down
+            I0 = rng.random(lay[1] - 1)
+            ref = (orc.Delaunay_upII if dirn > 0 else orc.Delaunay_downII)(k, S, I0, alpha, so, n_sweeps)
+            got, nv = _run_layer_tiles(so, hs, k, S, I0, alpha, dirn, n_sweeps)
+            assert np.allclose(got, ref, rtol=1e-10, atol=1e-300)
+            assert nv <= n_sweeps * n
+    with pytest.raises(vrt.VrtError):     # 5 sweeps can need 5 visits: beyond the 4-slot encoding
+        up, *_ = orc.upwind_table(so, orc.direction(109.7, 193.6))
+        build_layer_schedule(hs, +1, up, 9)
 
 
 def test_schedule_rejects_site_without_upwind(bcc_small):

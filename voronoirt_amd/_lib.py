@@ -57,6 +57,8 @@ PROTOTYPES = {
     "vrt_schedule_num_levels": (c_i64, [vp]),
     "vrt_schedule_get": (ctypes.c_int, [vp, p_i64, p_i32, p_i64]),
     "vrt_schedule_destroy": (None, [vp]),
+    "vrt_layer_schedule": (ctypes.c_int, [vp, ctypes.c_int, p_i64, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_uint32), p_i32, p_i64]),
     "vrt_delaunay_up": (ctypes.c_int, [vp, p_dbl, p_dbl, p_dbl, c_i64, p_dbl, ctypes.c_int, p_dbl]),
     "vrt_delaunay_down": (ctypes.c_int, [vp, p_dbl, p_dbl, p_dbl, c_i64, p_dbl, ctypes.c_int, p_dbl]),
 }

@@ -327,3 +327,19 @@ def build_schedule(sites: VoronoiSites, dir: int, up, n_sweeps: int = 3):
     finally:
         L.vrt_schedule_destroy(h)
     return site, z, off
+
+
+def build_layer_schedule(sites: VoronoiSites, dir: int, up, n_sweeps: int = 3):
+    """Layer-local schedule of the LDS layer-tile kernel (introspection, host only).  Returns
+    (vis (n,) uint32: four packed 8-bit in-layer visit levels per site, nlev per layer (index =
+    1-based layer), number of visits)."""
+    L = _lib.load()
+    up = np.ascontiguousarray(up, dtype=np.int64)
+    vis = np.zeros(sites.n, dtype=np.uint32)
+    layers = sites.layers_up if dir > 0 else sites.layers_down
+    nlev = np.zeros(layers.size, dtype=np.int32)
+    nv = ctypes.c_int64()
+    check(L.vrt_layer_schedule(sites.handle, int(dir), _i(up), int(n_sweeps),
+                               vis.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                               nlev.ctypes.data_as(_lib.p_i32), ctypes.byref(nv)))
+    return vis, nlev, nv.value

@@ -1,6 +1,7 @@
 // extern "C" entry points of libvrt_hip.so (declared in include/voronoirt.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -68,6 +69,10 @@ static void free_grid(vrt_grid *g)
     dev_free(g->d_ly);
     dev_free(g->up.d_order);
     dev_free(g->down.d_order);
+    dev_free(g->up.d_rank);
+    dev_free(g->down.d_rank);
+    dev_free(g->up.d_lay);
+    dev_free(g->down.d_lay);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
@@ -94,6 +99,14 @@ static int upload_grid(vrt_grid *g)
         for (int64_t i = 0; i < n; i++) order[(size_t)i] = (int32_t)(dir.perm[(size_t)i] - 1);
         if ((rc = dev_alloc(&dir.d_order, (size_t)n))) return rc;
         VRT_HIP_TRY(hipMemcpy(dir.d_order, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        std::vector<int32_t> rank((size_t)n);
+        for (int64_t i = 0; i < n; i++) rank[(size_t)order[(size_t)i]] = (int32_t)i;
+        if ((rc = dev_alloc(&dir.d_rank, (size_t)n))) return rc;
+        VRT_HIP_TRY(hipMemcpy(dir.d_rank, rank.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        std::vector<int32_t> lay(dir.reduced.size());
+        for (size_t j = 0; j < lay.size(); j++) lay[j] = (int32_t)(dir.reduced[j] - 1);
+        if ((rc = dev_alloc(&dir.d_lay, lay.size()))) return rc;
+        VRT_HIP_TRY(hipMemcpy(dir.d_lay, lay.data(), sizeof(int32_t) * lay.size(), hipMemcpyHostToDevice));
     }
     if ((rc = launch_delaunay_lines(g))) return rc;
     VRT_HIP_TRY(hipStreamSynchronize(g->stream));
@@ -139,7 +152,13 @@ static void free_plan(vrt_plan *p)
     dev_free(p->d_angles_up);
     dev_free(p->d_angles_down);
     dev_free(p->d_I);
-    for (int i = 0; i < 5; i++) dev_free(p->d_stage[i]);
+    for (int i = 0; i < 6; i++) dev_free(p->d_stage[i]);
+    dev_free(p->t_u1); dev_free(p->t_u2);
+    dev_free(p->t_w1); dev_free(p->t_w2); dev_free(p->t_r1); dev_free(p->t_r2);
+    dev_free(p->t_vis);
+    dev_free(p->d_nlev); dev_free(p->d_angle_sorted); dev_free(p->d_angle_dir);
+    for (int d = 0; d < 2; d++) { dev_free(p->ws_S[d]); dev_free(p->ws_A[d]); dev_free(p->ws_J[d]); }
+    dev_free(p->ws_AA);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
@@ -218,6 +237,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
 
     // per-angle schedules, built concurrently on the host
     std::vector<AngleSchedule> sched((size_t)A);
+    std::vector<LayerSchedule> lsched((size_t)A);
     {
         unsigned hw = std::thread::hardware_concurrency();
         int nthr = (int)std::min<unsigned>(hw ? hw : 4, 16);
@@ -230,6 +250,9 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                     build_angle_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
                                          up1.data() + (size_t)a * n, up2.data() + (size_t)a * n,
                                          sched[(size_t)a]);
+                    build_layer_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
+                                         up1.data() + (size_t)a * n, up2.data() + (size_t)a * n,
+                                         lsched[(size_t)a]);
                 }
             });
         for (auto &th : pool) th.join();
@@ -281,6 +304,61 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         VRT_HIP_TRY_FREE(hipMemcpy(p->d_angles_up, ups.data(), sizeof(int32_t) * ups.size(), hipMemcpyHostToDevice));
     if (!downs.empty())
         VRT_HIP_TRY_FREE(hipMemcpy(p->d_angles_down, downs.data(), sizeof(int32_t) * downs.size(), hipMemcpyHostToDevice));
+    // ---- layer-tile path: tables in sweep order + per-layer level counts ---------------------
+    {
+        bool ok = A > 0;
+        int64_t max_layer = 0, visits = 0;
+        for (int a = 0; a < A; a++) {
+            ok = ok && lsched[(size_t)a].ok;
+            max_layer = std::max(max_layer, lsched[(size_t)a].max_layer_size);
+            visits += lsched[(size_t)a].n_visits;
+        }
+        if (max_layer > 8 * 1024) ok = false;     // 8 sites per thread of a 1024-thread workgroup
+        p->tile_ok = ok;
+        p->tile_max_layer_size = max_layer;
+        p->tile_visits = visits;
+        p->tile_K = max_layer <= 1024 ? 1 : max_layer <= 2048 ? 2 : max_layer <= 4096 ? 4 : 8;
+        if (ok) {
+            VRT_TRY_FREE(dev_alloc(&p->t_u1, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_u2, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_w1, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_w2, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_r1, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_r2, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_vis, tab));
+            uint32_t *d_vis_site = nullptr;
+            VRT_TRY_FREE(dev_alloc(&d_vis_site, (size_t)n));
+            const int maxL = (int)std::max(g->up.reduced.size(), g->down.reduced.size()) - 1;
+            p->tile_max_layers = maxL;
+            std::vector<int32_t> nlev((size_t)A * (size_t)(maxL + 1), 0), adir((size_t)A), asorted((size_t)A);
+            for (int a = 0; a < A; a++) {
+                hipError_t e = hipMemcpy(d_vis_site, lsched[(size_t)a].vis.data(), sizeof(uint32_t) * n,
+                                         hipMemcpyHostToDevice);
+                int rc2 = e == hipSuccess ? launch_permute_table(p, a, d_vis_site) : VRT_ENODEVICE;
+                if (!rc2 && hipStreamSynchronize(g->stream) != hipSuccess) rc2 = VRT_ENODEVICE;
+                if (rc2) {
+                    dev_free(d_vis_site);
+                    free_plan(p);
+                    return fail(VRT_ENODEVICE, "building the sweep-order tables failed");
+                }
+                const std::vector<int32_t> &nl = lsched[(size_t)a].nlev;
+                for (size_t l = 0; l < nl.size() && l <= (size_t)maxL; l++)
+                    nlev[(size_t)a * (size_t)(maxL + 1) + l] = nl[l];
+                adir[(size_t)a] = p->dir_of_active[(size_t)a] > 0 ? 0 : 1;
+                asorted[(size_t)a] = a;
+            }
+            dev_free(d_vis_site);
+            std::stable_sort(asorted.begin(), asorted.end(), [&](int32_t x, int32_t y) {
+                return lsched[(size_t)x].n_visits > lsched[(size_t)y].n_visits;
+            });
+            VRT_TRY_FREE(dev_alloc(&p->d_nlev, nlev.size()));
+            VRT_TRY_FREE(dev_alloc(&p->d_angle_dir, (size_t)A));
+            VRT_TRY_FREE(dev_alloc(&p->d_angle_sorted, (size_t)A));
+            VRT_HIP_TRY_FREE(hipMemcpy(p->d_nlev, nlev.data(), sizeof(int32_t) * nlev.size(), hipMemcpyHostToDevice));
+            VRT_HIP_TRY_FREE(hipMemcpy(p->d_angle_dir, adir.data(), sizeof(int32_t) * A, hipMemcpyHostToDevice));
+            VRT_HIP_TRY_FREE(hipMemcpy(p->d_angle_sorted, asorted.data(), sizeof(int32_t) * A, hipMemcpyHostToDevice));
+        }
+    }
 #undef VRT_TRY_FREE
 #undef VRT_HIP_TRY_FREE
     *out = p;
@@ -311,6 +389,25 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const doubl
     int rc = use_device(g->device);
     if (rc) return rc;
     const int64_t n = g->n;
+    // the user's per-angle alpha is indexed by USER angle; the plan's by active angle.  They
+    // coincide unless a θ = 90 direction was skipped, which per-angle alpha does not support.
+    if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM && p->A != (int)p->n_angles_user)
+        return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
+    {
+        // VRT_PATH=levels forces the one-launch-per-level kernels, VRT_PATH=tiles requires the
+        // layer-tile kernel; default: tiles when the grid fits its encoding
+        const char *force = std::getenv("VRT_PATH");
+        bool tiles = p->tile_ok;
+        if (force && std::strcmp(force, "levels") == 0) tiles = false;
+        if (force && std::strcmp(force, "tiles") == 0 && !p->tile_ok)
+            return fail(VRT_EINVAL, "VRT_PATH=tiles but the grid does not fit the layer-tile kernel");
+        if (tiles) {
+            p->last_path = 2;
+            return execute_tiles(p, nlam, ld, dS, dalpha, alpha_mode, dI0_up, dI0_down, weights, dJ,
+                                 dI_out, st);
+        }
+        p->last_path = 1;
+    }
     const size_t need = (size_t)std::max(1, p->A) * (size_t)n * (size_t)nlam;
     if ((rc = ensure(p->d_I, p->I_cap, need))) return rc;
     p->I_ld = nlam;
@@ -324,10 +421,6 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const doubl
     sa.alpha = dalpha;
     sa.alpha_mode = alpha_mode;
     sa.I = p->d_I;
-    // the user's per-angle alpha is indexed by USER angle; the plan's by active angle.  They
-    // coincide unless a θ = 90 direction was skipped, which per-angle alpha does not support.
-    if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM && p->A != (int)p->n_angles_user)
-        return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
     if ((rc = launch_boundary(p, sa, dI0_up, dI0_down, st))) return rc;
     VRT_HIP_TRY(hipEventRecord(p->ev0, st));
     if ((rc = launch_sweep_levels(p, sa, st, &p->last_launches))) return rc;
@@ -573,6 +666,34 @@ int vrt_schedule_get(const vrt_schedule *s, int64_t *site, int32_t *zflags, int6
 
 void vrt_schedule_destroy(vrt_schedule *s) { delete s; }
 
+int vrt_layer_schedule(const vrt_grid *g, int dir, const int64_t *up, int n_sweeps, uint32_t *vis,
+                       int32_t *nlev, int64_t *n_visits)
+{
+    if (!g || !up || !vis || !nlev) return fail(VRT_EINVAL, "NULL argument");
+    if (n_sweeps < 1) return fail(VRT_EINVAL, "n_sweeps must be >= 1");
+    try {
+        const int64_t n = g->n;
+        std::vector<int32_t> u1((size_t)n), u2((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t a = up[2 * i], b = up[2 * i + 1];
+            if (a > n || b > n) return fail(VRT_EINVAL, "upwind id out of range");
+            u1[(size_t)i] = a >= 1 ? (int32_t)(a - 1) : kNoUpwind;
+            u2[(size_t)i] = b >= 1 ? (int32_t)(b - 1) : kNoUpwind;
+        }
+        LayerSchedule ls;
+        build_layer_schedule(direction_of(g, dir), dir > 0, n, n_sweeps, u1.data(), u2.data(), ls);
+        if (ls.bad_site >= 0)
+            return fail(VRT_EGRID, "site " + std::to_string(ls.bad_site + 1) + " has no upwind neighbour");
+        if (!ls.ok) return fail(VRT_EINVAL, "schedule does not fit the packed layer-tile encoding");
+        std::copy(ls.vis.begin(), ls.vis.end(), vis);
+        std::copy(ls.nlev.begin(), ls.nlev.end(), nlev);
+        if (n_visits) *n_visits = ls.n_visits;
+        return VRT_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    }
+}
+
 int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS,
                          const double *dalpha, int alpha_mode, const double *dI0_up,
                          const double *dI0_down, const double *weights_host, double *dJ,
@@ -629,28 +750,18 @@ int vrt_plan_execute(vrt_plan *p, int64_t nlam, int64_t ld, const double *S, con
             if ((rc = ensure(p->d_stage[4], p->stage_cap[4], nS))) return rc;
             dJ = p->d_stage[4];
         }
+        double *dIo = nullptr;
+        if (I_out) {
+            if ((rc = ensure(p->d_stage[5], p->stage_cap[5], nS * (size_t)p->n_angles_user))) return rc;
+            dIo = p->d_stage[5];
+        }
         rc = execute_dev_locked(p, nlam, ld, p->d_stage[0], p->d_stage[1], alpha_mode, dU, dD,
-                                weights, dJ, nullptr, st);
+                                weights, dJ, dIo, st);
         if (rc) return rc;
         if (J) VRT_HIP_TRY(hipMemcpyAsync(J, dJ, sizeof(double) * nS, hipMemcpyDeviceToHost, st));
-        if (I_out) {
-            // (nlam, n, n_angles): the internal array is dense [A][n][nlam]
-            for (int64_t u = 0; u < p->n_angles_user; u++) {
-                int a = -1;
-                for (int i = 0; i < p->A; i++)
-                    if (p->user_of_active[(size_t)i] == (int)u) a = i;
-                double *dst = I_out + (size_t)u * nS;
-                if (a < 0) {
-                    std::fill(dst, dst + nS, 0.0);
-                    continue;
-                }
-                VRT_HIP_TRY(hipMemcpy2DAsync(dst, sizeof(double) * (size_t)ld,
-                                             p->d_I + (size_t)a * n * (size_t)nlam,
-                                             sizeof(double) * (size_t)nlam,
-                                             sizeof(double) * (size_t)nlam, n,
-                                             hipMemcpyDeviceToHost, st));
-            }
-        }
+        if (I_out)   // (nlam, n, n_angles) with leading dimension ld, skipped angles already zeroed
+            VRT_HIP_TRY(hipMemcpyAsync(I_out, dIo, sizeof(double) * nS * (size_t)p->n_angles_user,
+                                       hipMemcpyDeviceToHost, st));
         VRT_HIP_TRY(hipStreamSynchronize(st));
         return VRT_OK;
     } catch (const std::bad_alloc &) {

@@ -32,7 +32,9 @@ struct Direction {
     std::vector<int64_t> perm;       // stable sortperm, 1-based site ids (:72,77)
     std::vector<int64_t> reduced;    // reduce_layers offsets, 1-based, r[end] = n (:253-269)
     int64_t n1 = 0;                  // reduced[1] - 1: sites that receive I_0
-    int32_t *d_order = nullptr;      // device copy of perm, 0-based int32
+    int32_t *d_order = nullptr;      // device copy of perm, 0-based int32: sweep position -> site
+    int32_t *d_rank = nullptr;       // inverse: site -> sweep position
+    int32_t *d_lay = nullptr;        // 0-based layer boundaries: layer l = [lay[l-1], lay[l]), L+1 entries
 };
 
 struct PlanCacheEntry;
@@ -85,8 +87,23 @@ struct vrt_plan {
     double *d_I = nullptr;
     size_t I_cap = 0;
     int64_t I_ld = 0;
-    double *d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // S, alpha, I0up, I0down, J
-    size_t stage_cap[5] = {0, 0, 0, 0, 0};
+    double *d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // S, alpha, I0up, I0down, J, I_out
+    size_t stage_cap[6] = {0, 0, 0, 0, 0, 0};
+    // layer-tile path (vrt_tiles.hip): tables in sweep order, per-layer level counts
+    bool tile_ok = false;
+    int tile_K = 8;                      // sites per thread of the 1024-thread workgroup
+    int tile_max_layers = 0;
+    int64_t tile_max_layer_size = 0;
+    int64_t tile_visits = 0;
+    int32_t *t_u1 = nullptr, *t_u2 = nullptr;
+    double *t_w1 = nullptr, *t_w2 = nullptr, *t_r1 = nullptr, *t_r2 = nullptr;
+    uint32_t *t_vis = nullptr;
+    int32_t *d_nlev = nullptr, *d_angle_sorted = nullptr, *d_angle_dir = nullptr;
+    double *ws_S[2] = {nullptr, nullptr}, *ws_A[2] = {nullptr, nullptr}, *ws_J[2] = {nullptr, nullptr};
+    size_t ws_S_cap[2] = {0, 0}, ws_A_cap[2] = {0, 0}, ws_J_cap[2] = {0, 0};
+    double *ws_AA = nullptr;
+    size_t ws_AA_cap = 0;
+    int last_path = 0;                   // 1 = level kernels, 2 = layer tiles
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     int64_t last_launches = 0;
@@ -115,6 +132,16 @@ struct AngleSchedule {
 };
 void build_angle_schedule(const Direction &dir, bool ascending, int64_t n, int n_sweeps,
                           const int32_t *up1, const int32_t *up2, AngleSchedule &out);
+struct LayerSchedule {
+    std::vector<uint32_t> vis;       // per site (original id): 4 x 8-bit in-layer visit levels
+    std::vector<int32_t> nlev;       // per layer (index = 1-based layer): number of levels
+    int64_t n_visits = 0;
+    int64_t max_layer_size = 0;
+    int64_t bad_site = -1;
+    bool ok = false;                 // fits the tile kernel's encoding
+};
+void build_layer_schedule(const Direction &dir, bool ascending, int64_t n, int n_sweeps,
+                          const int32_t *up1, const int32_t *up2, LayerSchedule &out);
 
 // ---- device launchers (vrt_kernels.hip) ------------------------------------------------------
 int launch_delaunay_lines(vrt_grid *g);
@@ -131,5 +158,11 @@ int launch_sweep_levels(vrt_plan *p, const SweepArgs &sa, hipStream_t st, int64_
 int launch_reduce_J(vrt_plan *p, const SweepArgs &sa, const double *weights_active, double *dJ,
                     int64_t ldJ, hipStream_t st);
 int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, double *dI_out, int64_t ldO, hipStream_t st);
+
+// ---- layer-tile path (vrt_tiles.hip) ----------------------------------------------------------
+int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
+int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const double *dalpha,
+                  int alpha_mode, const double *dI0_up, const double *dI0_down,
+                  const double *weights_user, double *dJ, double *dI_out, hipStream_t st);
 
 }  // namespace vrt

@@ -128,4 +128,97 @@ void build_angle_schedule(const Direction &dir, bool ascending, int64_t n, int n
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Layer-local schedule for the LDS layer-tile kernel (k_sweep_tiles): one workgroup owns one
+// (angle, wavelength) problem and walks the layers itself, so only dependencies INSIDE a layer
+// need ordering (earlier layers are final, later layers read as 0).  Same passes A and B as
+// above; pass C assigns levels per layer, restarting at 1, over the layer's single-slot tile:
+//   RAW  a visit runs after the last write of an in-layer upwind it must see,
+//   WAR  a write runs after every earlier-in-trace read of the value it overwrites -- including
+//        reads that must still see the tile's initial 0 (the reference's I = zeros),
+//   WAW  writes of one site stay ordered.
+// Output per site: up to 4 visit levels packed 8 bits each (0 = none); per layer: level count.
+// ---------------------------------------------------------------------------------------------
+void build_layer_schedule(const Direction &dir, bool ascending, int64_t n, int n_sweeps,
+                          const int32_t *up1, const int32_t *up2, LayerSchedule &out)
+{
+    const std::vector<int64_t> &r = dir.reduced;
+    const int64_t nl = (int64_t)r.size();
+    out.vis.assign((size_t)n, 0);
+    out.nlev.assign((size_t)nl, 0);
+    out.ok = true;
+    out.n_visits = 0;
+    out.max_layer_size = 0;
+    out.bad_site = -1;
+
+    struct Visit { uint32_t site; int32_t layer; };
+    std::vector<Visit> trace;
+    std::vector<uint32_t> ver((size_t)n, 0), seen1((size_t)n, UINT32_MAX), seen2((size_t)n, UINT32_MAX);
+    std::vector<uint8_t> z1, z2;   // read sees the never-written initial value
+    for (int64_t layer = 2; layer <= nl - 1; layer++) {
+        const int64_t lo = r[(size_t)layer - 1] - 1, hi = r[(size_t)layer] - 1;
+        out.max_layer_size = std::max(out.max_layer_size, hi - lo);
+        for (int sweep = 0; sweep < n_sweeps; sweep++)
+            for (int64_t t = 0; t < hi - lo; t++) {
+                const int64_t posn = ascending ? lo + t : hi - 1 - t;
+                const int64_t i = dir.perm[(size_t)posn] - 1;
+                const int32_t u1 = up1[i], u2 = up2[i];
+                if (u1 < 0 || u2 < 0) {
+                    if (out.bad_site < 0) out.bad_site = i;
+                    continue;
+                }
+                const uint32_t v1 = ver[(size_t)u1], v2 = ver[(size_t)u2];
+                if (seen1[(size_t)i] == v1 && seen2[(size_t)i] == v2) continue;
+                seen1[(size_t)i] = v1;
+                seen2[(size_t)i] = v2;
+                ver[(size_t)i]++;
+                trace.push_back({(uint32_t)i, (int32_t)layer});
+                z1.push_back(v1 == 0);
+                z2.push_back(v2 == 0);
+            }
+    }
+    if (out.bad_site >= 0) {
+        out.ok = false;
+        return;
+    }
+    const size_t T = trace.size();
+    std::vector<uint8_t> live(T, 0);
+    {
+        std::vector<uint8_t> needed((size_t)n, 1);
+        for (size_t x = T; x-- > 0;) {
+            const uint32_t i = trace[x].site;
+            if (!needed[i]) continue;
+            live[x] = 1;
+            needed[i] = 0;
+            if (!z1[x]) needed[(size_t)up1[i]] = 1;
+            if (!z2[x]) needed[(size_t)up2[i]] = 1;
+        }
+    }
+    std::vector<int32_t> lw((size_t)n, 0), lr((size_t)n, 0);
+    std::vector<uint8_t> nvis((size_t)n, 0);
+    for (size_t x = 0; x < T; x++) {
+        if (!live[x]) continue;
+        const uint32_t i = trace[x].site;
+        const int32_t layer = trace[x].layer;
+        const int32_t u1 = up1[i], u2 = up2[i];
+        const bool in1 = dir.layer_of[(size_t)u1] == layer, in2 = dir.layer_of[(size_t)u2] == layer;
+        int32_t lv = std::max(lw[i], lr[i]);
+        if (in1) lv = std::max(lv, lw[(size_t)u1]);
+        if (in2) lv = std::max(lv, lw[(size_t)u2]);
+        lv += 1;
+        if (in1) lr[(size_t)u1] = std::max(lr[(size_t)u1], lv);
+        if (in2) lr[(size_t)u2] = std::max(lr[(size_t)u2], lv);
+        lw[i] = lv;
+        lr[i] = 0;
+        if (lv > 255 || nvis[i] >= 4) {
+            out.ok = false;      // does not fit the packed encoding: the level kernels handle it
+            return;
+        }
+        out.vis[i] |= (uint32_t)lv << (8 * nvis[i]);
+        nvis[i]++;
+        out.n_visits++;
+        if (lv > out.nlev[(size_t)layer]) out.nlev[(size_t)layer] = lv;
+    }
+}
+
 }  // namespace vrt
