@@ -51,6 +51,10 @@ def parse_args():
     ap.add_argument("--shard", default="lambda", choices=["lambda", "angle"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lam", type=int, default=0, help="wavelengths in the CPU sample")
+    ap.add_argument("--angle-groups", type=int, default=1,
+                    help="diagnostics: run the angles in this many sequential groups (separate plans)")
+    ap.add_argument("--alpha0", type=float, default=1.0e-2,
+                    help="opacity scale at z_min [1/m] (diagnostics: tiny values take the Taylor branch)")
     return ap.parse_args()
 
 
@@ -64,10 +68,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    rank, world = distributed.init_process_group()
+    # VRT_BENCH_REHEARSE=1: every rank uses GPU 0 and the gloo backend (single-GPU rehearsal of
+    # the N > 1 code path; RCCL refuses two ranks on one device)
+    rehearse = os.environ.get("VRT_BENCH_REHEARSE") == "1"
+    rank, world = distributed.init_process_group("gloo" if rehearse else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if rehearse else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -104,7 +111,7 @@ def main():
     centre, sigma = 0.5 * (nlam - 1), max(nlam / 6.0, 1.0)
     S = 1.0 + 0.5 * torch.sin(2 * np.pi * (z - z_min) / (z_max - z_min))[:, None] \
         + 0.1 * torch.rand((n, nlam), generator=gen, device=dev, dtype=torch.float64)
-    strat = 1.0e-2 * torch.exp(-(z - z_min) / 0.7e6)
+    strat = args.alpha0 * torch.exp(-(z - z_min) / 0.7e6)
     if per_angle:
         alpha = torch.empty((A, n, nlam), device=dev, dtype=torch.float64)
         for j, ai in enumerate(my_angles):
@@ -127,11 +134,34 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
 
+    groups = None
+    if args.angle_groups > 1:
+        # diagnostics only: per-group plans, J of each group into its own buffer (the final add is
+        # not timed); groups = contiguous runs of the angle list sorted up-first
+        order = sorted(range(A), key=lambda j: (dirs_all[my_angles[j]] < 0, j))
+        chunks = np.array_split(np.array(order), args.angle_groups)
+        groups = []
+        for ch in chunks:
+            ch = np.sort(ch)
+            gp = vrt.FormalPlan(sites, k_all[my_angles[ch]], 3, dirs=dirs_all[my_angles[ch]])
+            ga = alpha[ch].contiguous() if per_angle else alpha
+            groups.append((gp, ga, w_mine[ch], torch.zeros_like(J)))
+
     def step():
+        if groups is not None:
+            for gp, ga, gw, gJ in groups:
+                gp.execute_dev(nlam, nlam, S.data_ptr(), ga.data_ptr(), alpha_mode, gw,
+                               dJ=gJ.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream)
+            return
         plan.execute_dev(nlam, nlam, S.data_ptr(), alpha.data_ptr(), alpha_mode, w_mine,
                          dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream)
         if args.shard == "angle" and world > 1:
-            distributed.allreduce_J(J)
+            if rehearse:       # gloo reduces host tensors
+                Jh = J.cpu()
+                distributed.allreduce_J(Jh)
+                J.copy_(Jh)
+            else:
+                distributed.allreduce_J(J)
 
     def barrier():
         if world > 1:
@@ -147,9 +177,13 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    sweep_ms, launches = plan.last_sweep_timing()    # HIP events on the launch stream, last step
+    if groups is not None:
+        tl = [gp.last_sweep_timing() for gp, _, _, _ in groups]
+        sweep_ms, launches = sum(t[0] for t in tl), sum(t[1] for t in tl)
+    else:
+        sweep_ms, launches = plan.last_sweep_timing()    # HIP events on the launch stream, last step
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

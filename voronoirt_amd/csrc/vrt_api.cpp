@@ -73,6 +73,10 @@ static void free_grid(vrt_grid *g)
     dev_free(g->down.d_rank);
     dev_free(g->up.d_lay);
     dev_free(g->down.d_lay);
+    dev_free(g->up.d_store);
+    dev_free(g->down.d_store);
+    dev_free(g->up.d_srank);
+    dev_free(g->down.d_srank);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
@@ -103,6 +107,12 @@ static int upload_grid(vrt_grid *g)
         for (int64_t i = 0; i < n; i++) rank[(size_t)order[(size_t)i]] = (int32_t)i;
         if ((rc = dev_alloc(&dir.d_rank, (size_t)n))) return rc;
         VRT_HIP_TRY(hipMemcpy(dir.d_rank, rank.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        std::vector<int32_t> srank((size_t)n);
+        for (int64_t i = 0; i < n; i++) srank[(size_t)dir.store[(size_t)i]] = (int32_t)i;
+        if ((rc = dev_alloc(&dir.d_store, (size_t)n))) return rc;
+        if ((rc = dev_alloc(&dir.d_srank, (size_t)n))) return rc;
+        VRT_HIP_TRY(hipMemcpy(dir.d_store, dir.store.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        VRT_HIP_TRY(hipMemcpy(dir.d_srank, srank.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
         std::vector<int32_t> lay(dir.reduced.size());
         for (size_t j = 0; j < lay.size(); j++) lay[j] = (int32_t)(dir.reduced[j] - 1);
         if ((rc = dev_alloc(&dir.d_lay, lay.size()))) return rc;
@@ -156,9 +166,10 @@ static void free_plan(vrt_plan *p)
     dev_free(p->t_u1); dev_free(p->t_u2);
     dev_free(p->t_w1); dev_free(p->t_w2); dev_free(p->t_r1); dev_free(p->t_r2);
     dev_free(p->t_vis);
-    dev_free(p->d_nlev); dev_free(p->d_angle_sorted); dev_free(p->d_angle_dir);
+    dev_free(p->d_nlev); dev_free(p->d_angle_dir); dev_free(p->d_task_map);
     for (int d = 0; d < 2; d++) { dev_free(p->ws_S[d]); dev_free(p->ws_A[d]); dev_free(p->ws_J[d]); }
     dev_free(p->ws_AA);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
@@ -271,6 +282,8 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         total += (int64_t)sched[(size_t)a].site.size();
     }
     // merge: global level t = union over the angles of their level t
+    std::vector<int32_t> srank_up((size_t)n);
+    for (int64_t i = 0; i < n; i++) srank_up[(size_t)g->up.store[(size_t)i]] = (int32_t)i;
     std::vector<uint32_t> node_site((size_t)total), node_meta((size_t)total);
     p->level_off.assign((size_t)max_levels + 1, 0);
     int64_t at = 0;
@@ -279,7 +292,16 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         for (int a = 0; a < A; a++) {
             const AngleSchedule &s = sched[(size_t)a];
             if (t + 1 >= (int64_t)s.level_off.size()) continue;
-            for (int64_t x = s.level_off[(size_t)t]; x < s.level_off[(size_t)t + 1]; x++) {
+            // Nodes of one level are independent, so their order inside the launch is free: sort
+            // them along the (layer, Morton(x, y)) storage curve so that neighbouring workgroups
+            // work on neighbouring sites and the upwind rows they share are still in L2.
+            const int64_t x0 = s.level_off[(size_t)t], x1 = s.level_off[(size_t)t + 1];
+            std::vector<std::pair<int32_t, int64_t>> keyed((size_t)(x1 - x0));
+            for (int64_t x = x0; x < x1; x++)
+                keyed[(size_t)(x - x0)] = {srank_up[(size_t)s.site[(size_t)x]], x};
+            std::sort(keyed.begin(), keyed.end());
+            for (const auto &kv : keyed) {
+                const int64_t x = kv.second;
                 node_site[(size_t)at] = s.site[(size_t)x];
                 node_meta[(size_t)at] = (uint32_t)a | ((uint32_t)s.zflags[(size_t)x] << 8);
                 at++;
@@ -317,7 +339,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         p->tile_ok = ok;
         p->tile_max_layer_size = max_layer;
         p->tile_visits = visits;
-        p->tile_K = max_layer <= 1024 ? 1 : max_layer <= 2048 ? 2 : max_layer <= 4096 ? 4 : 8;
+        p->tile_K = max_layer <= 2048 ? 2 : max_layer <= 4096 ? 4 : 8;
         if (ok) {
             VRT_TRY_FREE(dev_alloc(&p->t_u1, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_u2, tab));
@@ -330,7 +352,8 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             VRT_TRY_FREE(dev_alloc(&d_vis_site, (size_t)n));
             const int maxL = (int)std::max(g->up.reduced.size(), g->down.reduced.size()) - 1;
             p->tile_max_layers = maxL;
-            std::vector<int32_t> nlev((size_t)A * (size_t)(maxL + 1), 0), adir((size_t)A), asorted((size_t)A);
+            std::vector<int32_t> nlev((size_t)A * (size_t)(maxL + 1), 0), adir((size_t)A);
+            p->angle_visits.assign((size_t)A, 0);
             for (int a = 0; a < A; a++) {
                 hipError_t e = hipMemcpy(d_vis_site, lsched[(size_t)a].vis.data(), sizeof(uint32_t) * n,
                                          hipMemcpyHostToDevice);
@@ -345,18 +368,13 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                 for (size_t l = 0; l < nl.size() && l <= (size_t)maxL; l++)
                     nlev[(size_t)a * (size_t)(maxL + 1) + l] = nl[l];
                 adir[(size_t)a] = p->dir_of_active[(size_t)a] > 0 ? 0 : 1;
-                asorted[(size_t)a] = a;
+                p->angle_visits[(size_t)a] = lsched[(size_t)a].n_visits + n;   // + n: phase 1 touches every site
             }
             dev_free(d_vis_site);
-            std::stable_sort(asorted.begin(), asorted.end(), [&](int32_t x, int32_t y) {
-                return lsched[(size_t)x].n_visits > lsched[(size_t)y].n_visits;
-            });
             VRT_TRY_FREE(dev_alloc(&p->d_nlev, nlev.size()));
             VRT_TRY_FREE(dev_alloc(&p->d_angle_dir, (size_t)A));
-            VRT_TRY_FREE(dev_alloc(&p->d_angle_sorted, (size_t)A));
             VRT_HIP_TRY_FREE(hipMemcpy(p->d_nlev, nlev.data(), sizeof(int32_t) * nlev.size(), hipMemcpyHostToDevice));
             VRT_HIP_TRY_FREE(hipMemcpy(p->d_angle_dir, adir.data(), sizeof(int32_t) * A, hipMemcpyHostToDevice));
-            VRT_HIP_TRY_FREE(hipMemcpy(p->d_angle_sorted, asorted.data(), sizeof(int32_t) * A, hipMemcpyHostToDevice));
         }
     }
 #undef VRT_TRY_FREE
@@ -394,11 +412,13 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const doubl
     if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM && p->A != (int)p->n_angles_user)
         return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
     {
-        // VRT_PATH=levels forces the one-launch-per-level kernels, VRT_PATH=tiles requires the
-        // layer-tile kernel; default: tiles when the grid fits its encoding
+        // Two device paths produce the same results: "levels" (one launch per dependency level,
+        // any grid; the default -- it measures faster on MI355X) and
+        // "tiles" (one workgroup per (angle, wavelength) with the layer in LDS; needs layers of
+        // at most 8192 sites).  VRT_PATH selects one explicitly.
         const char *force = std::getenv("VRT_PATH");
-        bool tiles = p->tile_ok;
-        if (force && std::strcmp(force, "levels") == 0) tiles = false;
+        bool tiles = false;
+        if (force && std::strcmp(force, "tiles") == 0) tiles = true;
         if (force && std::strcmp(force, "tiles") == 0 && !p->tile_ok)
             return fail(VRT_EINVAL, "VRT_PATH=tiles but the grid does not fit the layer-tile kernel");
         if (tiles) {
@@ -423,7 +443,39 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const doubl
     sa.I = p->d_I;
     if ((rc = launch_boundary(p, sa, dI0_up, dI0_down, st))) return rc;
     VRT_HIP_TRY(hipEventRecord(p->ev0, st));
-    if ((rc = launch_sweep_levels(p, sa, st, &p->last_launches))) return rc;
+    {
+        // The level sequence is hundreds to thousands of short dependent launches.  VRT_GRAPH=1
+        // captures it once into a hipGraph and replays it while the arguments stay the same.
+        // Measured on MI355X it changes nothing (C2: 7.57 vs 7.56 ms, C4: 24.87 vs 24.91 ms --
+        // the launches are bound by the dependent-load latency inside each level, not by the
+        // host), so eager launches stay the default.
+        const char *genv = std::getenv("VRT_GRAPH");
+        const bool use_graph = genv && genv[0] == '1';
+        SweepKey key;
+        key.nlam = sa.nlam; key.ldS = sa.ldS; key.ldA = sa.ldA; key.ldI = sa.ldI;
+        key.S = sa.S; key.alpha = sa.alpha; key.I = sa.I; key.alpha_mode = sa.alpha_mode;
+        bool replayed = false;
+        if (use_graph) {
+            if (!(p->graph_exec && p->graph_key == key)) {
+                if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+                p->graph_exec = nullptr;
+                hipGraph_t graph = nullptr;
+                if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const int rc2 = launch_sweep_levels(p, sa, st, &p->last_launches);
+                    const hipError_t e = hipStreamEndCapture(st, &graph);
+                    if (rc2 == VRT_OK && e == hipSuccess && graph &&
+                        hipGraphInstantiate(&p->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess)
+                        p->graph_key = key;
+                    else
+                        p->graph_exec = nullptr;
+                    if (graph) (void)hipGraphDestroy(graph);
+                }
+                (void)hipGetLastError();
+            }
+            if (p->graph_exec && hipGraphLaunch(p->graph_exec, st) == hipSuccess) replayed = true;
+        }
+        if (!replayed && (rc = launch_sweep_levels(p, sa, st, &p->last_launches))) return rc;
+    }
     VRT_HIP_TRY(hipEventRecord(p->ev1, st));
     p->ev_valid = true;
     if (dJ) {

@@ -7,6 +7,7 @@
 // gives exactly "unassigned cells that list a cell of the previous layer" (voronoi_utils.jl:
 // 109-119) also for asymmetric neighbour lists, and detects unreachable cells (where the
 // reference loops forever) instead of hanging.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -123,6 +124,43 @@ static int layer_direction(const vrt_grid *g, int64_t wall, const std::vector<in
     for (int64_t l = 2; l <= L; l++) d.reduced[(size_t)l - 1] = start[(size_t)l] + 1;
     d.reduced[(size_t)L] = n;
     d.n1 = d.reduced[1] - 1;
+
+    // storage order for the layer-tile kernel: (layer, Morton(x, y)), perm[n] kept last
+    {
+        auto spread = [](uint32_t v) {            // 16 bits -> every other bit of 32
+            v &= 0xFFFFu;
+            v = (v | (v << 8)) & 0x00FF00FFu;
+            v = (v | (v << 4)) & 0x0F0F0F0Fu;
+            v = (v | (v << 2)) & 0x33333333u;
+            v = (v | (v << 1)) & 0x55555555u;
+            return v;
+        };
+        const double x0 = g->bounds[2], xs = g->bounds[3] - g->bounds[2];
+        const double y0 = g->bounds[4], ys = g->bounds[5] - g->bounds[4];
+        std::vector<uint64_t> key((size_t)n);
+        const int64_t last_site = d.perm[(size_t)n - 1] - 1;
+        for (int64_t i = 0; i < n; i++) {
+            double fx = xs > 0 ? (g->pos[3 * (size_t)i + 1] - x0) / xs : 0.0;
+            double fy = ys > 0 ? (g->pos[3 * (size_t)i + 2] - y0) / ys : 0.0;
+            fx = fx < 0 ? 0 : (fx > 1 ? 1 : fx);
+            fy = fy < 0 ? 0 : (fy > 1 ? 1 : fy);
+            const uint32_t m = spread((uint32_t)(fx * 65535.0)) | (spread((uint32_t)(fy * 65535.0)) << 1);
+            key[(size_t)i] = ((uint64_t)(uint32_t)d.layer_of[(size_t)i] << 32) | m;
+            if (i == last_site) key[(size_t)i] = ((uint64_t)(uint32_t)d.layer_of[(size_t)i] << 32) | 0xFFFFFFFFull;
+        }
+        d.store.resize((size_t)n);
+        for (int64_t i = 0; i < n; i++) d.store[(size_t)i] = (int32_t)i;
+        std::stable_sort(d.store.begin(), d.store.end(), [&](int32_t a, int32_t b) {
+            return key[(size_t)a] < key[(size_t)b];
+        });
+        // make sure the never-visited site really is last inside its (last) layer
+        for (int64_t q = n - 1; q >= 0; q--)
+            if (d.store[(size_t)q] == (int32_t)last_site) {
+                for (int64_t t = q; t < n - 1; t++) d.store[(size_t)t] = d.store[(size_t)t + 1];
+                d.store[(size_t)n - 1] = (int32_t)last_site;
+                break;
+            }
+    }
     return VRT_OK;
 }
 

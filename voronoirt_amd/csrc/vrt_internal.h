@@ -35,9 +35,28 @@ struct Direction {
     int32_t *d_order = nullptr;      // device copy of perm, 0-based int32: sweep position -> site
     int32_t *d_rank = nullptr;       // inverse: site -> sweep position
     int32_t *d_lay = nullptr;        // 0-based layer boundaries: layer l = [lay[l-1], lay[l]), L+1 entries
+    // STORAGE order of the layer-tile path: layers contiguous exactly like the sweep order, but
+    // inside a layer the sites are sorted along a Morton curve over (x, y) so that spatial
+    // neighbours (and therefore upwind gathers) share cache lines; the never-visited last site
+    // perm[n] stays at position n-1.  The Gauss-Seidel ORDER is unaffected (it lives in the schedule).
+    std::vector<int32_t> store;      // storage position -> site (0-based)
+    int32_t *d_store = nullptr;
+    int32_t *d_srank = nullptr;      // site -> storage position
 };
 
 struct PlanCacheEntry;
+
+// arguments a captured level-launch graph was recorded with
+struct SweepKey {
+    int64_t nlam = -1, ldS = 0, ldA = 0, ldI = 0;
+    const void *S = nullptr, *alpha = nullptr, *I = nullptr;
+    int alpha_mode = -1;
+    bool operator==(const SweepKey &o) const
+    {
+        return nlam == o.nlam && ldS == o.ldS && ldA == o.ldA && ldI == o.ldI && S == o.S &&
+               alpha == o.alpha && I == o.I && alpha_mode == o.alpha_mode;
+    }
+};
 
 }  // namespace vrt
 
@@ -98,12 +117,20 @@ struct vrt_plan {
     int32_t *t_u1 = nullptr, *t_u2 = nullptr;
     double *t_w1 = nullptr, *t_w2 = nullptr, *t_r1 = nullptr, *t_r2 = nullptr;
     uint32_t *t_vis = nullptr;
-    int32_t *d_nlev = nullptr, *d_angle_sorted = nullptr, *d_angle_dir = nullptr;
+    int32_t *d_nlev = nullptr, *d_angle_dir = nullptr;
+    std::vector<int64_t> angle_visits;   // surviving visits per active angle (task cost)
+    std::vector<int32_t> h_task_map;     // block -> angle | wavelength << 8
+    int32_t *d_task_map = nullptr;
+    size_t task_map_cap = 0;
+    int task_map_nlam = -1;
     double *ws_S[2] = {nullptr, nullptr}, *ws_A[2] = {nullptr, nullptr}, *ws_J[2] = {nullptr, nullptr};
     size_t ws_S_cap[2] = {0, 0}, ws_A_cap[2] = {0, 0}, ws_J_cap[2] = {0, 0};
     double *ws_AA = nullptr;
     size_t ws_AA_cap = 0;
     int last_path = 0;                   // 1 = level kernels, 2 = layer tiles
+    // hipGraph of the level-launch sequence, replayed while the arguments stay the same
+    hipGraphExec_t graph_exec = nullptr;
+    vrt::SweepKey graph_key;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     int64_t last_launches = 0;

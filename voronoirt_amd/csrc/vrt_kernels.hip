@@ -278,7 +278,14 @@ k_sweep_level(int64_t first, int count, int nlam, int64_t n, int64_t ldS, int64_
               const double *__restrict__ r1, const double *__restrict__ r2,
               const double *__restrict__ S, const double *__restrict__ alpha, double *I)
 {
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so
+    // blocks b, b+8, b+16, ... -- one XCD -- take a CONTIGUOUS eighth of the Morton-sorted node
+    // list; neighbouring sites then share upwind rows through that XCD's L2.  Bijective remap
+    // (cdna_hip_programming.md, "XCD swizzle must be bijective"); placement only affects speed.
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const unsigned qd = nb >> 3, rm = nb & 7u;
+    const unsigned chunk = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    const unsigned t = chunk * blockDim.x + threadIdx.x;
     const unsigned q = nlam == 1 ? t : t / (unsigned)nlam;
     if (q >= (unsigned)count) return;
     const unsigned l = nlam == 1 ? 0u : t - q * (unsigned)nlam;

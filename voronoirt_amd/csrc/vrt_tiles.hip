@@ -19,6 +19,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "vrt_internal.h"
 
@@ -55,7 +57,7 @@ int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site)
     const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
     const size_t o = (size_t)a * (size_t)n;
     hipLaunchKernelGGL(k_permute_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g->stream, n,
-                       dir.d_order, dir.d_rank, p->d_up1 + o, p->d_up2 + o, p->d_w1 + o, p->d_w2 + o,
+                       dir.d_store, dir.d_srank, p->d_up1 + o, p->d_up2 + o, p->d_w1 + o, p->d_w2 + o,
                        p->d_r1 + o, p->d_r2 + o, d_vis_site, p->t_u1 + o, p->t_u2 + o, p->t_w1 + o,
                        p->t_w2 + o, p->t_r1 + o, p->t_r2 + o, p->t_vis + o);
     VRT_HIP_TRY(hipGetLastError());
@@ -95,6 +97,7 @@ k_gather_vec(int64_t n, const int32_t *__restrict__ order, const double *__restr
 // I[a][l][p] = I0[p][l] for p < n1 (boundary layer, already in sweep order), blockIdx.z = angle slot
 __global__ void __launch_bounds__(256)
 k_boundary_sweep_order(int64_t n, int nlam, int64_t n1, const int32_t *__restrict__ angles,
+                       const int32_t *__restrict__ order, const int32_t *__restrict__ srank,
                        const double *__restrict__ I0, double *__restrict__ I)
 {
     __shared__ double tile[64][65];
@@ -110,26 +113,76 @@ k_boundary_sweep_order(int64_t n, int nlam, int64_t n1, const int32_t *__restric
     double *Ia = I + (size_t)a * (size_t)nlam * (size_t)n;
     for (int c = ty; c < 64; c += 4) {
         const int l = l0 + c;
-        if (l < nlam && p0 + tx < n1) Ia[(size_t)l * n + p0 + tx] = tile[tx][c];
+        // I_0 is ordered like perm[1:n1] (irregular_ray_tracing.jl:33); storage is Morton order
+        if (l < nlam && p0 + tx < n1) Ia[(size_t)l * n + srank[order[p0 + tx]]] = tile[tx][c];
     }
 }
 
 // ---- the solver ---------------------------------------------------------------------------------
+// linear_weights (functions.jl:484-500) with the arithmetic trimmed for the ALU-bound phase 1:
+// one Newton-refined reciprocal shared by the thick and the exponential branch, the Taylor
+// branch's /3 and /6 as multiplications, and exp(-x) for the only range it is needed in
+// (5e-4 <= x <= 50: no overflow, underflow, NaN or subnormal handling).  Each piece is accurate
+// to ~1 ulp; results differ from the oracle's libm at the 1e-16 level (contract: 1e-10).
+__device__ __forceinline__ double exp_neg(double x)       // exp(-x), 5e-4 <= x <= 50
+{
+    const double t = -x;
+    const double kf = rint(t * 1.4426950408889634074);    // k = round(t / ln 2), |k| <= 73
+    double r = fma(-kf, 6.93147180369123816490e-01, t);   // Cody-Waite: ln2 = hi + lo
+    r = fma(-kf, 1.90821492927058770002e-10, r);           // |r| <= 0.3466
+    double p = 1.0 / 6227020800.0;                         // Taylor to r^13/13!: remainder < 4e-18
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+
 __device__ __forceinline__ void lin_weights(double dtau, double &a, double &b, double &e)
 {
-    if (dtau < 5e-4) {                       // functions.jl:484-500
+    // reciprocal of dtau (only consumed when dtau >= 5e-4): hardware estimate + 2 Newton steps
+    double rc = __builtin_amdgcn_rcp(dtau);
+    rc = fma(fma(-dtau, rc, 1.0), rc, rc);
+    rc = fma(fma(-dtau, rc, 1.0), rc, rc);
+    const double ee = exp_neg(fmin(fmax(dtau, 5e-4), 50.0));
+    if (dtau < 5e-4) {
         e = 1.0 - dtau + 0.5 * (dtau * dtau);
-        a = dtau * (0.5 - dtau / 3.0);
-        b = dtau * (0.5 - dtau / 6.0);
+        a = dtau * (0.5 - dtau * (1.0 / 3.0));
+        b = dtau * (0.5 - dtau * (1.0 / 6.0));
     } else if (dtau > 50.0) {
         e = 0.0;
-        a = 1.0 / dtau;
+        a = rc;
         b = 1.0 - a;
     } else {
-        e = exp(-dtau);
-        a = (1.0 - e) / dtau - e;
+        e = ee;
+        a = (1.0 - e) * rc - e;
         b = 1.0 - a - e;
     }
+}
+
+// 32-bit byte offsets from a wave-uniform base: lets the compiler use the saddr + voffset form of
+// global_load (one VGPR per address instead of a 64-bit pair) -- the phase-1 batches are
+// register-bound.  Planes are n * 8 bytes < 4 GiB.
+__device__ __forceinline__ double ldd(const double *base, unsigned idx)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (size_t)(idx << 3));
+}
+__device__ __forceinline__ int ldi(const int32_t *base, unsigned idx)
+{
+    return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(base) + (size_t)(idx << 2));
+}
+__device__ __forceinline__ uint32_t ldu(const uint32_t *base, unsigned idx)
+{
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(base) + (size_t)(idx << 2));
 }
 
 struct TileArgs {
@@ -138,7 +191,8 @@ struct TileArgs {
     int A;
     int alpha_mode;
     int max_layers;                 // stride of nlev
-    const int32_t *angle_sorted;    // heaviest angle first (dispatch order = task order)
+    int tile_stride;                // doubles per LDS array (>= largest layer)
+    const int32_t *task_map;        // block -> angle | wavelength << 8 (XCD-aware, see build_task_map)
     const int32_t *angle_dir;       // [A] 0 = up, 1 = down
     const int32_t *lay[2];          // per direction: 0-based [lo, hi) boundaries, lay[d][L+1]
     int nlayers[2];                 // number of BFS layers per direction
@@ -150,18 +204,20 @@ struct TileArgs {
     const double *alpha[2];         // SITE: [n]; SITE_LAM: [nlam][n] per direction
     const double *alpha_angle;      // ANGLE: [A][nlam][n]
     double *I;                      // [A][nlam][n]
+    long long *dbg;                 // diagnostics (VRT_TILE_DEBUG=1): per task phase cycles, else NULL
 };
 
 template <int K>
 __global__ void __launch_bounds__(1024)
 k_sweep_tiles(TileArgs ta)
 {
-    extern __shared__ __attribute__((aligned(16))) double tile[];   // I of the current layer
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // I of the current layer, then the constant terms
+    double *cst = tile + ta.tile_stride;
     const int T = 1024;
     const int tid = threadIdx.x;
     const int task = blockIdx.x;
-    const int a = ta.angle_sorted[task / ta.nlam];
-    const int l = task % ta.nlam;
+    const int a = ta.task_map[task] & 0xFF;
+    const int l = ta.task_map[task] >> 8;
     const int d = ta.angle_dir[a];
     const int64_t n = ta.n;
     const size_t tab = (size_t)a * (size_t)n;
@@ -182,58 +238,105 @@ k_sweep_tiles(TileArgs ta)
     const int32_t *__restrict__ nlev = ta.nlev + (size_t)a * (size_t)(ta.max_layers + 1);
     const int L = ta.nlayers[d];
 
+    long long cyc1 = 0, cyc2 = 0, cyc3 = 0;
+    const bool timing = ta.dbg != nullptr;
     for (int layer = 2; layer <= L; layer++) {          // irregular_ray_tracing.jl:37
+        long long t0 = timing ? clock64() : 0;
         const int lo = lay[layer - 1], hi = lay[layer];  // hi of the last layer = n-1: perm[n] is never visited
         const int cnt = hi - lo;
-        double c[K], g1[K], g2[K];
-        int loc1[K], loc2[K];
+        double g1[K], g2[K];      // in-layer couplings e_r w_r (registers); the constant term c sits in LDS
+        uint32_t loc[K];        // in-layer tile slots of the two upwinds, 16 bits each
         uint32_t vis[K];
-        // ---- phase 1: coefficients of every site of the layer (global reads, registers) ----
+        // ---- phase 1: coefficients of every site of the layer (global reads -> registers).
+        // Straight-line, branch-free batches of two sites so that the 24 independent loads of a
+        // batch are in flight together (the dependent chain table -> gathers is paid per batch,
+        // not per site); invalid slots are clamped to the layer's last site and masked via vis.
+        // software pipeline: the table entries (upwind positions) of batch b+1 are requested
+        // while batch b's data loads are in flight, so only the first batch of a layer pays the
+        // dependent table -> gather latency.
+        int nu1[2], nu2[2];
+        uint32_t nvis[2];
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            const int slot = tid + k * T;
-            c[k] = 0.0; g1[k] = 0.0; g2[k] = 0.0; loc1[k] = 0; loc2[k] = 0; vis[k] = 0;
-            if (slot < cnt) {
-                const int p = lo + slot;
-                const int u1 = tu1[p], u2 = tu2[p];
-                const double w1 = tw1[p], w2 = tw2[p], r1 = tr1[p], r2 = tr2[p];
-                vis[k] = tvis[p];
-                const double S_c = S[p], a_c = Al[p];
-                const double S_1 = S[u1], a_1 = Al[u1], S_2 = S[u2], a_2 = Al[u2];
-                double ca, cb, ce;
-                lin_weights(r1 * (a_c + a_1) / 2.0, ca, cb, ce);       // trapezoidal, functions.jl:393
-                double t1;
-                if (u1 < lo) {                                           // earlier layer: final value
-                    t1 = ((ce * I[u1] + ca * S_1) + cb * S_c) * w1;
-                } else {
-                    t1 = (ca * S_1 + cb * S_c) * w1;
-                    if (u1 < hi) { g1[k] = ce * w1; loc1[k] = u1 - lo; } // in-layer: coupled through the tile
-                }                                                        // later layer / perm[n]: reads 0
-                lin_weights(r2 * (a_c + a_2) / 2.0, ca, cb, ce);
-                double t2;
-                if (u2 < lo) {
-                    t2 = ((ce * I[u2] + ca * S_2) + cb * S_c) * w2;
-                } else {
-                    t2 = (ca * S_2 + cb * S_c) * w2;
-                    if (u2 < hi) { g2[k] = ce * w2; loc2[k] = u2 - lo; }
-                }
-                c[k] = t1 + t2;
-                tile[slot] = 0.0;                                        // I = zero(S), :23
+        for (int j = 0; j < 2; j++) {
+            const int slot = tid + j * T;
+            const int p = lo + min(slot, cnt - 1);
+            nu1[j] = ldi(tu1, p);
+            nu2[j] = ldi(tu2, p);
+            nvis[j] = slot < cnt ? ldu(tvis, p) : 0u;
+        }
+#pragma unroll
+        for (int kb = 0; kb < K; kb += 2) {
+            int pp[2], uu1[2], uu2[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int slot = tid + (kb + j) * T;
+                pp[j] = lo + min(slot, cnt - 1);
+                uu1[j] = nu1[j];
+                uu2[j] = nu2[j];
+                vis[kb + j] = nvis[j];
             }
+            double w1[2], w2[2], r1[2], r2[2], S_c[2], a_c[2], S_1[2], a_1[2], S_2[2], a_2[2], I_1[2], I_2[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int p = pp[j], u1 = uu1[j], u2 = uu2[j];
+                w1[j] = ldd(tw1, p); w2[j] = ldd(tw2, p); r1[j] = ldd(tr1, p); r2[j] = ldd(tr2, p);
+                S_c[j] = ldd(S, p); a_c[j] = ldd(Al, p);
+                S_1[j] = ldd(S, u1); a_1[j] = ldd(Al, u1);
+                S_2[j] = ldd(S, u2); a_2[j] = ldd(Al, u2);
+                I_1[j] = ldd(I, min(u1, lo - 1));  // only used when u1 < lo (earlier layer: final)
+                I_2[j] = ldd(I, min(u2, lo - 1));
+            }
+            if (kb + 2 < K) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int slot = tid + (kb + 2 + j) * T;
+                    const int p = lo + min(slot, cnt - 1);
+                    nu1[j] = ldi(tu1, p);
+                    nu2[j] = ldi(tu2, p);
+                    nvis[j] = slot < cnt ? ldu(tvis, p) : 0u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int u1 = uu1[j], u2 = uu2[j];
+                double ca, cb, ce;
+                lin_weights(r1[j] * (a_c[j] + a_1[j]) / 2.0, ca, cb, ce);   // trapezoidal, functions.jl:393
+                const bool early1 = u1 < lo, in1 = (u1 >= lo) & (u1 < hi);   // else: later layer / perm[n] reads 0
+                const double t1 = early1 ? ((ce * I_1[j] + ca * S_1[j]) + cb * S_c[j]) * w1[j]
+                                         : (ca * S_1[j] + cb * S_c[j]) * w1[j];
+                const double gg1 = in1 ? ce * w1[j] : 0.0;
+                lin_weights(r2[j] * (a_c[j] + a_2[j]) / 2.0, ca, cb, ce);
+                const bool early2 = u2 < lo, in2 = (u2 >= lo) & (u2 < hi);
+                const double t2 = early2 ? ((ce * I_2[j] + ca * S_2[j]) + cb * S_c[j]) * w2[j]
+                                         : (ca * S_2[j] + cb * S_c[j]) * w2[j];
+                const double gg2 = in2 ? ce * w2[j] : 0.0;
+                g1[kb + j] = gg1;
+                g2[kb + j] = gg2;
+                loc[kb + j] = (in1 ? (uint32_t)(u1 - lo) : 0u) | ((in2 ? (uint32_t)(u2 - lo) : 0u) << 16);
+                const int slot = tid + (kb + j) * T;
+                if (slot < cnt) {
+                    tile[slot] = 0.0;                                        // I = zero(S), :23
+                    cst[slot] = t1 + t2;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);    // keep the batches apart: hoisting more loads spills
         }
         __syncthreads();
+        long long t1c = timing ? clock64() : 0;
         // ---- phase 2: the layer's Gauss-Seidel levels on the LDS tile ------------------------
         const int nl = nlev[layer];
         for (int t = 1; t <= nl; t++) {
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const uint32_t v = vis[k];
-                const bool hit = ((v & 0xFFu) == (uint32_t)t) | (((v >> 8) & 0xFFu) == (uint32_t)t) |
-                                 (((v >> 16) & 0xFFu) == (uint32_t)t) | ((v >> 24) == (uint32_t)t);
-                if (hit) tile[tid + k * T] = c[k] + g1[k] * tile[loc1[k]] + g2[k] * tile[loc2[k]];
+                // a site's visits come at increasing levels: the low byte is the next one
+                if ((vis[k] & 0xFFu) == (uint32_t)t) {
+                    tile[tid + k * T] = cst[tid + k * T] + g1[k] * tile[loc[k] & 0xFFFFu] + g2[k] * tile[loc[k] >> 16];
+                    vis[k] >>= 8;
+                }
             }
             __syncthreads();
         }
+        long long t2c = timing ? clock64() : 0;
         // ---- phase 3: the layer is final -> global, visible to this workgroup's next layers ---
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -241,6 +344,14 @@ k_sweep_tiles(TileArgs ta)
             if (slot < cnt) I[lo + slot] = tile[slot];
         }
         __syncthreads();
+        if (timing) {
+            const long long t3c = clock64();
+            cyc1 += t1c - t0; cyc2 += t2c - t1c; cyc3 += t3c - t2c;
+        }
+    }
+    if (timing && tid == 0) {
+        ta.dbg[4 * task + 0] = cyc1; ta.dbg[4 * task + 1] = cyc2; ta.dbg[4 * task + 2] = cyc3;
+        ta.dbg[4 * task + 3] = a;
     }
     if (tid == 0) I[n - 1] = 0.0;   // the never-visited site perm[n] keeps I = 0 (voronoi_utils.jl:266)
 }
@@ -333,6 +444,62 @@ static int ensure_dev(double *&buf, size_t &cap, size_t count)
     return VRT_OK;
 }
 
+// Block -> (angle, wavelength) map.  Workgroups are dealt round-robin to the 8 XCDs (block b runs
+// on the XCD that also runs b + 8, b + 16, ...: MI355X_MICROARCH.md, speed only), and every
+// XCD has a private 4 MB L2.  The 44-byte-per-site upwind table of an angle is shared by all
+// wavelength tasks of that angle, so each angle's wavelengths are split into two groups and the
+// groups are dealt to the XCDs (longest-processing-time first): the tasks that share a table
+// run on one XCD, in lockstep, and read it from that XCD's L2 instead of HBM.  A different
+// placement would only be slower, never wrong.
+static int build_task_map(vrt_plan *p, int nlam, hipStream_t st)
+{
+    const int A = p->A;
+    if (p->task_map_nlam == nlam && p->d_task_map) return VRT_OK;
+    const int ntask = A * nlam;
+    struct Group { int a, l0, l1; double cost; };
+    std::vector<Group> groups;
+    const int halves = nlam >= 2 ? 2 : 1;
+    for (int a = 0; a < A; a++)
+        for (int h = 0; h < halves; h++) {
+            const int l0 = h * nlam / halves, l1 = (h + 1) * nlam / halves;
+            groups.push_back({a, l0, l1, (double)p->angle_visits[(size_t)a] * (double)(l1 - l0)});
+        }
+    std::stable_sort(groups.begin(), groups.end(), [](const Group &x, const Group &y) { return x.cost > y.cost; });
+    std::vector<std::vector<int>> per_xcd(8);      // task lists, heaviest groups first
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const Group &gr : groups) {
+        int x = 0;
+        for (int q = 1; q < 8; q++)
+            if (load[q] < load[x]) x = q;
+        load[x] += gr.cost;
+        for (int l = gr.l0; l < gr.l1; l++) per_xcd[(size_t)x].push_back(gr.a | (l << 8));
+    }
+    // interleave: block b takes the next task of XCD b % 8; XCDs that run dry borrow from the fullest
+    p->h_task_map.assign((size_t)ntask, 0);
+    size_t cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < ntask; b++) {
+        int x = b % 8;
+        if (cur[x] >= per_xcd[(size_t)x].size()) {
+            size_t best = 0;
+            for (int q = 0; q < 8; q++) {
+                const size_t left = per_xcd[(size_t)q].size() - cur[q];
+                if (left > best) { best = left; x = q; }
+            }
+        }
+        p->h_task_map[(size_t)b] = per_xcd[(size_t)x][cur[x]++];
+    }
+    if (!p->d_task_map || p->task_map_cap < (size_t)ntask) {
+        if (p->d_task_map) (void)hipFree(p->d_task_map);
+        p->d_task_map = nullptr;
+        VRT_HIP_TRY(hipMalloc((void **)&p->d_task_map, sizeof(int32_t) * (size_t)std::max(ntask, 1)));
+        p->task_map_cap = (size_t)ntask;
+    }
+    VRT_HIP_TRY(hipMemcpyAsync(p->d_task_map, p->h_task_map.data(), sizeof(int32_t) * (size_t)ntask,
+                               hipMemcpyHostToDevice, st));
+    p->task_map_nlam = nlam;
+    return VRT_OK;
+}
+
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const double *dalpha,
                   int alpha_mode, const double *dI0_up, const double *dI0_down,
                   const double *weights_user, double *dJ, double *dI_out, hipStream_t st)
@@ -353,7 +520,9 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     ta.A = A;
     ta.alpha_mode = alpha_mode;
     ta.max_layers = p->tile_max_layers;
-    ta.angle_sorted = p->d_angle_sorted;
+    ta.tile_stride = (int)((std::max<int64_t>(p->tile_max_layer_size, 1) + 1) & ~(int64_t)1);
+    if ((rc = build_task_map(p, (int)nlam, st))) return rc;
+    ta.task_map = p->d_task_map;
     ta.angle_dir = p->d_angle_dir;
     ta.nlev = p->d_nlev;
     ta.t_u1 = p->t_u1; ta.t_u2 = p->t_u2;
@@ -368,17 +537,17 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         ta.S[d] = nullptr;
         ta.alpha[d] = nullptr;
         if (!use_dir[d]) continue;
-        hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_order, dS,
+        hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_store, dS,
                            p->ws_S[d]);
         ta.S[d] = p->ws_S[d];
         if (alpha_mode == VRT_ALPHA_SITE) {
             if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], (size_t)n))) return rc;
             hipLaunchKernelGGL(k_gather_vec, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
-                               dir.d_order, dalpha, p->ws_A[d]);
+                               dir.d_store, dalpha, p->ws_A[d]);
             ta.alpha[d] = p->ws_A[d];
         } else if (alpha_mode == VRT_ALPHA_SITE_LAM) {
             if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], plane))) return rc;
-            hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_order,
+            hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_store,
                                dalpha, p->ws_A[d]);
             ta.alpha[d] = p->ws_A[d];
         }
@@ -386,27 +555,30 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         if (dir.n1 > 0) {
             const dim3 bgrid((unsigned)((dir.n1 + 63) / 64), (unsigned)((nlam + 63) / 64), (unsigned)cnt);
             hipLaunchKernelGGL(k_boundary_sweep_order, bgrid, dim3(256), 0, st, n, (int)nlam, dir.n1,
-                               d == 0 ? p->d_angles_up : p->d_angles_down, d == 0 ? dI0_up : dI0_down,
-                               p->d_I);
+                               d == 0 ? p->d_angles_up : p->d_angles_down, dir.d_order, dir.d_srank,
+                               d == 0 ? dI0_up : dI0_down, p->d_I);
         }
     }
     if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM) {
         if ((rc = ensure_dev(p->ws_AA, p->ws_AA_cap, (size_t)A * plane))) return rc;
         for (int a = 0; a < A; a++) {
             const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-            hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_order,
+            hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_store,
                                dalpha + (size_t)a * (size_t)n * (size_t)ld, p->ws_AA + (size_t)a * plane);
         }
         ta.alpha_angle = p->ws_AA;
     }
     VRT_HIP_TRY(hipGetLastError());
 
+    const bool debug = std::getenv("VRT_TILE_DEBUG") != nullptr;
+    long long *d_dbg = nullptr;
+    ta.dbg = nullptr;
+    if (debug && hipMalloc((void **)&d_dbg, sizeof(long long) * 4 * (size_t)A * (size_t)nlam) == hipSuccess) ta.dbg = d_dbg;
     VRT_HIP_TRY(hipEventRecord(p->ev0, st));
     if (A > 0) {
-        const size_t lds = (size_t)std::max<int64_t>(p->tile_max_layer_size, 1) * sizeof(double);
+        const size_t lds = 2 * (size_t)ta.tile_stride * sizeof(double);
         const dim3 grid((unsigned)((size_t)A * (size_t)nlam));
         switch (p->tile_K) {
-        case 1: hipLaunchKernelGGL(k_sweep_tiles<1>, grid, dim3(1024), lds, st, ta); break;
         case 2: hipLaunchKernelGGL(k_sweep_tiles<2>, grid, dim3(1024), lds, st, ta); break;
         case 4: hipLaunchKernelGGL(k_sweep_tiles<4>, grid, dim3(1024), lds, st, ta); break;
         default: hipLaunchKernelGGL(k_sweep_tiles<8>, grid, dim3(1024), lds, st, ta); break;
@@ -416,6 +588,17 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     VRT_HIP_TRY(hipEventRecord(p->ev1, st));
     p->ev_valid = true;
     p->last_launches = 1;
+    if (d_dbg) {
+        (void)hipStreamSynchronize(st);
+        std::vector<long long> h(4 * (size_t)A * (size_t)nlam);
+        (void)hipMemcpy(h.data(), d_dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+        (void)hipFree(d_dbg);
+        double s1 = 0, s2 = 0, s3 = 0;
+        for (size_t t = 0; t < (size_t)A * (size_t)nlam; t++) { s1 += h[4 * t]; s2 += h[4 * t + 1]; s3 += h[4 * t + 2]; }
+        const double nt = (double)A * (double)nlam;
+        std::fprintf(stderr, "[vrt tiles] mean cycles per task (s_memtime, 100 MHz): phase1 %.0f phase2 %.0f phase3 %.0f; first task %lld %lld %lld, last task %lld %lld %lld\n",
+                     s1 / nt, s2 / nt, s3 / nt, h[0], h[1], h[2], h[h.size() - 4], h[h.size() - 3], h[h.size() - 2]);
+    }
 
     if (dJ) {
         double *Jd[2] = {nullptr, nullptr};
@@ -434,8 +617,8 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
                                (int64_t)plane, (int64_t)plane, dw, p->d_I, p->ws_J[d]);
             Jd[d] = p->ws_J[d];
         }
-        hipLaunchKernelGGL(k_combine_J, tgrid, dim3(256), 0, st, n, (int)nlam, ld, g->up.d_order,
-                           g->down.d_rank, Jd[0], Jd[1], dJ);
+        hipLaunchKernelGGL(k_combine_J, tgrid, dim3(256), 0, st, n, (int)nlam, ld, g->up.d_store,
+                           g->down.d_srank, Jd[0], Jd[1], dJ);
         VRT_HIP_TRY(hipGetLastError());
     }
     if (dI_out) {
@@ -444,7 +627,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         for (int64_t u = 0; u < p->n_angles_user; u++) {
             const int a = active_of_user[(size_t)u];
             const Direction &dir = (a >= 0 && p->dir_of_active[(size_t)a] < 0) ? g->down : g->up;
-            hipLaunchKernelGGL(k_from_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_order,
+            hipLaunchKernelGGL(k_from_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_store,
                                a >= 0 ? p->d_I + (size_t)a * plane : nullptr,
                                dI_out + (size_t)u * (size_t)n * (size_t)ld);
         }
