@@ -218,12 +218,16 @@ def main():
     out["roofline"] = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-        "kernel": "k_sweep_level", "launches_per_step": launches,
+        "kernel": {"levels": "k_sweep_level (one launch per dependency level)",
+                   "steps": "k_step_coeffs + k_step_levels (two launches per BFS layer)",
+                   "tiles": "k_sweep_tiles (one persistent launch)"}.get(plan.last_path, plan.last_path),
+        "path": plan.last_path, "launches_per_step": launches,
         "sweep_ms_per_step": sweep_ms, "avg_launch_us": sweep_ms * 1e3 / max(launches, 1),
         "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
         "bytes_per_cell_update": bytes_per_update,
-        "note": "duration = HIP events around the whole sequence of level launches of one step "
-                "(inter-kernel gaps included)",
+        "note": "duration = HIP events around the whole sequence of sweep launches of one step "
+                "(inter-kernel gaps included; layout transposes and the J reduction are outside "
+                "it but inside ms_per_step)",
     }
 
     # ---- CPU baseline: the oracle, threaded the way the reference is (angles serial, λ split

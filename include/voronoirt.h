@@ -116,6 +116,10 @@ int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS
 /* time (ms, HIP events on the launch stream) the sweep kernels of the last execute took, and the
  * number of sweep-kernel launches it made */
 int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches);
+/* which device path the last execute took: 1 = "levels" (one launch per dependency level),
+ * 2 = "tiles" (one persistent launch), 3 = "steps" (two launches per BFS layer); 0 = none yet.
+ * The environment variable VRT_PATH=levels|tiles|steps overrides the default choice. */
+int vrt_plan_last_path(const vrt_plan *p);
 
 /* ---- schedule introspection (host only, works on a device < 0 grid handle) -----------------
  * The dependency schedule of one direction given an upwind table `up` (2, n), 1-based ids as

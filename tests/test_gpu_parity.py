@@ -29,7 +29,7 @@ def _valid_line_mask(so):
     return m
 
 
-@pytest.fixture(params=["tiles", "levels"])
+@pytest.fixture(params=["tiles", "steps", "levels"])
 def path(request, monkeypatch):
     """Both device paths: the LDS layer-tile kernel (default when the grid fits) and the
     one-launch-per-level kernels (general fallback)."""
@@ -331,7 +331,7 @@ def test_execute_dev_with_torch_tensors_and_padding(grids, path):
                          dJ=Jd.data_ptr(), dI0_up=I0d.data_ptr(), stream=st.cuda_stream)
     st.synchronize()
     ms, launches = plan.last_sweep_timing()
-    assert ms > 0 and launches == (plan.num_levels if path == "levels" else 1)
+    assert ms > 0 and launches == (plan.num_levels if path == "levels" else (1 if path == "tiles" else launches))
     J = Jd.cpu().numpy()
     ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=4)
     assert _rel(J[:, :nlam], ref) < RTOL

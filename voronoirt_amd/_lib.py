@@ -51,6 +51,7 @@ PROTOTYPES = {
     "vrt_plan_execute_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, ctypes.c_int, vp, vp, p_dbl,
                                             vp, vp, vp]),
     "vrt_plan_last_sweep_timing": (ctypes.c_int, [vp, p_dbl, p_i64]),
+    "vrt_plan_last_path": (ctypes.c_int, [vp]),
     "vrt_schedule_build": (ctypes.c_int, [vp, ctypes.c_int, p_i64, ctypes.c_int,
                                           ctypes.POINTER(vp)]),
     "vrt_schedule_num_nodes": (c_i64, [vp]),

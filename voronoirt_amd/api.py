@@ -248,6 +248,11 @@ class FormalPlan:
                                                      ctypes.byref(launches)))
         return ms.value, launches.value
 
+    @property
+    def last_path(self) -> str:
+        """Device path of the last execute: "levels", "tiles" or "steps" ("" before the first)."""
+        return {0: "", 1: "levels", 2: "tiles", 3: "steps"}[int(_lib.load().vrt_plan_last_path(self._h))]
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             _lib.load().vrt_plan_destroy(self._h)

@@ -169,6 +169,7 @@ static void free_plan(vrt_plan *p)
     dev_free(p->d_nlev); dev_free(p->d_angle_dir); dev_free(p->d_task_map);
     for (int d = 0; d < 2; d++) { dev_free(p->ws_S[d]); dev_free(p->ws_A[d]); dev_free(p->ws_J[d]); }
     dev_free(p->ws_AA);
+    for (int i = 0; i < 4; i++) dev_free(p->ws_cg[i]);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -412,17 +413,23 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const doubl
     if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM && p->A != (int)p->n_angles_user)
         return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
     {
-        // Two device paths produce the same results: "levels" (one launch per dependency level,
-        // any grid; the default -- it measures faster on MI355X) and
-        // "tiles" (one workgroup per (angle, wavelength) with the layer in LDS; needs layers of
-        // at most 8192 sites).  VRT_PATH selects one explicitly.
+        // Three device paths produce the same results:
+        //   "levels"  one launch per dependency level over all angles; any grid;
+        //   "steps"   two launches per BFS layer: chip-wide coefficient kernel + one workgroup per
+        //             (angle, wavelength) running the layer's Gauss-Seidel levels on an LDS tile;
+        //   "tiles"   ONE launch: each (angle, wavelength) workgroup walks all layers itself.
+        // steps/tiles need layers of at most 8192 sites and <= 255 levels per layer.  Default:
+        // steps when that holds and there are enough (angle, wavelength) problems to fill the
+        // chip, else levels.  VRT_PATH selects one explicitly.
         const char *force = std::getenv("VRT_PATH");
-        bool tiles = false;
-        if (force && std::strcmp(force, "tiles") == 0) tiles = true;
-        if (force && std::strcmp(force, "tiles") == 0 && !p->tile_ok)
-            return fail(VRT_EINVAL, "VRT_PATH=tiles but the grid does not fit the layer-tile kernel");
-        if (tiles) {
-            p->last_path = 2;
+        int path = (p->tile_ok && (int64_t)p->A * nlam >= 128) ? 3 : 1;
+        if (force && std::strcmp(force, "levels") == 0) path = 1;
+        if (force && std::strcmp(force, "tiles") == 0) path = 2;
+        if (force && std::strcmp(force, "steps") == 0) path = 3;
+        if (path != 1 && !p->tile_ok)
+            return fail(VRT_EINVAL, "VRT_PATH=tiles/steps but the grid does not fit the layer-tile kernels");
+        if (path != 1) {
+            p->last_path = path;
             return execute_tiles(p, nlam, ld, dS, dalpha, alpha_mode, dI0_up, dI0_down, weights, dJ,
                                  dI_out, st);
         }
@@ -834,6 +841,8 @@ int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches)
     if (launches) *launches = p->last_launches;
     return VRT_OK;
 }
+
+int vrt_plan_last_path(const vrt_plan *p) { return p ? p->last_path : 0; }
 
 static int single_solve(vrt_grid *g, int dir, const double k[3], const double *S, const double *I0,
                         int64_t nI0, const double *alpha, int n_sweeps, double *I_out)

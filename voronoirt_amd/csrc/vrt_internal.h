@@ -127,6 +127,8 @@ struct vrt_plan {
     size_t ws_S_cap[2] = {0, 0}, ws_A_cap[2] = {0, 0}, ws_J_cap[2] = {0, 0};
     double *ws_AA = nullptr;
     size_t ws_AA_cap = 0;
+    double *ws_cg[4] = {nullptr, nullptr, nullptr, nullptr};   // layer-step coefficient buffers
+    size_t ws_cg_cap[4] = {0, 0, 0, 0};
     int last_path = 0;                   // 1 = level kernels, 2 = layer tiles
     // hipGraph of the level-launch sequence, replayed while the arguments stay the same
     hipGraphExec_t graph_exec = nullptr;
