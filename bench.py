@@ -58,6 +58,28 @@ def parse_args():
     return ap.parse_args()
 
 
+def pmc_traffic_per_launch(workload, path, nlam, world, launches):
+    """HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes of this same
+    command (profiles/r1/c4_summary.json; PMC counters cannot be read from inside the run).
+    bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B): on gfx950 FETCH_SIZE tallies the 128-B
+    requests of these streams at 64 B (MI355X_MICROARCH.md, HBM section).  None when the
+    configuration differs from the profiled one."""
+    if workload != "C4" or nlam != WORKLOADS["C4"][3] or world != 1:
+        return None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r1", "c4_summary.json")))
+        tag = {"steps": "steps_default", "levels": "levels", "tiles": "tiles"}[path]
+        kernels = {"steps": ("k_step_coeffs", "k_step_levels"), "levels": ("k_sweep_level",),
+                   "tiles": ("k_sweep_tiles",)}[path]
+        total = 0.0
+        for name, c in prof["pmc_one_step"][tag].items():
+            if any(k in name for k in kernels):
+                total += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        return total / max(launches, 1) if total > 0 else None
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     import torch
@@ -217,7 +239,8 @@ def main():
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
     out["roofline"] = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": pmc_traffic_per_launch(args.workload, plan.last_path, nlam, world, launches),
         "kernel": {"levels": "k_sweep_level (one launch per dependency level)",
                    "steps": "k_step_coeffs + k_step_levels (two launches per BFS layer)",
                    "tiles": "k_sweep_tiles (one persistent launch)"}.get(plan.last_path, plan.last_path),

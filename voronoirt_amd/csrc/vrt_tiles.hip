@@ -379,6 +379,7 @@ struct StepArgs {
     int cg_stride;            // slots per (angle, wavelength) in the coefficient buffers
     double *cg_c, *cg_g1, *cg_g2;
     uint32_t *cg_loc;
+    int debug_skip_levels;    // diagnostics only (VRT_DEBUG_SKIP_LEVELS=1): wrong results
 };
 
 // block = 256 consecutive slots (a Morton-coherent patch: the upwind gathers of neighbouring
@@ -469,7 +470,7 @@ k_step_levels(StepArgs sa)
         if (ok) tile[slot] = 0.0;                  // I = zero(S), irregular_ray_tracing.jl:23
     }
     __syncthreads();
-    const int nl = ta.nlev[(size_t)a * (size_t)(ta.max_layers + 1) + sa.layer];
+    const int nl = sa.debug_skip_levels ? 0 : ta.nlev[(size_t)a * (size_t)(ta.max_layers + 1) + sa.layer];
     for (int t = 1; t <= nl; t++) {
         // (issuing all 2K LDS reads of a level unconditionally ahead of the branches measured
         // 19 % slower than this per-site form)
@@ -722,6 +723,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         sa.cg_stride = stride;
         sa.cg_c = p->ws_cg[0]; sa.cg_g1 = p->ws_cg[1]; sa.cg_g2 = p->ws_cg[2];
         sa.cg_loc = reinterpret_cast<uint32_t *>(p->ws_cg[3]);
+        sa.debug_skip_levels = std::getenv("VRT_DEBUG_SKIP_LEVELS") != nullptr;
         const int Lmax = std::max(ta.nlayers[0] * (use_dir[0] ? 1 : 0), ta.nlayers[1] * (use_dir[1] ? 1 : 0));
         const dim3 g1((unsigned)((p->tile_max_layer_size + 255) / 256),
                       (unsigned)((size_t)A * (size_t)((nlam + kStepLam - 1) / kStepLam)));
