@@ -146,6 +146,22 @@ int vrt_delaunay_up(vrt_grid *g, const double k[3], const double *S, const doubl
 int vrt_delaunay_down(vrt_grid *g, const double k[3], const double *S, const double *I0,
                       int64_t nI0, const double *alpha, int n_sweeps, double *I_out);
 
+/* ---- regular-grid short characteristics ---------------------------------
+ * Drop-in bodies for short_characteristics_up / short_characteristics_down
+ * (src/characteristics.jl:19-95, :110-180), batched over independent solves the way
+ * J_λ_regular loops over angles and wavelengths (src/lambda_iteration.jl:1-58).
+ *   z[nz], x[nx], y[ny]   grid axes (x, y carry the reference's one-cell periodic ghost border)
+ *   k (3, n_solve), up[n_solve] (1: rays travel up, boundary at z[1]; 0: down, boundary at z[end])
+ *   S, alpha (nz, nx, ny[, n_solve]) Julia order a[iz + nz*(ix + nx*iy)]; stride 0 = shared by all
+ *   solves, nz*nx*ny = one array per solve
+ *   I0 (nx, ny, n_solve), I_out (nz, nx, ny, n_solve)
+ * Host pointers; the arrays are staged through the device. */
+int vrt_short_characteristics(int64_t nz, int64_t nx, int64_t ny, const double *z, const double *x,
+                              const double *y, int64_t n_solve, const double *k, const int *up,
+                              const double *S, int64_t S_stride, const double *alpha,
+                              int64_t alpha_stride, const double *I0, int n_sweeps, int device,
+                              double *I_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,10 @@ def lib():
                                     _p_dbl, _p_i64, _c_i64, _p_i64, _p_i64, _c_i64, _p_i64,
                                     _c_i64, ctypes.c_int, _p_dbl]
         L.orc_J_voronoi.restype = ctypes.c_int
+        L.orc_short_characteristics.argtypes = [ctypes.c_int, _p_dbl, _p_dbl, _p_dbl, _p_dbl, _p_dbl,
+                                                _p_dbl, _p_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _p_dbl,
+                                                ctypes.POINTER(ctypes.c_int)]
+        L.orc_short_characteristics.restype = ctypes.c_int
         L.orc_max_threads.argtypes = []
         L.orc_max_threads.restype = ctypes.c_int
         _lib = L
@@ -278,3 +282,33 @@ def J_voronoi(weights, theta, phi, S, alpha, sites: OracleSites, I0_up=None, I0_
 
 def max_threads() -> int:
     return lib().orc_max_threads()
+
+
+def _short_characteristics(up, k, S_0, I_0, alpha, z, x, y, n_sweeps, return_planes=False):
+    """Regular-grid solver.  Arrays in numpy (ny, nx, nz) C-order == Julia (nz, nx, ny); I_0 in
+    (ny, nx) C-order == Julia (nx, ny)."""
+    k = _f64(k)
+    S_0 = _f64(S_0)
+    alpha = _f64(alpha)
+    I_0 = _f64(I_0)
+    z, x, y = _f64(z), _f64(x), _f64(y)
+    ny, nx, nz = S_0.shape
+    assert (nz, nx, ny) == (z.size, x.size, y.size) and I_0.shape == (ny, nx) and alpha.shape == S_0.shape
+    out = np.zeros_like(S_0)
+    kinds = np.zeros(nz, dtype=np.int32)
+    rc = lib().orc_short_characteristics(1 if up else 0, _d(k), _d(S_0), _d(I_0), _d(alpha), _d(z),
+                                         _d(x), _d(y), nz, nx, ny, n_sweeps, _d(out),
+                                         kinds.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if rc:
+        raise RuntimeError("orc_short_characteristics failed")
+    return (out, kinds) if return_planes else out
+
+
+def short_characteristics_up(k, S_0, I_0, alpha, z, x, y, n_sweeps=3, return_planes=False):
+    """src/characteristics.jl:19-95"""
+    return _short_characteristics(True, k, S_0, I_0, alpha, z, x, y, n_sweeps, return_planes)
+
+
+def short_characteristics_down(k, S_0, I_0, alpha, z, x, y, n_sweeps=3, return_planes=False):
+    """src/characteristics.jl:110-180"""
+    return _short_characteristics(False, k, S_0, I_0, alpha, z, x, y, n_sweeps, return_planes)

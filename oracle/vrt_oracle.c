@@ -9,10 +9,15 @@
  * (meudnaes/VoronoiRT, Julia), keeping every quirk.  Each function cites the reference
  * file:line it follows (paths relative to the reference checkout).
  *
- * PARITY STATUS: "parity unpinned" by the reference's own tests -- the reference holds no
- * golden vector, known-answer test or fixture for the Voronoi path,
- * and no Julia toolchain exists in the build image to run it.  The oracle is pinned only by
- * analytic known answers that follow from the reference code itself (tests/test_oracle.py).
+ * PARITY STATUS, Voronoi path: "parity unpinned" by the reference's own tests -- the reference
+ * holds no golden vector, known-answer test or fixture for the Voronoi path (SURVEY.md section
+ * 4/8c), and no Julia toolchain exists in the build image to run it.  That part is pinned only
+ * by analytic known answers that follow from the reference code itself and by an independent
+ * second transcription (tests/test_oracle.py, oracle/pyref.py).
+ * PARITY STATUS, regular-grid solver (end of this file) and the numerics it shares with the
+ * Voronoi path (linear_weights, trapezoidal): PINNED by outputs of the reference itself -- the
+ * data files data/searchlight_data/I_160_45_regular.npy and I_20_15_regular.npy are reproduced
+ * to a few ulp (tests/test_regular.py).
  *
  * Memory layouts mirror Julia's column-major arrays so the same buffers can be handed to the
  * C-ABI product library:
@@ -422,4 +427,247 @@ int orc_max_threads(void)
 #else
     return 1;
 #endif
+}
+
+/* ==========================================================================================
+ * Regular-grid short characteristics -- src/characteristics.jl.
+ * Literal restatement of short_characteristics_up/down and the six per-plane kernels, kept
+ * with their quirks (ghost-zone refresh inside the sweep loop only in yz_up_ray :480-482;
+ * xz_down_ray takes the centre values from the UPPER plane :794,804; the carried row
+ * I_upper/I_lower is not reset between sweeps).
+ * Arrays are Julia column-major: S, alpha, I (nz, nx, ny) -> a[iz + nz*(ix + nx*iy)];
+ * I_0 and every plane (nx, ny) -> p[ix + nx*iy].  Indices below are 0-based.
+ * PINNED by reference output: data/searchlight_data/I_160_45_regular.npy and
+ * I_20_15_regular.npy (tests/test_regular.py).
+ * ========================================================================================== */
+
+/* bilinear -- src/functions.jl:332-355 */
+static double orc_bilinear(double x_mrk, double y_mrk, double x1, double x2, double y1, double y2,
+                           double Q11, double Q12, double Q21, double Q22)
+{
+    double dx = x2 - x1, dy = y2 - y1;
+    double f1 = ((x2 - x_mrk) * Q11 + (x_mrk - x1) * Q21) / dx;
+    double f2 = ((x2 - x_mrk) * Q12 + (x_mrk - x1) * Q22) / dx;
+    return ((y2 - y_mrk) * f1 + (y_mrk - y1) * f2) / dy;
+}
+
+/* xy_intersect(k) -- src/functions.jl:430-457 */
+void orc_xy_intersect(const double *k, int *sign_x, int *sign_y)
+{
+    if (k[1] > 0 && k[2] > 0) { *sign_x = -1; *sign_y = -1; }
+    else if (k[1] < 0 && k[2] > 0) { *sign_x = 1; *sign_y = -1; }
+    else if (k[1] < 0 && k[2] < 0) { *sign_x = 1; *sign_y = 1; }
+    else if (k[1] > 0 && k[2] < 0) { *sign_x = -1; *sign_y = 1; }
+    else { *sign_x = 1; *sign_y = 1; }
+}
+
+#define A3(a, iz, ix, iy) (a)[(iz) + nz * ((ix) + nx * (iy))]
+#define P2(p, ix, iy) (p)[(ix) + nx * (iy)]
+
+/* xy_up_ray :191-278 / xy_down_ray :288-372.  up: idz_upwind = idz-1; down: idz+1.
+ * I0 = intensity of the upwind plane, I = new plane (nx*ny, zero-initialised here). */
+static void orc_xy_ray(int up, const double *k, i64 idz, int sign_x, int sign_y, const double *I0,
+                       const double *S, const double *alpha, const double *z, const double *x,
+                       const double *y, i64 nz, i64 nx, i64 ny, double *I)
+{
+    for (i64 t = 0; t < nx * ny; t++) I[t] = 0.0;
+    i64 idz_u = up ? idz - 1 : idz + 1;
+    double dz = z[idz_u] - z[idz];
+    double r = fabs(dz / k[0]);
+    double x_inc = r * k[1], y_inc = r * k[2];
+    int hx = (sign_x + 1) / 2, hy = (sign_y + 1) / 2;
+    for (i64 idx = 1; idx <= nx - 2; idx++) {
+        i64 xl = idx - hx, xu = xl + 1;
+        double x_up = x[idx] + x_inc;
+        for (i64 idy = 1; idy <= ny - 2; idy++) {
+            i64 yl = idy - hy, yu = yl + 1;
+            double y_up = y[idy] + y_inc;
+            double a_c = A3(alpha, idz, idx, idy);
+            double a_u = orc_bilinear(x_up, y_up, x[xl], x[xu], y[yl], y[yu],
+                                      A3(alpha, idz_u, xl, yl), A3(alpha, idz_u, xl, yu),
+                                      A3(alpha, idz_u, xu, yl), A3(alpha, idz_u, xu, yu));
+            double dtau = r * (a_c + a_u) / 2;
+            double S_c = A3(S, idz, idx, idy);
+            double S_u = orc_bilinear(x_up, y_up, x[xl], x[xu], y[yl], y[yu],
+                                      A3(S, idz_u, xl, yl), A3(S, idz_u, xl, yu),
+                                      A3(S, idz_u, xu, yl), A3(S, idz_u, xu, yu));
+            double a, b, e;
+            orc_linear_weights(dtau, &a, &b, &e);
+            double I_u = orc_bilinear(x_up, y_up, x[xl], x[xu], y[yl], y[yu],
+                                      P2(I0, xl, yl), P2(I0, xl, yu), P2(I0, xu, yl), P2(I0, xu, yu));
+            P2(I, idx, idy) = (e * I_u + a * S_u) + b * S_c;
+        }
+        P2(I, idx, 0) = P2(I, idx, ny - 2);       /* ghost zones :270-271 */
+        P2(I, idx, ny - 1) = P2(I, idx, 1);
+    }
+    for (i64 idy = 0; idy < ny; idy++) {          /* :274-275 */
+        P2(I, 0, idy) = P2(I, nx - 2, idy);
+        P2(I, nx - 1, idy) = P2(I, 1, idy);
+    }
+}
+
+/* yz_up_ray :383-487 / yz_down_ray :497-604: upwind point on the x = x[idx + sign_x] plane. */
+static void orc_yz_ray(int up, const double *k, i64 idz, int sign_x, int sign_y, const double *I0,
+                       const double *S, const double *alpha, const double *z, const double *x,
+                       const double *y, i64 nz, i64 nx, i64 ny, i64 n_sweeps, double *I)
+{
+    for (i64 t = 0; t < nx * ny; t++) I[t] = 0.0;
+    double *I_row = (double *)calloc((size_t)ny, sizeof(double));  /* I_upper / I_lower :399,514 */
+    double dx = x[1] - x[0];
+    i64 sx0 = sign_x == 1 ? 1 : nx - 2, sx1 = sign_x == 1 ? nx - 2 : 1;   /* range_bounds */
+    i64 sy0 = sign_y == 1 ? 1 : ny - 2, sy1 = sign_y == 1 ? ny - 2 : 1;
+    double z_c = z[idz];
+    i64 idz_o = up ? idz - 1 : idz + 1;            /* the other plane of the z interval */
+    double r = fabs(dx / k[1]);
+    double z_inc = r * k[0], y_inc = r * k[2];
+    double z_up = z_c + z_inc;
+    double zb1 = up ? z[idz_o] : z_c, zb2 = up ? z_c : z[idz_o];      /* z_bounds */
+    i64 iz_lo = up ? idz_o : idz, iz_hi = up ? idz : idz_o;             /* α_lower / α_upper planes */
+    int hy = (sign_y + 1) / 2;
+    for (i64 sweep = 0; sweep < n_sweeps; sweep++) {
+        for (i64 idx = sx0; sign_x == 1 ? idx <= sx1 : idx >= sx1; idx += sign_x) {
+            i64 xu = idx + sign_x;                 /* idx_upwind */
+            for (i64 idy = sy0; sign_y == 1 ? idy <= sy1 : idy >= sy1; idy += sign_y) {
+                i64 yl = idy - hy, yu = yl + 1;
+                double y_up = y[idy] + y_inc;
+                double a_c = A3(alpha, idz, idx, idy);   /* α_upper[idx,idy] (up) / α_lower (down): both = plane idz */
+                double a_u = orc_bilinear(z_up, y_up, zb1, zb2, y[yl], y[yu],
+                                          A3(alpha, iz_lo, xu, yl), A3(alpha, iz_lo, xu, yu),
+                                          A3(alpha, iz_hi, xu, yl), A3(alpha, iz_hi, xu, yu));
+                double dtau = r * (a_c + a_u) / 2;
+                double S_c = A3(S, idz, idx, idy);
+                double S_u = orc_bilinear(z_up, y_up, zb1, zb2, y[yl], y[yu],
+                                          A3(S, iz_lo, xu, yl), A3(S, iz_lo, xu, yu),
+                                          A3(S, iz_hi, xu, yl), A3(S, iz_hi, xu, yu));
+                double a, b, e;
+                orc_linear_weights(dtau, &a, &b, &e);
+                double I_u;
+                if (up)     /* rows: [I_0 at the lower plane ; carried row at z_centre] :458-459 */
+                    I_u = orc_bilinear(z_up, y_up, zb1, zb2, y[yl], y[yu],
+                                       P2(I0, xu, yl), P2(I0, xu, yu), I_row[yl], I_row[yu]);
+                else        /* rows: [carried row at z_centre ; I_0 at the upper plane] :577-578 */
+                    I_u = orc_bilinear(z_up, y_up, zb1, zb2, y[yl], y[yu],
+                                       I_row[yl], I_row[yu], P2(I0, xu, yl), P2(I0, xu, yu));
+                P2(I, idx, idy) = (e * I_u + a * S_u) + b * S_c;
+            }
+            P2(I, idx, 0) = P2(I, idx, ny - 2);
+            P2(I, idx, ny - 1) = P2(I, idx, 1);
+            for (i64 j = 0; j < ny; j++) I_row[j] = P2(I, idx, j);   /* I_upper = I[idx, :] (copy) */
+        }
+        if (up)                                     /* yz_up_ray: inside the sweep loop :480-482 */
+            for (i64 idy = 0; idy < ny; idy++) {
+                P2(I, 0, idy) = P2(I, nx - 2, idy);
+                P2(I, nx - 1, idy) = P2(I, 1, idy);
+            }
+    }
+    if (!up)                                        /* yz_down_ray: after the sweeps :599-601 */
+        for (i64 idy = 0; idy < ny; idy++) {
+            P2(I, 0, idy) = P2(I, nx - 2, idy);
+            P2(I, nx - 1, idy) = P2(I, 1, idy);
+        }
+    free(I_row);
+}
+
+/* xz_up_ray :614-716 / xz_down_ray :726-835: upwind point on the y = y[idy + sign_y] plane. */
+static void orc_xz_ray(int up, const double *k, i64 idz, int sign_x, int sign_y, const double *I0,
+                       const double *S, const double *alpha, const double *z, const double *x,
+                       const double *y, i64 nz, i64 nx, i64 ny, i64 n_sweeps, double *I)
+{
+    for (i64 t = 0; t < nx * ny; t++) I[t] = 0.0;
+    /* the reference allocates zero(I_0[end,:]) (length ny) and then assigns I[:, idy] (length
+     * nx); before the first assignment only zeros are read, so nx zeros are equivalent when
+     * nx == ny (the only case the reference's square grids exercise) */
+    double *I_col = (double *)calloc((size_t)(nx > ny ? nx : ny), sizeof(double));
+    double dy = y[1] - y[0];
+    i64 sx0 = sign_x == 1 ? 1 : nx - 2, sx1 = sign_x == 1 ? nx - 2 : 1;
+    i64 sy0 = sign_y == 1 ? 1 : ny - 2, sy1 = sign_y == 1 ? ny - 2 : 1;
+    double z_c = z[idz];
+    i64 idz_o = up ? idz - 1 : idz + 1;
+    double r = fabs(dy / k[2]);
+    double z_inc = r * k[0], x_inc = r * k[1];
+    double z_up = z_c + z_inc;
+    double zb1 = up ? z[idz_o] : z_c, zb2 = up ? z_c : z[idz_o];
+    i64 iz_lo = up ? idz_o : idz, iz_hi = up ? idz : idz_o;
+    /* centre values: α_upper[idx, idy] in BOTH variants (:672 and :794) -- for the down ray that
+     * is the plane idz+1, not the plane being solved (reference quirk) */
+    i64 iz_c = iz_hi;
+    int hx = (sign_x + 1) / 2;
+    for (i64 sweep = 0; sweep < n_sweeps; sweep++) {
+        for (i64 idy = sy0; sign_y == 1 ? idy <= sy1 : idy >= sy1; idy += sign_y) {
+            i64 yu = idy + sign_y;                 /* idy_upwind */
+            for (i64 idx = sx0; sign_x == 1 ? idx <= sx1 : idx >= sx1; idx += sign_x) {
+                i64 xl = idx - hx, xu = xl + 1;
+                double x_up = x[idx] + x_inc;
+                double a_c = A3(alpha, iz_c, idx, idy);
+                double a_u = orc_bilinear(z_up, x_up, zb1, zb2, x[xl], x[xu],
+                                          A3(alpha, iz_lo, xl, yu), A3(alpha, iz_lo, xu, yu),
+                                          A3(alpha, iz_hi, xl, yu), A3(alpha, iz_hi, xu, yu));
+                double dtau = r * (a_c + a_u) / 2;
+                double S_c = A3(S, iz_c, idx, idy);
+                double S_u = orc_bilinear(z_up, x_up, zb1, zb2, x[xl], x[xu],
+                                          A3(S, iz_lo, xl, yu), A3(S, iz_lo, xu, yu),
+                                          A3(S, iz_hi, xl, yu), A3(S, iz_hi, xu, yu));
+                double a, b, e;
+                orc_linear_weights(dtau, &a, &b, &e);
+                double I_u;
+                if (up)
+                    I_u = orc_bilinear(z_up, x_up, zb1, zb2, x[xl], x[xu],
+                                       P2(I0, xl, yu), P2(I0, xu, yu), I_col[xl], I_col[xu]);
+                else
+                    I_u = orc_bilinear(z_up, x_up, zb1, zb2, x[xl], x[xu],
+                                       I_col[xl], I_col[xu], P2(I0, xl, yu), P2(I0, xu, yu));
+                P2(I, idx, idy) = (e * I_u + a * S_u) + b * S_c;
+            }
+            P2(I, 0, idy) = P2(I, nx - 2, idy);    /* :704-705 / :822-823 */
+            P2(I, nx - 1, idy) = P2(I, 1, idy);
+            for (i64 i = 0; i < nx; i++) I_col[i] = P2(I, i, idy);   /* I_upper = I[:, idy] */
+        }
+    }
+    for (i64 idx = 0; idx < nx; idx++) {           /* after the sweeps :713-714 / :831-832 */
+        P2(I, idx, 0) = P2(I, idx, ny - 2);
+        P2(I, idx, ny - 1) = P2(I, idx, 1);
+    }
+    free(I_col);
+}
+
+/* short_characteristics_up :19-95 (up = 1) / short_characteristics_down :110-180 (up = 0).
+ * plane_kind (optional, nz ints) receives 1/2/3 = xy/yz/xz per solved plane (0 for the boundary). */
+int orc_short_characteristics(int up, const double *k, const double *S, const double *I0,
+                              const double *alpha, const double *z, const double *x,
+                              const double *y, i64 nz, i64 nx, i64 ny, i64 n_sweeps, double *I,
+                              int *plane_kind)
+{
+    if (nz < 2 || nx < 3 || ny < 3) return -1;
+    for (i64 t = 0; t < nz * nx * ny; t++) I[t] = 0.0;
+    double dx = x[1] - x[0], dy = y[1] - y[0];
+    double r_x = fabs(dx / k[1]), r_y = fabs(dy / k[2]);
+    int sign_x, sign_y;
+    orc_xy_intersect(k, &sign_x, &sign_y);
+    double *prev = (double *)malloc(sizeof(double) * (size_t)(nx * ny));
+    double *cur = (double *)malloc(sizeof(double) * (size_t)(nx * ny));
+    i64 iz_b = up ? 0 : nz - 1;
+    for (i64 ix = 0; ix < nx; ix++)
+        for (i64 iy = 0; iy < ny; iy++) A3(I, iz_b, ix, iy) = P2(I0, ix, iy);   /* :61 / :146 */
+    if (plane_kind) for (i64 t = 0; t < nz; t++) plane_kind[t] = 0;
+    for (i64 s = 1; s < nz; s++) {
+        i64 idz = up ? s : nz - 1 - s;
+        i64 idz_u = up ? idz - 1 : idz + 1;
+        double dz = up ? z[idz] - z[idz - 1] : z[idz + 1] - z[idz];
+        double r_z = fabs(dz / k[0]);
+        int cut = 1;                                 /* argmin([r_z, r_x, r_y]): first minimum */
+        double m = r_z;
+        if (r_x < m) { m = r_x; cut = 2; }
+        if (r_y < m) { m = r_y; cut = 3; }
+        for (i64 ix = 0; ix < nx; ix++)
+            for (i64 iy = 0; iy < ny; iy++) P2(prev, ix, iy) = A3(I, idz_u, ix, iy);
+        if (cut == 1) orc_xy_ray(up, k, idz, sign_x, sign_y, prev, S, alpha, z, x, y, nz, nx, ny, cur);
+        else if (cut == 2) orc_yz_ray(up, k, idz, sign_x, sign_y, prev, S, alpha, z, x, y, nz, nx, ny, n_sweeps, cur);
+        else orc_xz_ray(up, k, idz, sign_x, sign_y, prev, S, alpha, z, x, y, nz, nx, ny, n_sweeps, cur);
+        if (plane_kind) plane_kind[idz] = cut;
+        for (i64 ix = 0; ix < nx; ix++)
+            for (i64 iy = 0; iy < ny; iy++) A3(I, idz, ix, iy) = P2(cur, ix, iy);
+    }
+    free(prev);
+    free(cur);
+    return 0;
 }

@@ -1,0 +1,130 @@
+"""Regular-grid short characteristics: the oracle against the REFERENCE'S OWN
+committed outputs, and the HIP kernel against the oracle.
+
+tests/golden/I_160_45_regular.npy and I_20_15_regular.npy are data files the reference holds
+(data/searchlight_data/, loaded by its python/plot_searchlight.py): the top / bottom plane of
+`searchlight_regular` (src/compare_searchlight.jl:154-225: 51^3 unit cube, alpha = S = 0, a disk of
+radius 0.1 lit on the boundary plane with xi = i/nx, ghost border stripped) for (θ, ϕ) = (160°, 45°)
+up and (20°, 15°) down.  They were produced by an earlier revision of the reference (those angles
+are not in today's quadrature file); its down-ray direction had k_x, k_y negated relative to
+today's k = [cos θ, cos ϕ sin θ, sin ϕ sin θ], i.e. the second file is reproduced with ϕ = 195°.
+Both are outputs of the reference itself, so this pins the oracle's regular solver (bilinear,
+linear_weights, trapezoidal, plane marching, ghost zones) to reference arithmetic."""
+import os
+
+import numpy as np
+import pytest
+
+import voronoirt_amd as vrt
+from oracle import oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _searchlight(n=51):
+    z = np.linspace(0, 1, n)
+    x = np.linspace(0, 1, n)
+    y = np.linspace(0, 1, n)
+    S = np.zeros((n, n, n))
+    al = np.zeros((n, n, n))
+    I0 = np.zeros((n, n))                       # (ny, nx)
+    for i in range(1, n + 1):                   # compare_searchlight.jl:180-190
+        for j in range(1, n + 1):
+            if np.sqrt((i / n - 0.5) ** 2 + (j / n - 0.5) ** 2) < 0.1:
+                I0[j - 1, i - 1] = 1.0
+    return z, x, y, S, al, I0
+
+
+def _exit_plane(I, up):
+    plane = I[:, :, -1] if up else I[:, :, 0]   # I[end, :, :] / I[1, :, :]
+    return plane[1:-1, 1:-1].T                  # [:, 2:end-1, 2:end-1], indexed [ix, iy] like the .npy
+
+
+@pytest.mark.parametrize("fname,theta,phi,up", [("I_160_45_regular.npy", 160.0, 45.0, True),
+                                                  ("I_20_15_regular.npy", 20.0, 195.0, False)])
+def test_oracle_reproduces_reference_searchlight_outputs(fname, theta, phi, up):
+    z, x, y, S, al, I0 = _searchlight()
+    assert I0.sum() == 80.0                     # "Bottom: 80" (compare_searchlight.jl:209)
+    ref = np.load(os.path.join(GOLDEN, fname))
+    k = orc.direction(theta, phi)
+    f = orc.short_characteristics_up if up else orc.short_characteristics_down
+    I, kinds = f(k, S, I0, al, z, x, y, 3, return_planes=True)
+    assert set(kinds.tolist()) == {0, 1}        # these rays cut the xy planes only
+    got = _exit_plane(I, up)
+    assert got.shape == ref.shape == (49, 49)
+    assert np.abs(got - ref).max() < 1e-15      # a few ulp of the reference's own output
+    assert abs(got.sum() - ref.sum()) < 1e-13 and abs(ref.sum() - 80.0) < 1e-12   # conservation
+
+
+def _random_problem(nz, nx, ny, seed):
+    rng = np.random.default_rng(seed)
+    z = np.cumsum(rng.uniform(0.5, 1.5, nz)) / nz        # non-uniform z like a real atmosphere
+    x = np.linspace(0, 1, nx)
+    y = np.linspace(0, 1.3, ny)
+    S = 1 + rng.random((ny, nx, nz))
+    al = 10 ** rng.uniform(-3, 3, (ny, nx, nz)) * 5
+    I0 = rng.random((ny, nx))
+    return z, x, y, S, al, I0
+
+
+def test_oracle_plane_kinds_cover_all_six_kernels():
+    z, x, y, S, al, I0 = _random_problem(9, 12, 10, 1)
+    seen = set()
+    for theta, phi in ((170.0, 30.0), (100.0, 10.0), (100.0, 80.0), (10.0, 200.0), (80.0, 190.0), (80.0, 100.0)):
+        k = orc.direction(theta, phi)
+        f = orc.short_characteristics_up if theta > 90 else orc.short_characteristics_down
+        I, kinds = f(k, S, I0, al, z, x, y, 3, return_planes=True)
+        assert np.isfinite(I).all()
+        seen |= {(theta > 90, int(c)) for c in kinds if c}
+    assert seen == {(True, 1), (True, 2), (True, 3), (False, 1), (False, 2), (False, 3)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname,theta,phi,up", [("I_160_45_regular.npy", 160.0, 45.0, True),
+                                                  ("I_20_15_regular.npy", 20.0, 195.0, False)])
+def test_gpu_reproduces_reference_searchlight_outputs(fname, theta, phi, up):
+    z, x, y, S, al, I0 = _searchlight()
+    ref = np.load(os.path.join(GOLDEN, fname))
+    k = vrt.direction(theta, phi)
+    f = vrt.short_characteristics_up if up else vrt.short_characteristics_down
+    got = _exit_plane(f(k, S, I0, al, z, x, y, 3), up)
+    assert np.abs(got - ref).max() < 1e-15
+    assert abs(got.sum() - 80.0) < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_regular_matches_oracle_all_plane_kinds():
+    """Random S, α (all three linear_weights branches), non-uniform z, nx != ny, every one of the
+    six per-plane kernels; batched call with shared and per-solve fields."""
+    z, x, y, S, al, I0 = _random_problem(11, 14, 12, 2)
+    angles = [(170.0, 30.0), (100.0, 10.0), (100.0, 80.0), (10.0, 200.0), (80.0, 190.0), (80.0, 100.0),
+              (125.0, 300.0), (55.0, 250.0), (180.0, 0.0)]
+    ks = np.stack([vrt.direction(t, p) for t, p in angles])
+    ups = [t > 90 for t, _ in angles]
+    rng = np.random.default_rng(3)
+    I0s = rng.random((len(angles),) + I0.shape)
+    got = vrt.short_characteristics_batch(ks, ups, S, I0s, al, z, x, y, 3)
+    for j, (t, p) in enumerate(angles):
+        f = orc.short_characteristics_up if ups[j] else orc.short_characteristics_down
+        ref = f(ks[j], S, I0s[j], al, z, x, y, 3)
+        assert np.abs(got[j] - ref).max() / np.abs(ref).max() < 1e-12, (t, p)
+    # per-solve S and alpha, other sweep counts
+    Ss = np.stack([S * (1 + 0.1 * j) for j in range(3)])
+    als = np.stack([al * (1 + 0.3 * j) for j in range(3)])
+    for n_sweeps in (1, 2):
+        got = vrt.short_characteristics_batch(ks[1:4], ups[1:4], Ss, I0s[1:4], als, z, x, y, n_sweeps)
+        for j in range(3):
+            f = orc.short_characteristics_up if ups[1 + j] else orc.short_characteristics_down
+            ref = f(ks[1 + j], Ss[j], I0s[1 + j], als[j], z, x, y, n_sweeps)
+            assert np.abs(got[j] - ref).max() / np.abs(ref).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_regular_errors():
+    z, x, y, S, al, I0 = _random_problem(5, 6, 6, 4)
+    with pytest.raises(vrt.VrtError):
+        vrt.short_characteristics_up([0.0, 1.0, 0.0], S, I0, al, z, x, y)      # horizontal ray
+    with pytest.raises(vrt.VrtError):
+        vrt.short_characteristics_up([0.5, 0.5, 0.5], S, I0, al, z, x, y)      # not a unit vector
+    with pytest.raises(ValueError):
+        vrt.short_characteristics_up(vrt.direction(150, 20), S[:-1], I0, al, z, x, y)

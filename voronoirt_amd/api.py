@@ -348,3 +348,42 @@ def build_layer_schedule(sites: VoronoiSites, dir: int, up, n_sweeps: int = 3):
                                vis.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
                                nlev.ctypes.data_as(_lib.p_i32), ctypes.byref(nv)))
     return vis, nlev, nv.value
+
+
+# ---- regular grid ---------------------------------------------------------------
+def short_characteristics_batch(k, up, S_0, I_0, alpha, z, x, y, n_sweeps: int = 3, device: int = 0):
+    """Batched regular-grid formal solve.  k (n_solve, 3); up (n_solve,) bools; S_0 / alpha either
+    one array (ny, nx, nz) shared by every solve or (n_solve, ny, nx, nz); I_0 (n_solve, ny, nx).
+    numpy C-order (ny, nx, nz) is Julia's (nz, nx, ny).  Returns I (n_solve, ny, nx, nz)."""
+    k = _f64(np.atleast_2d(k))
+    ns = k.shape[0]
+    upv = np.ascontiguousarray(np.asarray(up, dtype=bool).reshape(ns), dtype=np.int32)
+    z, x, y = _f64(z), _f64(x), _f64(y)
+    nz, nx, ny = z.size, x.size, y.size
+    S_0, alpha, I_0 = _f64(S_0), _f64(alpha), _f64(I_0)
+    vol = nz * nx * ny
+
+    def stride(a, name):
+        if a.shape == (ny, nx, nz):
+            return 0
+        if a.shape == (ns, ny, nx, nz):
+            return vol
+        raise ValueError(f"{name} has shape {a.shape}, expected {(ny, nx, nz)} or {(ns, ny, nx, nz)}")
+    sS, sA = stride(S_0, "S_0"), stride(alpha, "alpha")
+    I_0 = I_0.reshape(ns, ny, nx)
+    out = np.zeros((ns, ny, nx, nz))
+    check(_lib.load().vrt_short_characteristics(nz, nx, ny, _d(z), _d(x), _d(y), ns, _d(k),
+                                                upv.ctypes.data_as(_lib.p_int), _d(S_0), sS, _d(alpha),
+                                                sA, _d(I_0), int(n_sweeps), int(device), _d(out)))
+    return out
+
+
+def short_characteristics_up(k, S_0, I_0, alpha, z, x, y, n_sweeps: int = 3, device: int = 0):
+    """Intensity on the regular grid for rays travelling up (src/characteristics.jl:19-95);
+    the reference's `atmos` argument is replaced by its three axes."""
+    return short_characteristics_batch([k], [True], S_0, I_0, alpha, z, x, y, n_sweeps, device)[0]
+
+
+def short_characteristics_down(k, S_0, I_0, alpha, z, x, y, n_sweeps: int = 3, device: int = 0):
+    """Intensity on the regular grid for rays travelling down (src/characteristics.jl:110-180)."""
+    return short_characteristics_batch([k], [False], S_0, I_0, alpha, z, x, y, n_sweeps, device)[0]
