@@ -414,3 +414,58 @@ def test_full_size_sample_against_oracle(full_grid):
             ref = orc.Delaunay_downII(k, S, I0, al, so, 3)
             got = vrt.Delaunay_downII(k, S, I0, al, hs, 3)
         assert _rel(got, ref) < RTOL
+
+
+def test_large_layers_fall_back_to_level_kernels():
+    """Layers above 8192 sites do not fit the LDS layer-tile kernels: the library must choose the
+    general level path by itself, refuse VRT_PATH=tiles/steps, and still match the oracle."""
+    import os
+    pos, nbr, bounds = synth.bcc_grid(66, 3, seed=5)          # 2 * 66^2 = 8712 sites per layer
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    assert int(np.diff(so.layers_up).max()) > 8192
+    n = so.n
+    rng = np.random.default_rng(8)
+    nlam = 12
+    S = 1 + rng.random((n, nlam))
+    al = 1e-6 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    I0 = rng.random((so.layers_up[1] - 1, nlam))
+    old = os.environ.pop("VRT_PATH", None)
+    try:
+        J, _ = plan.execute(S, al, weights=w, I0_up=I0)
+        assert plan.last_path == "levels"                     # 144 problems would otherwise pick "steps"
+        ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
+        assert _rel(J, ref) < RTOL
+        os.environ["VRT_PATH"] = "steps"
+        with pytest.raises(vrt.VrtError):
+            plan.execute(S, al, weights=w, I0_up=I0)
+    finally:
+        os.environ.pop("VRT_PATH", None)
+        if old is not None:
+            os.environ["VRT_PATH"] = old
+    plan.close()
+    hs.close()
+
+
+def test_default_path_choice(grids):
+    """Many (angle, wavelength) problems -> layer-step kernels; a single solve -> level kernels."""
+    import os
+    old = os.environ.pop("VRT_PATH", None)
+    try:
+        hs, so = grids["voronoi"]
+        n = so.n
+        rng = np.random.default_rng(1)
+        w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+        plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+        S = 1 + rng.random((n, 16))
+        al = 5 * 10 ** rng.uniform(-2, 2, (n, 16))
+        plan.execute(S, al, weights=w)
+        assert plan.last_path == "steps"
+        plan.execute(S[:, :2].copy(), al[:, :2].copy(), weights=w)
+        assert plan.last_path == "levels"
+        plan.close()
+    finally:
+        if old is not None:
+            os.environ["VRT_PATH"] = old
