@@ -37,6 +37,7 @@ WORKLOADS = {
     "C4": (59, 143, "ul7n12.dat", 51, True, 2022),    # ~1M sites, 12 angles x 51 λ (line)
     "C3": (59, 143, "ul9n20.dat", 20, False, 1998),   # ~1M sites, 20 angles x 20 λ (continuum)
     "C2": (37, 90, "ul7n12.dat", 1, False, 1998),     # ~250k sites, 12 angles x 1 λ
+    "C5": (94, 227, "ul9n20.dat", 100, False, 1998),  # ~4M sites, 20 angles x 100 λ (use --dtype f32)
     "tiny": (8, 12, "ul7n12.dat", 4, True, 7),
 }
 
@@ -53,6 +54,8 @@ def parse_args():
     ap.add_argument("--cpu-lam", type=int, default=0, help="wavelengths in the CPU sample")
     ap.add_argument("--angle-groups", type=int, default=1,
                     help="diagnostics: run the angles in this many sequential groups (separate plans)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                    help="storage type of S, alpha, I, J (arithmetic is always fp64)")
     ap.add_argument("--alpha0", type=float, default=1.0e-2,
                     help="opacity scale at z_min [1/m] (diagnostics: tiny values take the Taylor branch)")
     return ap.parse_args()
@@ -151,6 +154,9 @@ def main():
     bottom = torch.as_tensor(sites.perm_up[:n1_up] - 1, device=dev)
     I0_up = S[bottom].contiguous()          # I_0 = S at the bottom layer for up rays; down: zeros
     J = torch.zeros((n, nlam), device=dev, dtype=torch.float64)
+    f32 = args.dtype == "f32"
+    if f32:
+        S, alpha, I0_up, J = (t.to(torch.float32).contiguous() for t in (S, alpha, I0_up, J))
     w_mine = weights[my_angles]
     torch.cuda.synchronize()
 
@@ -173,10 +179,10 @@ def main():
         if groups is not None:
             for gp, ga, gw, gJ in groups:
                 gp.execute_dev(nlam, nlam, S.data_ptr(), ga.data_ptr(), alpha_mode, gw,
-                               dJ=gJ.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream)
+                               dJ=gJ.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
             return
         plan.execute_dev(nlam, nlam, S.data_ptr(), alpha.data_ptr(), alpha_mode, w_mine,
-                         dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream)
+                         dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
         if args.shard == "angle" and world > 1:
             if rehearse:       # gloo reduces host tensors
                 Jh = J.cpu()
@@ -221,7 +227,7 @@ def main():
         "metric": "formal-solve cell-updates/sec", "value": value, "unit": "cell-updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong" if args.shard == "angle" else "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: jittered-BCC Voronoi grid a={a} c={c} ({n} sites, "
                         f"L_up={len(sites.layers_up) - 1} layers), {quad} ({n_angles} angles), "
@@ -233,7 +239,7 @@ def main():
         "setup_s": {"grid_generate": t_gen, "grid_create": t_grid, "plan_create": t_plan},
     }
     # roofline of the dominant kernel (k_sweep_level): algorithmic bytes / event-timed duration
-    bytes_per_update = 40.0 + 40.0 / nlam
+    bytes_per_update = (20.0 if f32 else 40.0) + 40.0 / nlam
     local_updates = n * A * nlam
     alg_bytes = local_updates * bytes_per_update
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
@@ -262,18 +268,18 @@ def main():
         t0 = time.time()
         so = orc.make_sites(pos, nbr, bounds)
         t_osites = time.time() - t0
-        S_h = S[:, :lam_s].contiguous().cpu().numpy()
+        S_h = S[:, :lam_s].contiguous().cpu().numpy().astype(np.float64)
         if per_angle:
-            al_h = alpha[:, :, :lam_s].contiguous().cpu().numpy()
+            al_h = alpha[:, :, :lam_s].contiguous().cpu().numpy().astype(np.float64)
         else:
-            al_h = alpha[:, :lam_s].contiguous().cpu().numpy()
-        I0_h = I0_up[:, :lam_s].contiguous().cpu().numpy()
+            al_h = alpha[:, :lam_s].contiguous().cpu().numpy().astype(np.float64)
+        I0_h = I0_up[:, :lam_s].contiguous().cpu().numpy().astype(np.float64)
         t0 = time.time()
         J_ref = orc.J_voronoi(w_mine, theta[my_angles], phi[my_angles], S_h, al_h, so, I0_up=I0_h,
                               nthreads=cores)
         t_cpu = time.time() - t0
         cpu_updates = n * A * lam_s
-        J_gpu = J[:, :lam_s].cpu().numpy()
+        J_gpu = J[:, :lam_s].cpu().numpy().astype(np.float64)
         if args.shard == "angle" and world > 1:
             parity = None    # J holds the all-reduced sum of every rank's angles
         else:

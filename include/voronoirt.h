@@ -113,6 +113,14 @@ int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS
                          const double *dalpha, int alpha_mode, const double *dI0_up,
                          const double *dI0_down, const double *weights_host, double *dJ,
                          double *dI_out, void *stream);
+/* fp32 VALUE path (BASELINE config C5): S, alpha, I_0, J and the per-angle intensities are stored
+ * as float, halving the bytes of this bandwidth-bound path; the geometry tables and all
+ * arithmetic stay fp64.  Results agree with the fp64 solve to fp32 storage rounding (~1e-6
+ * relative).  Runs on the level kernels. */
+int vrt_plan_execute_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dS,
+                             const float *dalpha, int alpha_mode, const float *dI0_up,
+                             const float *dI0_down, const double *weights_host, float *dJ,
+                             float *dI_out, void *stream);
 /* time (ms, HIP events on the launch stream) the sweep kernels of the last execute took, and the
  * number of sweep-kernel launches it made */
 int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches);

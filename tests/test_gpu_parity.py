@@ -469,3 +469,38 @@ def test_default_path_choice(grids):
     finally:
         if old is not None:
             os.environ["VRT_PATH"] = old
+
+
+def test_fp32_value_path_against_fp64_oracle(grids):
+    """BASELINE config C5's path: S, α, I_0, J stored as float32, arithmetic in fp64.  Checked
+    against the fp64 oracle fed with the same float32-rounded inputs; the remaining difference is
+    the float32 rounding of the stored intensities (tolerance 5e-6 relative, fp64 path: 1e-10)."""
+    import torch
+    hs, so = grids["voronoi"]
+    n = so.n
+    nlam = 7
+    rng = np.random.default_rng(12)
+    S = (1 + rng.random((n, nlam))).astype(np.float32)
+    al = (5 * 10 ** rng.uniform(-3, 3, (n, 1)) * (1 + rng.random((n, nlam)))).astype(np.float32)
+    I0 = rng.random((so.layers_up[1] - 1, nlam)).astype(np.float32)
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    dev = torch.device("cuda", 0)
+    Sd, Ad, I0d = (torch.from_numpy(a).to(dev).contiguous() for a in (S, al, I0))
+    Jd = torch.zeros((n, nlam), dtype=torch.float32, device=dev)
+    Id = torch.zeros((nq, n, nlam), dtype=torch.float32, device=dev)
+    plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=Jd.data_ptr(),
+                     dI0_up=I0d.data_ptr(), dI_out=Id.data_ptr(),
+                     stream=torch.cuda.current_stream().cuda_stream, f32=True)
+    torch.cuda.synchronize()
+    assert plan.last_path == "levels"
+    ref = orc.J_voronoi(w, th, ph, S.astype(np.float64), al.astype(np.float64), so,
+                        I0_up=I0.astype(np.float64), nthreads=4)
+    J = Jd.cpu().numpy().astype(np.float64)
+    assert _rel(J, ref) < 5e-6
+    assert _rel(J, ref) > 1e-12          # it really is the float32 path
+    k = vrt.direction(th[1], ph[1])
+    Iref = orc.Delaunay_upII(k, S[:, 0].astype(np.float64), I0[:, 0].astype(np.float64),
+                             al[:, 0].astype(np.float64), so, 3)
+    assert _rel(Id[1, :, 0].cpu().numpy().astype(np.float64), Iref) < 5e-6
+    plan.close()

@@ -50,6 +50,8 @@ PROTOTYPES = {
                                         p_dbl, p_dbl, p_dbl]),
     "vrt_plan_execute_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, ctypes.c_int, vp, vp, p_dbl,
                                             vp, vp, vp]),
+    "vrt_plan_execute_dev_f32": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, ctypes.c_int, vp, vp, p_dbl,
+                                                vp, vp, vp]),
     "vrt_plan_last_sweep_timing": (ctypes.c_int, [vp, p_dbl, p_i64]),
     "vrt_plan_last_path": (ctypes.c_int, [vp]),
     "vrt_schedule_build": (ctypes.c_int, [vp, ctypes.c_int, p_i64, ctypes.c_int,

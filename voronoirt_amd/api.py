@@ -233,13 +233,14 @@ class FormalPlan:
 
     def execute_dev(self, nlam: int, ld: int, dS: int, dalpha: int, alpha_mode: int, weights,
                     dJ: int = 0, dI0_up: int = 0, dI0_down: int = 0, dI_out: int = 0,
-                    stream: int = 0) -> None:
+                    stream: int = 0, f32: bool = False) -> None:
         """Device pointers (ints, e.g. torch.Tensor.data_ptr()) and a hipStream_t handle
-        (torch.cuda.current_stream().cuda_stream).  Asynchronous on `stream`."""
+        (torch.cuda.current_stream().cuda_stream).  Asynchronous on `stream`.  f32=True: the
+        buffers hold float32 values (fp32 value path, arithmetic stays fp64)."""
         w = _f64(weights)
-        check(_lib.load().vrt_plan_execute_dev(self._h, nlam, ld, dS, dalpha, alpha_mode,
-                                               dI0_up or None, dI0_down or None, _d(w),
-                                               dJ or None, dI_out or None, stream or None))
+        fn = _lib.load().vrt_plan_execute_dev_f32 if f32 else _lib.load().vrt_plan_execute_dev
+        check(fn(self._h, nlam, ld, dS, dalpha, alpha_mode, dI0_up or None, dI0_down or None, _d(w),
+                 dJ or None, dI_out or None, stream or None))
 
     def last_sweep_timing(self):
         ms = ctypes.c_double()

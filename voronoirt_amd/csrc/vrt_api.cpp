@@ -395,11 +395,14 @@ static int ensure(double *&buf, size_t &cap, size_t count)
     return VRT_OK;
 }
 
-static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS,
-                              const double *dalpha, int alpha_mode, const double *dI0_up,
-                              const double *dI0_down, const double *weights, double *dJ,
-                              double *dI_out, hipStream_t st)
+static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_,
+                              const void *dalpha_, int alpha_mode, const void *dI0_up_,
+                              const void *dI0_down_, const double *weights, void *dJ_,
+                              void *dI_out_, hipStream_t st, bool f32 = false)
 {
+    const double *dS = (const double *)dS_, *dalpha = (const double *)dalpha_;
+    const double *dI0_up = (const double *)dI0_up_, *dI0_down = (const double *)dI0_down_;
+    double *dJ = (double *)dJ_, *dI_out = (double *)dI_out_;
     vrt_grid *g = p->g;
     if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
     if (!dS || !dalpha) return fail(VRT_EINVAL, "S and alpha must not be NULL");
@@ -422,12 +425,14 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const doubl
         // steps when that holds and there are enough (angle, wavelength) problems to fill the
         // chip, else levels.  VRT_PATH selects one explicitly.
         const char *force = std::getenv("VRT_PATH");
-        int path = (p->tile_ok && (int64_t)p->A * nlam >= 128) ? 3 : 1;
+        int path = (p->tile_ok && (int64_t)p->A * nlam >= 128 && !f32) ? 3 : 1;
         if (force && std::strcmp(force, "levels") == 0) path = 1;
         if (force && std::strcmp(force, "tiles") == 0) path = 2;
         if (force && std::strcmp(force, "steps") == 0) path = 3;
         if (path != 1 && !p->tile_ok)
             return fail(VRT_EINVAL, "VRT_PATH=tiles/steps but the grid does not fit the layer-tile kernels");
+        if (path != 1 && f32)
+            return fail(VRT_EINVAL, "the fp32 value path runs on the level kernels only (VRT_PATH=levels)");
         if (path != 1) {
             p->last_path = path;
             return execute_tiles(p, nlam, ld, dS, dalpha, alpha_mode, dI0_up, dI0_down, weights, dJ,
@@ -436,19 +441,20 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const doubl
         p->last_path = 1;
     }
     const size_t need = (size_t)std::max(1, p->A) * (size_t)n * (size_t)nlam;
-    if ((rc = ensure(p->d_I, p->I_cap, need))) return rc;
+    if ((rc = ensure(p->d_I, p->I_cap, f32 ? (need + 1) / 2 : need))) return rc;
     p->I_ld = nlam;
     SweepArgs sa;
+    sa.f32 = f32;
     sa.n = n;
     sa.nlam = nlam;
     sa.ldS = ld;
     sa.ldA = alpha_mode == VRT_ALPHA_SITE ? 1 : ld;
     sa.ldI = nlam;
-    sa.S = dS;
-    sa.alpha = dalpha;
+    sa.S = dS_;
+    sa.alpha = dalpha_;
     sa.alpha_mode = alpha_mode;
     sa.I = p->d_I;
-    if ((rc = launch_boundary(p, sa, dI0_up, dI0_down, st))) return rc;
+    if ((rc = launch_boundary(p, sa, dI0_up_, dI0_down_, st))) return rc;
     VRT_HIP_TRY(hipEventRecord(p->ev0, st));
     {
         // The level sequence is hundreds to thousands of short dependent launches.  VRT_GRAPH=1
@@ -488,9 +494,9 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const doubl
     if (dJ) {
         double wact[kMaxAngles];
         for (int a = 0; a < p->A; a++) wact[a] = weights[p->user_of_active[(size_t)a]];
-        if ((rc = launch_reduce_J(p, sa, wact, dJ, ld, st))) return rc;
+        if ((rc = launch_reduce_J(p, sa, wact, dJ_, ld, st))) return rc;
     }
-    if (dI_out && (rc = launch_copy_I_out(p, sa, dI_out, ld, st))) return rc;
+    if (dI_out && (rc = launch_copy_I_out(p, sa, dI_out_, ld, st))) return rc;
     return VRT_OK;
 }
 
@@ -763,6 +769,23 @@ int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS
         std::lock_guard<std::mutex> lock(p->mu);
         return execute_dev_locked(p, nlam, ld, dS, dalpha, alpha_mode, dI0_up, dI0_down,
                                   weights_host, dJ, dI_out, (hipStream_t)stream);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_plan_execute_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dS,
+                             const float *dalpha, int alpha_mode, const float *dI0_up,
+                             const float *dI0_down, const double *weights_host, float *dJ,
+                             float *dI_out, void *stream)
+{
+    if (!p) return fail(VRT_EINVAL, "NULL plan");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        return execute_dev_locked(p, nlam, ld, dS, dalpha, alpha_mode, dI0_up, dI0_down, weights_host,
+                                  dJ, dI_out, (hipStream_t)stream, /*f32=*/true);
     } catch (const std::bad_alloc &) {
         return fail(VRT_ENOMEM, "out of host memory");
     } catch (...) {

@@ -177,16 +177,17 @@ int launch_delaunay_lines(vrt_grid *g);
 int launch_upwind_table(vrt_plan *p, int a);
 struct SweepArgs {
     int64_t n, nlam, ldS, ldA, ldI;
-    const double *S, *alpha;
+    const void *S, *alpha;     // double, or float when f32
     int alpha_mode;
-    double *I;
+    void *I;
+    bool f32 = false;          // fp32 storage of S, α, I, J (arithmetic stays fp64)
 };
-int launch_boundary(vrt_plan *p, const SweepArgs &sa, const double *dI0_up, const double *dI0_down,
+int launch_boundary(vrt_plan *p, const SweepArgs &sa, const void *dI0_up, const void *dI0_down,
                     hipStream_t st);
 int launch_sweep_levels(vrt_plan *p, const SweepArgs &sa, hipStream_t st, int64_t *launches);
-int launch_reduce_J(vrt_plan *p, const SweepArgs &sa, const double *weights_active, double *dJ,
+int launch_reduce_J(vrt_plan *p, const SweepArgs &sa, const double *weights_active, void *dJ,
                     int64_t ldJ, hipStream_t st);
-int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, double *dI_out, int64_t ldO, hipStream_t st);
+int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, void *dI_out, int64_t ldO, hipStream_t st);
 
 // ---- layer-tile path (vrt_tiles.hip) ----------------------------------------------------------
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);

@@ -202,10 +202,10 @@ int launch_upwind_table(vrt_plan *p, int a)
 // Boundary: I[perm[1:n1]] = I_0 (irregular_ray_tracing.jl:31-35) and I = 0 for the one site of
 // the last layer the reference never visits (voronoi_utils.jl:266).  blockIdx.y = angle slot.
 // --------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_boundary(int64_t n, int64_t nlam, int64_t ldI, int64_t n1, const int32_t *__restrict__ order,
-           const int32_t *__restrict__ angles, const double *__restrict__ I0,
-           double *__restrict__ I)
+           const int32_t *__restrict__ angles, const T *__restrict__ I0, T *__restrict__ I)
 {
     const int a = angles[blockIdx.y];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,17 +213,17 @@ k_boundary(int64_t n, int64_t nlam, int64_t ldI, int64_t n1, const int32_t *__re
     if (t >= total) return;
     const int64_t p = t / nlam;
     const int64_t l = t - p * nlam;
-    double *Ia = I + (size_t)a * (size_t)n * (size_t)ldI;
+    T *Ia = I + (size_t)a * (size_t)n * (size_t)ldI;
     if (p < n1) {
         const int64_t site = order[p];
-        Ia[(size_t)site * ldI + l] = I0 ? I0[(size_t)p * nlam + l] : 0.0;
+        Ia[(size_t)site * ldI + l] = I0 ? I0[(size_t)p * nlam + l] : (T)0;
     } else {
         const int64_t site = order[n - 1];
-        Ia[(size_t)site * ldI + l] = 0.0;
+        Ia[(size_t)site * ldI + l] = (T)0;
     }
 }
 
-int launch_boundary(vrt_plan *p, const SweepArgs &sa, const double *dI0_up, const double *dI0_down,
+int launch_boundary(vrt_plan *p, const SweepArgs &sa, const void *dI0_up, const void *dI0_down,
                     hipStream_t st)
 {
     vrt_grid *g = p->g;
@@ -234,10 +234,14 @@ int launch_boundary(vrt_plan *p, const SweepArgs &sa, const double *dI0_up, cons
         // when the grid has a single layer every site but the last is boundary (n1 = n - 1)
         const int64_t total = (dir.n1 + 1) * sa.nlam;
         const int64_t blocks = (total + 255) / 256;
-        hipLaunchKernelGGL(k_boundary, dim3((unsigned)blocks, (unsigned)cnt), dim3(256), 0, st,
-                           sa.n, sa.nlam, sa.ldI, dir.n1, dir.d_order,
-                           d == 0 ? p->d_angles_up : p->d_angles_down,
-                           d == 0 ? dI0_up : dI0_down, sa.I);
+        const int32_t *ang = d == 0 ? p->d_angles_up : p->d_angles_down;
+        const void *I0 = d == 0 ? dI0_up : dI0_down;
+        if (sa.f32)
+            hipLaunchKernelGGL(k_boundary<float>, dim3((unsigned)blocks, (unsigned)cnt), dim3(256), 0, st, sa.n,
+                               sa.nlam, sa.ldI, dir.n1, dir.d_order, ang, (const float *)I0, (float *)sa.I);
+        else
+            hipLaunchKernelGGL(k_boundary<double>, dim3((unsigned)blocks, (unsigned)cnt), dim3(256), 0, st, sa.n,
+                               sa.nlam, sa.ldI, dir.n1, dir.d_order, ang, (const double *)I0, (double *)sa.I);
         VRT_HIP_TRY(hipGetLastError());
     }
     return VRT_OK;
@@ -269,14 +273,16 @@ __device__ __forceinline__ void linear_weights(double dtau, double &a, double &b
     }
 }
 
-template <int ALPHA_MODE>
+// T = storage type of S, α and I (double, or float for the fp32 value path of BASELINE config C5);
+// the arithmetic is always fp64.
+template <typename T, int ALPHA_MODE>
 __global__ void __launch_bounds__(256)
 k_sweep_level(int64_t first, int count, int nlam, int64_t n, int64_t ldS, int64_t ldA, int64_t ldI,
               const uint32_t *__restrict__ node_site, const uint32_t *__restrict__ node_meta,
               const int32_t *__restrict__ up1, const int32_t *__restrict__ up2,
               const double *__restrict__ w1, const double *__restrict__ w2,
               const double *__restrict__ r1, const double *__restrict__ r2,
-              const double *__restrict__ S, const double *__restrict__ alpha, double *I)
+              const T *__restrict__ S, const T *__restrict__ alpha, T *I)
 {
     // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so
     // blocks b, b+8, b+16, ... -- one XCD -- take a CONTIGUOUS eighth of the Morton-sorted node
@@ -296,9 +302,9 @@ k_sweep_level(int64_t first, int count, int nlam, int64_t n, int64_t ldS, int64_
     const int32_t u1 = up1[row], u2 = up2[row];
     const double W1 = w1[row], W2 = w2[row], R1 = r1[row], R2 = r2[row];
 
-    const double *Aa = alpha;
+    const T *Aa = alpha;
     if (ALPHA_MODE == VRT_ALPHA_ANGLE_SITE_LAM) Aa += (size_t)a * (size_t)n * (size_t)ldA;
-    double *Ia = I + (size_t)a * (size_t)n * (size_t)ldI;
+    T *Ia = I + (size_t)a * (size_t)n * (size_t)ldI;
 
     double a_c, a_1, a_2;
     if (ALPHA_MODE == VRT_ALPHA_SITE) {
@@ -311,15 +317,15 @@ k_sweep_level(int64_t first, int count, int nlam, int64_t n, int64_t ldS, int64_
     const double S_c = S[(size_t)site * ldS + l];
     const double S_1 = S[(size_t)u1 * ldS + l];
     const double S_2 = S[(size_t)u2 * ldS + l];
-    const double I_1 = (meta & 0x100u) ? 0.0 : Ia[(size_t)u1 * ldI + l];
-    const double I_2 = (meta & 0x200u) ? 0.0 : Ia[(size_t)u2 * ldI + l];
+    const double I_1 = (meta & 0x100u) ? 0.0 : (double)Ia[(size_t)u1 * ldI + l];
+    const double I_2 = (meta & 0x200u) ? 0.0 : (double)Ia[(size_t)u2 * ldI + l];
 
     double ca, cb, ce;
     linear_weights(R1 * (a_c + a_1) / 2.0, ca, cb, ce);
     const double t1 = ((ce * I_1 + ca * S_1) + cb * S_c) * W1;
     linear_weights(R2 * (a_c + a_2) / 2.0, ca, cb, ce);
     const double t2 = ((ce * I_2 + ca * S_2) + cb * S_c) * W2;
-    Ia[(size_t)site * ldI + l] = (0.0 + t1) + t2;
+    Ia[(size_t)site * ldI + l] = (T)((0.0 + t1) + t2);
 }
 
 int launch_sweep_levels(vrt_plan *p, const SweepArgs &sa, hipStream_t st, int64_t *launches)
@@ -334,15 +340,21 @@ int launch_sweep_levels(vrt_plan *p, const SweepArgs &sa, hipStream_t st, int64_
         while (first < last) {
             const int64_t cnt = std::min(max_nodes, last - first);
             const int64_t blocks = (cnt * sa.nlam + 255) / 256;
-#define VRT_LAUNCH_SWEEP(MODE)                                                                     \
-    hipLaunchKernelGGL(k_sweep_level<MODE>, dim3((unsigned)blocks), dim3(256), 0, st, first,       \
+#define VRT_LAUNCH_SWEEP_T(TT, MODE)                                                               \
+    hipLaunchKernelGGL((k_sweep_level<TT, MODE>), dim3((unsigned)blocks), dim3(256), 0, st, first, \
                        (int)cnt, (int)sa.nlam, sa.n, sa.ldS, sa.ldA, sa.ldI, p->d_node_site,       \
                        p->d_node_meta, p->d_up1, p->d_up2, p->d_w1, p->d_w2, p->d_r1, p->d_r2,     \
-                       sa.S, sa.alpha, sa.I)
+                       (const TT *)sa.S, (const TT *)sa.alpha, (TT *)sa.I)
+#define VRT_LAUNCH_SWEEP(MODE)                                                                     \
+    do {                                                                                           \
+        if (sa.f32) VRT_LAUNCH_SWEEP_T(float, MODE);                                               \
+        else VRT_LAUNCH_SWEEP_T(double, MODE);                                                     \
+    } while (0)
             if (sa.alpha_mode == VRT_ALPHA_SITE) VRT_LAUNCH_SWEEP(VRT_ALPHA_SITE);
             else if (sa.alpha_mode == VRT_ALPHA_SITE_LAM) VRT_LAUNCH_SWEEP(VRT_ALPHA_SITE_LAM);
             else VRT_LAUNCH_SWEEP(VRT_ALPHA_ANGLE_SITE_LAM);
 #undef VRT_LAUNCH_SWEEP
+#undef VRT_LAUNCH_SWEEP_T
             nl++;
             first += cnt;
         }
@@ -359,9 +371,10 @@ struct WeightTable {
     double w[kMaxAngles];
 };
 
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_reduce_J(int64_t n, int64_t nlam, int64_t ldI, int64_t ldJ, int A, WeightTable wt,
-           const double *__restrict__ I, double *__restrict__ J)
+           const T *__restrict__ I, T *__restrict__ J)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * nlam) return;
@@ -369,46 +382,55 @@ k_reduce_J(int64_t n, int64_t nlam, int64_t ldI, int64_t ldJ, int A, WeightTable
     const int64_t l = t - site * nlam;
     double acc = 0.0;
     for (int a = 0; a < A; a++)
-        acc += wt.w[a] * I[((size_t)a * (size_t)n + (size_t)site) * (size_t)ldI + l];
-    J[(size_t)site * ldJ + l] = acc;
+        acc += wt.w[a] * (double)I[((size_t)a * (size_t)n + (size_t)site) * (size_t)ldI + l];
+    J[(size_t)site * ldJ + l] = (T)acc;
 }
 
-int launch_reduce_J(vrt_plan *p, const SweepArgs &sa, const double *weights_active, double *dJ,
+int launch_reduce_J(vrt_plan *p, const SweepArgs &sa, const double *weights_active, void *dJ,
                     int64_t ldJ, hipStream_t st)
 {
     WeightTable wt;
     for (int a = 0; a < kMaxAngles; a++) wt.w[a] = a < p->A ? weights_active[a] : 0.0;
     const int64_t total = sa.n * sa.nlam;
     const int64_t blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(k_reduce_J, dim3((unsigned)blocks), dim3(256), 0, st, sa.n, sa.nlam, sa.ldI,
-                       ldJ, p->A, wt, sa.I, dJ);
+    if (sa.f32)
+        hipLaunchKernelGGL(k_reduce_J<float>, dim3((unsigned)blocks), dim3(256), 0, st, sa.n, sa.nlam, sa.ldI,
+                           ldJ, p->A, wt, (const float *)sa.I, (float *)dJ);
+    else
+        hipLaunchKernelGGL(k_reduce_J<double>, dim3((unsigned)blocks), dim3(256), 0, st, sa.n, sa.nlam, sa.ldI,
+                           ldJ, p->A, wt, (const double *)sa.I, (double *)dJ);
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
 
 // per-angle intensities to the caller's (nlam, n, n_angles) array; skipped (θ = 90) angles -> 0
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_copy_I(int64_t n, int64_t nlam, int64_t ldI, int64_t ldO, int src_angle,
-         const double *__restrict__ I, double *__restrict__ out)
+         const T *__restrict__ I, T *__restrict__ out)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * nlam) return;
     const int64_t site = t / nlam;
     const int64_t l = t - site * nlam;
     out[(size_t)site * ldO + l] =
-        src_angle < 0 ? 0.0 : I[((size_t)src_angle * (size_t)n + (size_t)site) * (size_t)ldI + l];
+        src_angle < 0 ? (T)0 : I[((size_t)src_angle * (size_t)n + (size_t)site) * (size_t)ldI + l];
 }
 
-int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, double *dI_out, int64_t ldO, hipStream_t st)
+int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, void *dI_out, int64_t ldO, hipStream_t st)
 {
     std::vector<int> active_of_user((size_t)p->n_angles_user, -1);
     for (int a = 0; a < p->A; a++) active_of_user[(size_t)p->user_of_active[(size_t)a]] = a;
     const int64_t total = sa.n * sa.nlam;
     const int64_t blocks = (total + 255) / 256;
     for (int64_t u = 0; u < p->n_angles_user; u++) {
-        hipLaunchKernelGGL(k_copy_I, dim3((unsigned)blocks), dim3(256), 0, st, sa.n, sa.nlam, sa.ldI,
-                           ldO, active_of_user[(size_t)u], sa.I,
-                           dI_out + (size_t)u * (size_t)sa.n * (size_t)ldO);
+        const size_t off = (size_t)u * (size_t)sa.n * (size_t)ldO;
+        if (sa.f32)
+            hipLaunchKernelGGL(k_copy_I<float>, dim3((unsigned)blocks), dim3(256), 0, st, sa.n, sa.nlam, sa.ldI,
+                               ldO, active_of_user[(size_t)u], (const float *)sa.I, (float *)dI_out + off);
+        else
+            hipLaunchKernelGGL(k_copy_I<double>, dim3((unsigned)blocks), dim3(256), 0, st, sa.n, sa.nlam, sa.ldI,
+                               ldO, active_of_user[(size_t)u], (const double *)sa.I, (double *)dI_out + off);
     }
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
