@@ -504,3 +504,35 @@ def test_fp32_value_path_against_fp64_oracle(grids):
                              al[:, 0].astype(np.float64), so, 3)
     assert _rel(Id[1, :, 0].cpu().numpy().astype(np.float64), Iref) < 5e-6
     plan.close()
+
+
+def test_plain_c_caller_matches_oracle(tmp_path):
+    """examples/c_caller.c -- a C host standing in for the Julia caller -- gives the oracle's answer."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "voronoirt_amd")
+    exe = tmp_path / "c_caller"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_caller.c"), "-o", str(exe),
+                           "-L", libdir, "-lvrt_hip", f"-Wl,-rpath,{libdir}", "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = np.array([float(ln.split()[1]) for ln in out.stdout.strip().splitlines()])
+    nx, ny, nz = 3, 3, 4
+    n = nx * ny * nz
+    pos = np.zeros((n, 3))
+    nbr = np.zeros((7, n), dtype=np.int64)
+    for i in range(nx):
+        for j in range(ny):
+            for k in range(nz):
+                s = (i * ny + j) * nz + k
+                pos[s] = ((k + 0.5) / nz, (i + 0.5) / nx, (j + 0.5) / ny)
+                nbr[0, s] = 6
+                nbr[1:, s] = [((i + 1) % nx * ny + j) * nz + k + 1, ((i - 1) % nx * ny + j) * nz + k + 1,
+                              (i * ny + (j + 1) % ny) * nz + k + 1, (i * ny + (j - 1) % ny) * nz + k + 1,
+                              s + 2 if k + 1 < nz else -6, s if k > 0 else -5]
+    so = orc.make_sites(pos, nbr, (0, 1, 0, 1, 0, 1))
+    ref = orc.Delaunay_upII(orc.direction(150.0, 30.0), np.ones(n), np.full(so.layers_up[1] - 1, 3.0),
+                            np.full(n, 2.0), so, 3)
+    assert _rel(got, ref) < RTOL

@@ -444,3 +444,16 @@ def test_gloo_world2_reduce_and_gather(tmp_path):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert f"rank {r} ok" in out
+
+
+def test_header_is_valid_c_and_c_caller_links(tmp_path):
+    """include/voronoirt.h must be consumable from plain C (the Julia ccall / cgo / JNI side sees a C
+    ABI), and the example C host links against the library."""
+    hdr = os.path.join(ROOT, "include", "voronoirt.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    exe = tmp_path / "c_caller"
+    libdir = os.path.join(ROOT, "voronoirt_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_caller.c"), "-o", str(exe),
+                           "-L", libdir, "-lvrt_hip", f"-Wl,-rpath,{libdir}", "-lm"])
+    assert exe.exists()
