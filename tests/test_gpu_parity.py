@@ -435,7 +435,7 @@ def test_large_layers_fall_back_to_level_kernels():
     old = os.environ.pop("VRT_PATH", None)
     try:
         J, _ = plan.execute(S, al, weights=w, I0_up=I0)
-        assert plan.last_path == "levels"                     # 144 problems would otherwise pick "steps"
+        assert plan.last_path == "levels"                     # 144 problems would otherwise pick "tiles"
         ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
         assert _rel(J, ref) < RTOL
         os.environ["VRT_PATH"] = "steps"
@@ -450,7 +450,8 @@ def test_large_layers_fall_back_to_level_kernels():
 
 
 def test_default_path_choice(grids):
-    """Many (angle, wavelength) problems -> layer-step kernels; a single solve -> level kernels."""
+    """More (angle, wavelength) problems than CUs -> layer-step kernels; fewer -> the single
+    persistent launch of the tile kernel."""
     import os
     old = os.environ.pop("VRT_PATH", None)
     try:
@@ -459,12 +460,12 @@ def test_default_path_choice(grids):
         rng = np.random.default_rng(1)
         w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
         plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
-        S = 1 + rng.random((n, 16))
-        al = 5 * 10 ** rng.uniform(-2, 2, (n, 16))
+        S = 1 + rng.random((n, 24))
+        al = 5 * 10 ** rng.uniform(-2, 2, (n, 24))
         plan.execute(S, al, weights=w)
         assert plan.last_path == "steps"
         plan.execute(S[:, :2].copy(), al[:, :2].copy(), weights=w)
-        assert plan.last_path == "levels"
+        assert plan.last_path == "tiles"
         plan.close()
     finally:
         if old is not None:

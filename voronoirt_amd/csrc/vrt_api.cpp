@@ -421,11 +421,14 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         //   "steps"   two launches per BFS layer: chip-wide coefficient kernel + one workgroup per
         //             (angle, wavelength) running the layer's Gauss-Seidel levels on an LDS tile;
         //   "tiles"   ONE launch: each (angle, wavelength) workgroup walks all layers itself.
-        // steps/tiles need layers of at most 8192 sites and <= 255 levels per layer.  Default:
-        // steps when that holds and there are enough (angle, wavelength) problems to fill the
-        // chip, else levels.  VRT_PATH selects one explicitly.
+        // steps/tiles need layers of at most 8192 sites and <= 255 levels per layer.  Default when
+        // that holds: tiles while the (angle, wavelength) problems fit one round of workgroups
+        // (<= 256: one launch, no per-layer launch cost -- C2: 1.4 ms vs 7.6 ms on levels), steps
+        // beyond (C4: 21.7 vs 27.2 ms on tiles); levels otherwise and for the fp32 value path.
+        // VRT_PATH selects one explicitly.
         const char *force = std::getenv("VRT_PATH");
-        int path = (p->tile_ok && (int64_t)p->A * nlam >= 128 && !f32) ? 3 : 1;
+        int path = 1;
+        if (p->tile_ok && !f32) path = (int64_t)p->A * nlam <= 256 ? 2 : 3;
         if (force && std::strcmp(force, "levels") == 0) path = 1;
         if (force && std::strcmp(force, "tiles") == 0) path = 2;
         if (force && std::strcmp(force, "steps") == 0) path = 3;
