@@ -537,3 +537,34 @@ def test_plain_c_caller_matches_oracle(tmp_path):
     ref = orc.Delaunay_upII(orc.direction(150.0, 30.0), np.ones(n), np.full(so.layers_up[1] - 1, 3.0),
                             np.full(n, 2.0), so, 3)
     assert _rel(got, ref) < RTOL
+
+
+def test_degenerate_grids_and_plans(path):
+    """Edge cases on every device path: a single-layer grid (every cell touches the wall: no sweep
+    at all, I = I_0 except the never-visited last site), a two-layer grid, one angle / one
+    wavelength, and a plan whose only direction is horizontal (θ = 90: skipped, J = 0)."""
+    rng = np.random.default_rng(3)
+    for nz in (1, 2, 3):
+        pos, nbr, bounds = synth.regular_lattice_grid(4, 3, nz, seed=nz, jitter=0.2)
+        hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+        so = orc.make_sites(pos, nbr, bounds)
+        n = so.n
+        assert np.array_equal(hs.layers_up, so.layers_up) and np.array_equal(hs.perm_down, so.perm_down)
+        S, al = 1 + rng.random(n), 3 * rng.random(n)
+        for theta, phi in ((150.0, 20.0), (40.0, 250.0)):
+            k = vrt.direction(theta, phi)
+            up = theta > 90
+            lay = so.layers_up if up else so.layers_down
+            I0 = 1 + rng.random(lay[1] - 1)
+            got = (vrt.Delaunay_upII if up else vrt.Delaunay_downII)(k, S, I0, al, hs, 3)
+            ref = (orc.Delaunay_upII if up else orc.Delaunay_downII)(k, S, I0, al, so, 3)
+            assert _rel(got, ref) < RTOL
+            if nz == 1:
+                perm = so.perm_up if up else so.perm_down
+                assert np.array_equal(got[perm[:-1] - 1], I0) and got[perm[-1] - 1] == 0.0
+        # θ = 90 only: nothing to solve, J = 0 (lambda_iteration.jl:98,104 skip it)
+        plan = vrt.FormalPlan(hs, [vrt.direction(90.0, 10.0)], 3, dirs=[0])
+        J, I = plan.execute(np.ones((n, 2)), np.ones((n, 2)), weights=[1.0], want_I=True)
+        assert (J == 0).all() and (I == 0).all()
+        plan.close()
+        hs.close()

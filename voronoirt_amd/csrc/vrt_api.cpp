@@ -432,6 +432,7 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         if (force && std::strcmp(force, "levels") == 0) path = 1;
         if (force && std::strcmp(force, "tiles") == 0) path = 2;
         if (force && std::strcmp(force, "steps") == 0) path = 3;
+        if (p->A == 0) path = 1;      // nothing to solve (every direction skipped): J = 0 via the level path
         if (path != 1 && !p->tile_ok)
             return fail(VRT_EINVAL, "VRT_PATH=tiles/steps but the grid does not fit the layer-tile kernels");
         if (path != 1 && f32)

@@ -124,6 +124,9 @@ k_boundary_sweep_order(int64_t n, int nlam, int64_t n1, const int32_t *__restric
         const int l = l0 + c;
         // I_0 is ordered like perm[1:n1] (irregular_ray_tracing.jl:33); storage is Morton order
         if (l < nlam && p0 + tx < n1) Ia[(size_t)l * n + srank[order[p0 + tx]]] = tile[tx][c];
+        // the never-visited site perm[n] (storage position n-1) keeps I = 0 (voronoi_utils.jl:266)
+        // -- also on a single-layer grid, where no layer kernel ever runs
+        if (blockIdx.x == 0 && tx == 0 && l < nlam) Ia[(size_t)l * n + (n - 1)] = 0.0;
     }
 }
 
