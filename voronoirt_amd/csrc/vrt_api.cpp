@@ -176,6 +176,78 @@ static void free_plan(vrt_plan *p)
     delete p;
 }
 
+// Global-level schedule of the "levels" path (merged over the active angles), built on first use:
+// plan creation only pays for what the default path of the grid needs.
+static int ensure_level_schedule(vrt_plan *p)
+{
+    if (p->level_ready) return VRT_OK;
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const int A = p->A;
+    const int n_sweeps = p->n_sweeps;
+    std::vector<AngleSchedule> sched((size_t)A);
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int nthr = (int)std::min<unsigned>(hw ? hw : 4, 16);
+        nthr = std::max(1, std::min(nthr, std::max(A, 1)));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; t++)
+            pool.emplace_back([&, t]() {
+                for (int a = t; a < A; a += nthr) {
+                    const bool up = p->dir_of_active[(size_t)a] > 0;
+                    build_angle_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
+                                         p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n,
+                                         sched[(size_t)a]);
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    int64_t max_levels = 0, total = 0;
+    for (int a = 0; a < A; a++) {
+        if (sched[(size_t)a].bad_site >= 0) return fail(VRT_EGRID, "site without an upwind neighbour");
+        max_levels = std::max<int64_t>(max_levels, (int64_t)sched[(size_t)a].level_off.size() - 1);
+        total += (int64_t)sched[(size_t)a].site.size();
+    }
+    // merge: global level t = union over the angles of their level t
+    std::vector<int32_t> srank_up((size_t)n);
+    for (int64_t i = 0; i < n; i++) srank_up[(size_t)g->up.store[(size_t)i]] = (int32_t)i;
+    std::vector<uint32_t> node_site((size_t)total), node_meta((size_t)total);
+    p->level_off.assign((size_t)max_levels + 1, 0);
+    int64_t at = 0;
+    for (int64_t t = 0; t < max_levels; t++) {
+        p->level_off[(size_t)t] = at;
+        for (int a = 0; a < A; a++) {
+            const AngleSchedule &s = sched[(size_t)a];
+            if (t + 1 >= (int64_t)s.level_off.size()) continue;
+            // Nodes of one level are independent, so their order inside the launch is free: sort
+            // them along the (layer, Morton(x, y)) storage curve so that neighbouring workgroups
+            // work on neighbouring sites and the upwind rows they share are still in L2.
+            const int64_t x0 = s.level_off[(size_t)t], x1 = s.level_off[(size_t)t + 1];
+            std::vector<std::pair<int32_t, int64_t>> keyed((size_t)(x1 - x0));
+            for (int64_t x = x0; x < x1; x++)
+                keyed[(size_t)(x - x0)] = {srank_up[(size_t)s.site[(size_t)x]], x};
+            std::sort(keyed.begin(), keyed.end());
+            for (const auto &kv : keyed) {
+                const int64_t x = kv.second;
+                node_site[(size_t)at] = s.site[(size_t)x];
+                node_meta[(size_t)at] = (uint32_t)a | ((uint32_t)s.zflags[(size_t)x] << 8);
+                at++;
+            }
+        }
+    }
+    p->level_off[(size_t)max_levels] = at;
+    p->n_nodes = total;
+    int rc;
+    if ((rc = dev_alloc(&p->d_node_site, (size_t)total))) return rc;
+    if ((rc = dev_alloc(&p->d_node_meta, (size_t)total))) return rc;
+    if (total) {
+        VRT_HIP_TRY(hipMemcpy(p->d_node_site, node_site.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
+        VRT_HIP_TRY(hipMemcpy(p->d_node_meta, node_meta.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
+    }
+    p->level_ready = true;
+    return VRT_OK;
+}
+
 static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, const int *dirs,
                             int n_sweeps, vrt_plan **out)
 {
@@ -247,8 +319,11 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         VRT_HIP_TRY_FREE(hipMemcpy(up2.data(), p->d_up2, sizeof(int32_t) * tab, hipMemcpyDeviceToHost));
     }
 
-    // per-angle schedules, built concurrently on the host
-    std::vector<AngleSchedule> sched((size_t)A);
+    // per-angle layer-local schedules (always needed: they drive the default steps/tiles paths and
+    // detect sites without an upwind neighbour), built concurrently on the host.  The global-level
+    // schedule of the "levels" path is built on first use (ensure_level_schedule).
+    p->h_up1.swap(up1);
+    p->h_up2.swap(up2);
     std::vector<LayerSchedule> lsched((size_t)A);
     {
         unsigned hw = std::thread::hardware_concurrency();
@@ -259,63 +334,22 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             pool.emplace_back([&, t]() {
                 for (int a = t; a < A; a += nthr) {
                     const bool up = p->dir_of_active[(size_t)a] > 0;
-                    build_angle_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
-                                         up1.data() + (size_t)a * n, up2.data() + (size_t)a * n,
-                                         sched[(size_t)a]);
                     build_layer_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
-                                         up1.data() + (size_t)a * n, up2.data() + (size_t)a * n,
+                                         p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n,
                                          lsched[(size_t)a]);
                 }
             });
         for (auto &th : pool) th.join();
     }
-    int64_t max_levels = 0, total = 0;
     for (int a = 0; a < A; a++) {
-        if (sched[(size_t)a].bad_site >= 0) {
-            std::string msg = "site " + std::to_string(sched[(size_t)a].bad_site + 1) +
+        if (lsched[(size_t)a].bad_site >= 0) {
+            std::string msg = "site " + std::to_string(lsched[(size_t)a].bad_site + 1) +
                               " has no neighbour with k . line > -1 for angle " +
                               std::to_string(p->user_of_active[(size_t)a] + 1) +
                               " (the reference reads an uninitialised index here)";
             free_plan(p);
             return fail(VRT_EGRID, msg);
         }
-        max_levels = std::max<int64_t>(max_levels, (int64_t)sched[(size_t)a].level_off.size() - 1);
-        total += (int64_t)sched[(size_t)a].site.size();
-    }
-    // merge: global level t = union over the angles of their level t
-    std::vector<int32_t> srank_up((size_t)n);
-    for (int64_t i = 0; i < n; i++) srank_up[(size_t)g->up.store[(size_t)i]] = (int32_t)i;
-    std::vector<uint32_t> node_site((size_t)total), node_meta((size_t)total);
-    p->level_off.assign((size_t)max_levels + 1, 0);
-    int64_t at = 0;
-    for (int64_t t = 0; t < max_levels; t++) {
-        p->level_off[(size_t)t] = at;
-        for (int a = 0; a < A; a++) {
-            const AngleSchedule &s = sched[(size_t)a];
-            if (t + 1 >= (int64_t)s.level_off.size()) continue;
-            // Nodes of one level are independent, so their order inside the launch is free: sort
-            // them along the (layer, Morton(x, y)) storage curve so that neighbouring workgroups
-            // work on neighbouring sites and the upwind rows they share are still in L2.
-            const int64_t x0 = s.level_off[(size_t)t], x1 = s.level_off[(size_t)t + 1];
-            std::vector<std::pair<int32_t, int64_t>> keyed((size_t)(x1 - x0));
-            for (int64_t x = x0; x < x1; x++)
-                keyed[(size_t)(x - x0)] = {srank_up[(size_t)s.site[(size_t)x]], x};
-            std::sort(keyed.begin(), keyed.end());
-            for (const auto &kv : keyed) {
-                const int64_t x = kv.second;
-                node_site[(size_t)at] = s.site[(size_t)x];
-                node_meta[(size_t)at] = (uint32_t)a | ((uint32_t)s.zflags[(size_t)x] << 8);
-                at++;
-            }
-        }
-    }
-    p->level_off[(size_t)max_levels] = at;
-    p->n_nodes = total;
-    VRT_TRY_FREE(dev_alloc(&p->d_node_site, (size_t)total));
-    VRT_TRY_FREE(dev_alloc(&p->d_node_meta, (size_t)total));
-    if (total) {
-        VRT_HIP_TRY_FREE(hipMemcpy(p->d_node_site, node_site.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
-        VRT_HIP_TRY_FREE(hipMemcpy(p->d_node_meta, node_meta.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
     }
     std::vector<int32_t> ups, downs;
     for (int a = 0; a < A; a++) (p->dir_of_active[(size_t)a] > 0 ? ups : downs).push_back(a);
@@ -444,6 +478,7 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         }
         p->last_path = 1;
     }
+    if ((rc = ensure_level_schedule(p))) return rc;
     const size_t need = (size_t)std::max(1, p->A) * (size_t)n * (size_t)nlam;
     if ((rc = ensure(p->d_I, p->I_cap, f32 ? (need + 1) / 2 : need))) return rc;
     p->I_ld = nlam;
@@ -642,8 +677,18 @@ void vrt_plan_destroy(vrt_plan *p)
     free_plan(p);
 }
 
-int64_t vrt_plan_num_levels(const vrt_plan *p) { return p ? (int64_t)p->level_off.size() - 1 : 0; }
-int64_t vrt_plan_num_nodes(const vrt_plan *p) { return p ? p->n_nodes : 0; }
+int64_t vrt_plan_num_levels(const vrt_plan *p)
+{
+    if (!p) return 0;
+    if (ensure_level_schedule(const_cast<vrt_plan *>(p))) return -1;
+    return (int64_t)p->level_off.size() - 1;
+}
+int64_t vrt_plan_num_nodes(const vrt_plan *p)
+{
+    if (!p) return 0;
+    if (ensure_level_schedule(const_cast<vrt_plan *>(p))) return -1;
+    return p->n_nodes;
+}
 
 int vrt_plan_get_upwind(const vrt_plan *p, int64_t angle, int64_t *up, double *dots, double *w,
                         double *r)

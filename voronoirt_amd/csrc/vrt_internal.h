@@ -97,6 +97,8 @@ struct vrt_plan {
     uint32_t *d_node_site = nullptr;    // site id (0-based)
     uint32_t *d_node_meta = nullptr;    // active angle | zero-read flags
     std::vector<int64_t> level_off;     // nodes of level t are [level_off[t], level_off[t+1])
+    bool level_ready = false;           // the level schedule is built on first use
+    std::vector<int32_t> h_up1, h_up2;  // host copies of the upwind ids (schedule building)
     int64_t n_nodes = 0;
     // per-direction lists of active angle indices (for the boundary kernel)
     int32_t *d_angles_up = nullptr, *d_angles_down = nullptr;
