@@ -154,6 +154,16 @@ int vrt_delaunay_up(vrt_grid *g, const double k[3], const double *S, const doubl
 int vrt_delaunay_down(vrt_grid *g, const double k[3], const double *S, const double *I0,
                       int64_t nI0, const double *alpha, int n_sweeps, double *I_out);
 
+/* ---- Λ-iteration epilogue on the device (the physics-free part) -----------
+ * S_new[l,i] = (1 - eps[i]) J[l,i] + eps[i] B[l,i]           (src/lambda_iteration.jl:261-263)
+ * *max_rel_change = max |1 - S_old/S_new|, NaN if any term is NaN  (criterion, :325-349)
+ * All arrays are device pointers, (nlam, n) with leading dimension ld, eps[n]; S_new may alias
+ * neither S_old nor J.  Synchronises `stream` (the scalar comes back to the host), so a whole
+ * Λ-iteration J -> S_new -> J ... stays device-resident. */
+int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *dJ, const double *dB,
+                          const double *deps, const double *dS_old, double *dS_new,
+                          double *max_rel_change, void *stream);
+
 /* ---- regular-grid short characteristics ---------------------------------
  * Drop-in bodies for short_characteristics_up / short_characteristics_down
  * (src/characteristics.jl:19-95, :110-180), batched over independent solves the way

@@ -568,3 +568,54 @@ def test_degenerate_grids_and_plans(path):
         assert (J == 0).all() and (I == 0).all()
         plan.close()
         hs.close()
+
+
+def test_device_resident_lambda_iteration(grids):
+    """A whole Λ-iteration without host round trips (the loop of Λ_voronoi,
+    src/lambda_iteration.jl:253-283, with the physics reduced to given ε and B): J on the device,
+    S_new = (1-ε)J + εB and the convergence measure on the device, repeated; against the same loop
+    driven by the CPU oracle."""
+    import torch
+    from voronoirt_amd.api import lambda_update_dev
+    hs, so = grids["voronoi"]
+    n = so.n
+    nlam = 24                                              # 288 problems: layer-step kernels
+    rng = np.random.default_rng(21)
+    B = 1 + rng.random((n, nlam))
+    eps = 10 ** rng.uniform(-3, 0, n)                      # destruction probability per site
+    al = 5 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    n1 = so.layers_up[1] - 1
+    bottom = so.perm_up[:n1] - 1
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    Bd, epsd, ald = (torch.from_numpy(a).to(dev).contiguous() for a in (B, eps, al))
+    S_old = torch.zeros((n, nlam), dtype=torch.float64, device=dev)
+    S_new = Bd.clone()                                     # S_new = B initially (LTE start)
+    Jd = torch.zeros_like(S_new)
+    bottom_d = torch.from_numpy(bottom).to(dev)
+    S_ref_new, S_ref_old = B.copy(), np.zeros_like(B)
+    hist_gpu, hist_ref = [], []
+    for it in range(4):
+        S_old.copy_(S_new)
+        I0 = S_old[bottom_d].contiguous()
+        plan.execute_dev(nlam, nlam, S_old.data_ptr(), ald.data_ptr(), _lib.ALPHA_SITE_LAM, w,
+                         dJ=Jd.data_ptr(), dI0_up=I0.data_ptr(), stream=stream)
+        hist_gpu.append(lambda_update_dev(hs, nlam, nlam, Jd.data_ptr(), Bd.data_ptr(), epsd.data_ptr(),
+                                          S_old.data_ptr(), S_new.data_ptr(), stream))
+        S_ref_old = S_ref_new.copy()
+        J_ref = orc.J_voronoi(w, th, ph, S_ref_old, al, so, I0_up=S_ref_old[bottom], nthreads=8)
+        S_ref_new = (1 - eps)[:, None] * J_ref + eps[:, None] * B
+        hist_ref.append(float(np.abs(1 - S_ref_old / S_ref_new).max()))
+    assert plan.last_path == "steps"
+    assert _rel(S_new.cpu().numpy(), S_ref_new) < RTOL
+    assert np.allclose(hist_gpu, hist_ref, rtol=1e-9)
+    assert hist_gpu[-1] < hist_gpu[0]                      # the iteration contracts
+    # NaN propagates like Julia's maximum
+    S_new[0, 0] = float("nan")
+    S_old.copy_(S_new)
+    d = lambda_update_dev(hs, nlam, nlam, Jd.data_ptr(), Bd.data_ptr(), epsd.data_ptr(), S_old.data_ptr(),
+                          S_new.data_ptr(), stream)
+    assert np.isnan(d)
+    plan.close()

@@ -388,3 +388,14 @@ def short_characteristics_up(k, S_0, I_0, alpha, z, x, y, n_sweeps: int = 3, dev
 def short_characteristics_down(k, S_0, I_0, alpha, z, x, y, n_sweeps: int = 3, device: int = 0):
     """Intensity on the regular grid for rays travelling down (src/characteristics.jl:110-180)."""
     return short_characteristics_batch([k], [False], S_0, I_0, alpha, z, x, y, n_sweeps, device)[0]
+
+
+def lambda_update_dev(sites: VoronoiSites, nlam: int, ld: int, dJ: int, dB: int, deps: int, dS_old: int,
+                      dS_new: int, stream: int = 0) -> float:
+    """Device-resident Λ-iteration epilogue: S_new = (1 - ε) J + ε B (src/lambda_iteration.jl:261-263)
+    and the convergence measure max |1 - S_old/S_new| of `criterion` (:325-349), which is returned.
+    Arguments are device pointers (torch data_ptr())."""
+    out = ctypes.c_double()
+    check(_lib.load().vrt_lambda_update_dev(sites.handle, nlam, ld, dJ, dB, deps, dS_old, dS_new,
+                                            ctypes.byref(out), stream or None))
+    return out.value

@@ -916,6 +916,30 @@ int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches)
 
 int vrt_plan_last_path(const vrt_plan *p) { return p ? p->last_path : 0; }
 
+int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *dJ, const double *dB,
+                          const double *deps, const double *dS_old, double *dS_new, double *max_rel_change,
+                          void *stream)
+{
+    if (!g || !dJ || !dB || !deps || !dS_old || !dS_new || !max_rel_change)
+        return fail(VRT_EINVAL, "NULL argument");
+    if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *d_res = nullptr;
+    VRT_HIP_TRY(hipMalloc((void **)&d_res, 2 * sizeof(unsigned long long)));
+    rc = launch_lambda_update(g->n, nlam, ld, dJ, dB, deps, dS_old, dS_new, d_res, st);
+    unsigned long long h[2] = {0, 0};
+    if (!rc && hipMemcpyAsync(h, d_res, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) rc = VRT_ENODEVICE;
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = VRT_ENODEVICE;
+    (void)hipFree(d_res);
+    if (rc) return rc == VRT_ENODEVICE ? fail(rc, "HIP error in vrt_lambda_update_dev") : rc;
+    double d;
+    std::memcpy(&d, &h[0], sizeof(double));
+    *max_rel_change = h[1] ? std::nan("") : d;
+    return VRT_OK;
+}
+
 static int single_solve(vrt_grid *g, int dir, const double k[3], const double *S, const double *I0,
                         int64_t nI0, const double *alpha, int n_sweeps, double *I_out)
 {

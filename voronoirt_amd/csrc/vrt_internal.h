@@ -191,6 +191,10 @@ int launch_reduce_J(vrt_plan *p, const SweepArgs &sa, const double *weights_acti
                     int64_t ldJ, hipStream_t st);
 int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, void *dI_out, int64_t ldO, hipStream_t st);
 
+int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, const double *dB,
+                         const double *deps, const double *dS_old, double *dS_new,
+                         unsigned long long *d_result, hipStream_t st);
+
 // ---- layer-tile path (vrt_tiles.hip) ----------------------------------------------------------
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const double *dalpha,

@@ -436,4 +436,52 @@ int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, void *dI_out, int64_t ld
     return VRT_OK;
 }
 
+// --------------------------------------------------------------------------------------------
+// Λ-iteration epilogue (the part that needs no physics library):
+//   S_new[l, i] = (1 - ε_i) J[l, i] + ε_i B[l, i]                 lambda_iteration.jl:261-263
+//   diff = max_{l,i} |1 - S_old[l, i] / S_new[l, i]|                criterion, :325-349
+// One pass over (site, λ); the maximum is reduced per wave with shuffles and merged with an
+// integer atomicMax on the IEEE bits (all candidates are >= 0, so the bit pattern orders like
+// the value); a NaN anywhere makes the result NaN as Julia's `maximum` does.
+// --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *__restrict__ J,
+                const double *__restrict__ B, const double *__restrict__ eps,
+                const double *__restrict__ S_old, double *__restrict__ S_new,
+                unsigned long long *__restrict__ result /* [0] max bits, [1] NaN flag */)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double d = 0.0;
+    bool isnan_ = false;
+    if (t < n * nlam) {
+        const int64_t site = t / nlam, l = t - site * nlam;
+        const size_t o = (size_t)site * ld + l;
+        const double e = eps[site];
+        const double s_new = (1.0 - e) * J[o] + e * B[o];
+        S_new[o] = s_new;
+        d = fabs(1.0 - S_old[o] / s_new);
+        isnan_ = !(d == d);
+        if (isnan_) d = 0.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d = fmax(d, __shfl_xor(d, off, 64));
+    const unsigned long long any_nan = __ballot(isnan_);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&result[0], (unsigned long long)__double_as_longlong(d));
+        if (any_nan) atomicMax(&result[1], 1ull);
+    }
+}
+
+int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, const double *dB,
+                         const double *deps, const double *dS_old, double *dS_new,
+                         unsigned long long *d_result, hipStream_t st)
+{
+    VRT_HIP_TRY(hipMemsetAsync(d_result, 0, 2 * sizeof(unsigned long long), st));
+    const int64_t total = n * nlam;
+    hipLaunchKernelGGL(k_lambda_update, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n, nlam, ld,
+                       dJ, dB, deps, dS_old, dS_new, d_result);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 }  // namespace vrt
