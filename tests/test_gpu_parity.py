@@ -619,3 +619,36 @@ def test_device_resident_lambda_iteration(grids):
                           S_new.data_ptr(), stream)
     assert np.isnan(d)
     plan.close()
+
+
+def test_concurrent_single_solves_on_one_handle(grids):
+    """The reference calls Delaunay_*II concurrently from Threads.@threads with a shared `sites`
+    (lambda_iteration.jl:91-107); the drop-in must be re-entrant on one grid handle."""
+    import threading
+    hs, so = grids["bcc"]
+    n = so.n
+    rng = np.random.default_rng(77)
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    jobs = []
+    for j in range(12):
+        S = 1 + rng.random(n)
+        al = 1e-6 * 10 ** rng.uniform(-2, 2, n)
+        up = th[j] > 90
+        lay = so.layers_up if up else so.layers_down
+        I0 = rng.random(lay[1] - 1)
+        jobs.append((vrt.direction(th[j], ph[j]), S, I0, al, up))
+    out = [None] * len(jobs)
+
+    def work(j):
+        k, S, I0, al, up = jobs[j]
+        for _ in range(3):
+            out[j] = (vrt.Delaunay_upII if up else vrt.Delaunay_downII)(k, S, I0, al, hs, 3)
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for j, (k, S, I0, al, up) in enumerate(jobs):
+        ref = (orc.Delaunay_upII if up else orc.Delaunay_downII)(k, S, I0, al, so, 3)
+        assert _rel(out[j], ref) < RTOL

@@ -73,6 +73,7 @@ static void free_grid(vrt_grid *g)
     dev_free(g->down.d_rank);
     dev_free(g->up.d_lay);
     dev_free(g->down.d_lay);
+    dev_free(g->d_scalars);
     dev_free(g->up.d_store);
     dev_free(g->down.d_store);
     dev_free(g->up.d_srank);
@@ -926,13 +927,13 @@ int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *d
     int rc = use_device(g->device);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    unsigned long long *d_res = nullptr;
-    VRT_HIP_TRY(hipMalloc((void **)&d_res, 2 * sizeof(unsigned long long)));
+    std::lock_guard<std::mutex> lock(g->mu);
+    if (!g->d_scalars) VRT_HIP_TRY(hipMalloc((void **)&g->d_scalars, 2 * sizeof(unsigned long long)));
+    unsigned long long *d_res = g->d_scalars;
     rc = launch_lambda_update(g->n, nlam, ld, dJ, dB, deps, dS_old, dS_new, d_res, st);
     unsigned long long h[2] = {0, 0};
     if (!rc && hipMemcpyAsync(h, d_res, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) rc = VRT_ENODEVICE;
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = VRT_ENODEVICE;
-    (void)hipFree(d_res);
     if (rc) return rc == VRT_ENODEVICE ? fail(rc, "HIP error in vrt_lambda_update_dev") : rc;
     double d;
     std::memcpy(&d, &h[0], sizeof(double));
@@ -950,24 +951,25 @@ static int single_solve(vrt_grid *g, int dir, const double k[3], const double *S
                                     std::to_string(d.n1));
     if (nI0 > 0 && !I0) return fail(VRT_EINVAL, "I_0 is NULL");
     try {
+        // The cache lookup, a possible eviction and the solve itself run under the grid's mutex:
+        // concurrent callers (the reference calls these from Threads.@threads) are serialised per
+        // grid handle, which also keeps an evicted plan from being used by another thread.
+        std::lock_guard<std::mutex> lock(g->mu);
         vrt_plan *plan = nullptr;
-        {
-            std::lock_guard<std::mutex> lock(g->mu);
-            for (PlanCacheEntry *c : g->cache)
-                if (c->n_sweeps == n_sweeps * dir && c->k[0] == k[0] && c->k[1] == k[1] && c->k[2] == k[2])
-                    plan = c->plan;
-            if (!plan) {
-                int dirs[1] = {dir};
-                int rc = plan_create_impl(g, 1, k, dirs, n_sweeps, &plan);
-                if (rc) return rc;
-                if (g->cache.size() >= 64) {   // drop the oldest entry
-                    vrt_plan_destroy(g->cache.front()->plan);
-                    delete g->cache.front();
-                    g->cache.erase(g->cache.begin());
-                }
-                PlanCacheEntry *c = new PlanCacheEntry{{k[0], k[1], k[2]}, n_sweeps * dir, plan};
-                g->cache.push_back(c);
+        for (PlanCacheEntry *c : g->cache)
+            if (c->n_sweeps == n_sweeps * dir && c->k[0] == k[0] && c->k[1] == k[1] && c->k[2] == k[2])
+                plan = c->plan;
+        if (!plan) {
+            int dirs[1] = {dir};
+            int rc = plan_create_impl(g, 1, k, dirs, n_sweeps, &plan);
+            if (rc) return rc;
+            if (g->cache.size() >= 64) {   // drop the oldest entry
+                vrt_plan_destroy(g->cache.front()->plan);
+                delete g->cache.front();
+                g->cache.erase(g->cache.begin());
             }
+            PlanCacheEntry *c = new PlanCacheEntry{{k[0], k[1], k[2]}, n_sweeps * dir, plan};
+            g->cache.push_back(c);
         }
         const double one = 1.0;
         // I_out doubles as J with weight 1: J = 0 + 1*I is exact

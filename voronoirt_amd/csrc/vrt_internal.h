@@ -75,6 +75,7 @@ struct vrt_grid {
     int32_t *d_col = nullptr;
     double *d_lz = nullptr, *d_lx = nullptr, *d_ly = nullptr;   // Delaunay lines, CSR-packed SoA
     hipStream_t stream = nullptr;
+    unsigned long long *d_scalars = nullptr;   // scratch of the Λ-iteration epilogue's reduction
     // cache of single-angle plans for vrt_delaunay_up/down
     std::mutex mu;
     std::vector<vrt::PlanCacheEntry *> cache;
