@@ -13,7 +13,9 @@
  * holds no golden vector, known-answer test or fixture for the Voronoi path (SURVEY.md section
  * 4/8c), and no Julia toolchain exists in the build image to run it.  That part is pinned only
  * by analytic known answers that follow from the reference code itself and by an independent
- * second transcription (tests/test_oracle.py, oracle/pyref.py).
+ * second transcription (tests/test_oracle.py, oracle/pyref.py), and -- statistically -- by the
+ * reference's committed searchlight rasters (beam centroid, width and peak of
+ * data/searchlight_data/I_*_voronoi.npy; tests/test_searchlight_reference.py).
  * PARITY STATUS, regular-grid solver (end of this file) and the numerics it shares with the
  * Voronoi path (linear_weights, trapezoidal): PINNED by outputs of the reference itself -- the
  * data files data/searchlight_data/I_160_45_regular.npy and I_20_15_regular.npy are reproduced
