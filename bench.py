@@ -212,7 +212,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         "metric": "formal-solve cell-updates/sec", "value": value, "unit": "cell-updates/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong" if args.shard == "angle" else "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "storage_dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": f"{workload}: jittered-BCC Voronoi grid a={a} c={c} ({n} sites, "
                         f"L_up={len(sites.layers_up) - 1} layers), {quad} ({n_angles} angles), "
@@ -246,7 +246,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
 
     # ---- CPU baseline: the oracle, threaded the way the reference is (angles serial, λ split
     # over threads), on a bounded sample of the same workload; also a full-size parity check ----
-    if rank == 0 and cpu_baseline:
+    if rank == 0 and world == 1 and cpu_baseline:      # reported at N = 1 only
         from oracle import oracle as orc
         cores = min(len(os.sched_getaffinity(0)), 16)
         lam_s = args.cpu_lam if args.cpu_lam > 0 else min(nlam, cores)

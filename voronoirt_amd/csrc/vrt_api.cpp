@@ -167,6 +167,7 @@ static void free_plan(vrt_plan *p)
     dev_free(p->t_u1); dev_free(p->t_u2);
     dev_free(p->t_w1); dev_free(p->t_w2); dev_free(p->t_r1); dev_free(p->t_r2);
     dev_free(p->t_vis);
+    dev_free(p->t_loc);
     dev_free(p->d_nlev); dev_free(p->d_angle_dir); dev_free(p->d_task_map);
     for (int d = 0; d < 2; d++) { dev_free(p->ws_S[d]); dev_free(p->ws_A[d]); dev_free(p->ws_J[d]); }
     dev_free(p->ws_AA);
@@ -384,6 +385,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             VRT_TRY_FREE(dev_alloc(&p->t_r1, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_r2, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_vis, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_loc, tab));
             uint32_t *d_vis_site = nullptr;
             VRT_TRY_FREE(dev_alloc(&d_vis_site, (size_t)n));
             const int maxL = (int)std::max(g->up.reduced.size(), g->down.reduced.size()) - 1;

@@ -119,7 +119,7 @@ struct vrt_plan {
     int64_t tile_visits = 0;
     int32_t *t_u1 = nullptr, *t_u2 = nullptr;
     double *t_w1 = nullptr, *t_w2 = nullptr, *t_r1 = nullptr, *t_r2 = nullptr;
-    uint32_t *t_vis = nullptr;
+    uint32_t *t_vis = nullptr, *t_loc = nullptr;
     int32_t *d_nlev = nullptr, *d_angle_dir = nullptr;
     std::vector<int64_t> angle_visits;   // surviving visits per active angle (task cost)
     std::vector<int32_t> h_task_map;     // block -> angle | wavelength << 8

@@ -34,16 +34,29 @@ k_permute_table(int64_t n, const int32_t *__restrict__ order, const int32_t *__r
                 const int32_t *__restrict__ up1, const int32_t *__restrict__ up2,
                 const double *__restrict__ w1, const double *__restrict__ w2,
                 const double *__restrict__ r1, const double *__restrict__ r2,
-                const uint32_t *__restrict__ vis, int32_t *__restrict__ t_u1,
-                int32_t *__restrict__ t_u2, double *__restrict__ t_w1, double *__restrict__ t_w2,
-                double *__restrict__ t_r1, double *__restrict__ t_r2, uint32_t *__restrict__ t_vis)
+                const uint32_t *__restrict__ vis, const int32_t *__restrict__ lay, int nlayers,
+                int32_t *__restrict__ t_u1, int32_t *__restrict__ t_u2, double *__restrict__ t_w1,
+                double *__restrict__ t_w2, double *__restrict__ t_r1, double *__restrict__ t_r2,
+                uint32_t *__restrict__ t_vis, uint32_t *__restrict__ t_loc)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int32_t s = order[p];
     const int32_t a = up1[s], b = up2[s];
-    t_u1[p] = a >= 0 ? rank[a] : -1;
-    t_u2[p] = b >= 0 ? rank[b] : -1;
+    const int32_t ua = a >= 0 ? rank[a] : -1, ub = b >= 0 ? rank[b] : -1;
+    t_u1[p] = ua;
+    t_u2[p] = ub;
+    // in-layer tile slots of the two upwinds (16 bits each; 0 when the upwind is not in the
+    // site's own layer -- its coupling coefficient is 0 then): depends on (angle, site) only
+    int lo_i = 0, hi_i = nlayers;                 // layer l = [lay[l-1], lay[l]): find l with p inside
+    while (hi_i - lo_i > 1) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (lay[mid] <= p) lo_i = mid; else hi_i = mid;
+    }
+    const int lo = lay[lo_i], hi = lay[lo_i + 1];
+    const uint32_t l1 = (ua >= lo && ua < hi) ? (uint32_t)(ua - lo) : 0u;
+    const uint32_t l2 = (ub >= lo && ub < hi) ? (uint32_t)(ub - lo) : 0u;
+    t_loc[p] = l1 | (l2 << 16);
     t_w1[p] = w1[s];
     t_w2[p] = w2[s];
     t_r1[p] = r1[s];
@@ -59,8 +72,9 @@ int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site)
     const size_t o = (size_t)a * (size_t)n;
     hipLaunchKernelGGL(k_permute_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g->stream, n,
                        dir.d_store, dir.d_srank, p->d_up1 + o, p->d_up2 + o, p->d_w1 + o, p->d_w2 + o,
-                       p->d_r1 + o, p->d_r2 + o, d_vis_site, p->t_u1 + o, p->t_u2 + o, p->t_w1 + o,
-                       p->t_w2 + o, p->t_r1 + o, p->t_r2 + o, p->t_vis + o);
+                       p->d_r1 + o, p->d_r2 + o, d_vis_site, dir.d_lay, (int)dir.reduced.size() - 1,
+                       p->t_u1 + o, p->t_u2 + o, p->t_w1 + o, p->t_w2 + o, p->t_r1 + o, p->t_r2 + o,
+                       p->t_vis + o, p->t_loc + o);
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
@@ -212,6 +226,7 @@ struct TileArgs {
     const int32_t *t_u1, *t_u2;     // [A][n] sweep positions of the upwinds
     const double *t_w1, *t_w2, *t_r1, *t_r2;
     const uint32_t *t_vis;
+    const uint32_t *t_loc;          // [A][n] packed in-layer tile slots of the two upwinds
     const double *S[2];             // per direction [nlam][n]
     const double *alpha[2];         // SITE: [n]; SITE_LAM: [nlam][n] per direction
     const double *alpha_angle;      // ANGLE: [A][nlam][n]
@@ -380,8 +395,7 @@ struct StepArgs {
     TileArgs ta;
     int layer;                // 1-based BFS layer being solved
     int cg_stride;            // slots per (angle, wavelength) in the coefficient buffers
-    double *cg_c, *cg_g1, *cg_g2;
-    uint32_t *cg_loc;
+    double *cg_c, *cg_g1, *cg_g2;   // (loc and vis are λ-independent: read from the table)
     int debug_skip_levels;    // diagnostics only (VRT_DEBUG_SKIP_LEVELS=1): wrong results
 };
 
@@ -414,7 +428,6 @@ k_step_coeffs(StepArgs sa)
     const bool early1 = u1 < lo, in1 = (u1 >= lo) & (u1 < hi);
     const bool early2 = u2 < lo, in2 = (u2 >= lo) & (u2 < hi);
     const int i1 = min(u1, lo - 1), i2 = min(u2, lo - 1);
-    const uint32_t locw = (in1 ? (uint32_t)(u1 - lo) : 0u) | ((in2 ? (uint32_t)(u2 - lo) : 0u) << 16);
     const int lend = min(l0 + kStepLam, ta.nlam);
     for (int l = l0; l < lend; l++) {
         const double *__restrict__ S = ta.S[d] + (size_t)l * (size_t)n;
@@ -437,7 +450,6 @@ k_step_coeffs(StepArgs sa)
         sa.cg_c[o] = t1 + t2;
         sa.cg_g1[o] = gg1;
         sa.cg_g2[o] = gg2;
-        sa.cg_loc[o] = locw;
     }
 }
 
@@ -456,6 +468,7 @@ k_step_levels(StepArgs sa)
     const int cnt = hi - lo;
     const int64_t n = ta.n;
     const uint32_t *__restrict__ tvis = ta.t_vis + (size_t)a * (size_t)n;
+    const uint32_t *__restrict__ tloc = ta.t_loc + (size_t)a * (size_t)n;
     double *I = ta.I + ((size_t)a * ta.nlam + l) * (size_t)n;
     const size_t o = (size_t)task * (size_t)sa.cg_stride;
     double c[K], g1[K], g2[K];
@@ -468,7 +481,7 @@ k_step_levels(StepArgs sa)
         c[k] = sa.cg_c[o + s];
         g1[k] = sa.cg_g1[o + s];
         g2[k] = sa.cg_g2[o + s];
-        loc[k] = sa.cg_loc[o + s];
+        loc[k] = tloc[lo + s];
         vis[k] = ok ? tvis[lo + s] : 0u;
         if (ok) tile[slot] = 0.0;                  // I = zero(S), irregular_ray_tracing.jl:23
     }
@@ -666,6 +679,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     ta.t_u1 = p->t_u1; ta.t_u2 = p->t_u2;
     ta.t_w1 = p->t_w1; ta.t_w2 = p->t_w2; ta.t_r1 = p->t_r1; ta.t_r2 = p->t_r2;
     ta.t_vis = p->t_vis;
+    ta.t_loc = p->t_loc;
     ta.alpha_angle = nullptr;
     ta.I = p->d_I;
     for (int d = 0; d < 2; d++) {
@@ -720,12 +734,10 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         if ((rc = ensure_dev(p->ws_cg[0], p->ws_cg_cap[0], cgn))) return rc;
         if ((rc = ensure_dev(p->ws_cg[1], p->ws_cg_cap[1], cgn))) return rc;
         if ((rc = ensure_dev(p->ws_cg[2], p->ws_cg_cap[2], cgn))) return rc;
-        if ((rc = ensure_dev(p->ws_cg[3], p->ws_cg_cap[3], (cgn + 1) / 2))) return rc;
         StepArgs sa;
         sa.ta = ta;
         sa.cg_stride = stride;
         sa.cg_c = p->ws_cg[0]; sa.cg_g1 = p->ws_cg[1]; sa.cg_g2 = p->ws_cg[2];
-        sa.cg_loc = reinterpret_cast<uint32_t *>(p->ws_cg[3]);
         sa.debug_skip_levels = std::getenv("VRT_DEBUG_SKIP_LEVELS") != nullptr;
         const int Lmax = std::max(ta.nlayers[0] * (use_dir[0] ? 1 : 0), ta.nlayers[1] * (use_dir[1] ? 1 : 0));
         const dim3 g1((unsigned)((p->tile_max_layer_size + 255) / 256),
