@@ -100,3 +100,35 @@ def test_gpu_searchlight_matches_reference_image_statistics(searchlight_grid, na
     img, k = _run(vrt.Delaunay_upII, vrt.Delaunay_downII, hs, pos, theta, phi, up)
     _check(img, k, ref)
     hs.close()
+
+
+@pytest.mark.gpu
+def test_gpu_J_on_true_voronoi_grid_at_reference_resolution(searchlight_grid):
+    """J_λ_voronoi on the 51^3-site TRUE Voronoi tessellation (irregular layer sizes, 5-30
+    neighbours per cell, upwind neighbours in later layers): 12 angles x 24 wavelengths (layer-step
+    kernels) and a single wavelength (tile kernel) against the oracle."""
+    pos, nbr, bounds, so = searchlight_grid
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    for key in ("layers_up", "layers_down", "perm_up", "perm_down"):
+        assert np.array_equal(getattr(hs, key), getattr(so, key)), key
+    n = so.n
+    rng = np.random.default_rng(5)
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    for a in (0, 5, 8):
+        up, dots, wt, r, st = orc.upwind_table(so, vrt.direction(th[a], ph[a]))
+        gup, gd, gw, gr = plan.upwind(a)
+        ok = st == 0
+        assert np.array_equal(gup[ok], up[ok]) and np.array_equal(gd[ok], dots[ok])
+    for nlam, expect in ((24, "steps"), (1, "tiles")):
+        S = 1 + rng.random((n, nlam))
+        al = 30 * 10 ** rng.uniform(-3, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+        I0 = rng.random((so.layers_up[1] - 1, nlam))
+        J, _ = plan.execute(S, al, weights=w, I0_up=I0)
+        assert plan.last_path == expect
+        lam_check = [0, nlam - 1] if nlam > 1 else [0]
+        ref = orc.J_voronoi(w, th, ph, S[:, lam_check], al[:, lam_check], so, I0_up=I0[:, lam_check], nthreads=4)
+        err = np.abs(J[:, lam_check] - ref).max() / np.abs(ref).max()
+        assert err < 1e-10, (nlam, err)
+    plan.close()
+    hs.close()
