@@ -172,6 +172,12 @@ static void free_plan(vrt_plan *p)
     for (int d = 0; d < 2; d++) { dev_free(p->ws_S[d]); dev_free(p->ws_A[d]); dev_free(p->ws_J[d]); }
     dev_free(p->ws_AA);
     for (int i = 0; i < 4; i++) dev_free(p->ws_cg[i]);
+    dev_free(p->d_step_angles);
+    if (p->step_fork) (void)hipEventDestroy(p->step_fork);
+    for (int i = 0; i < 4; i++) {
+        if (p->step_join[i]) (void)hipEventDestroy(p->step_join[i]);
+        if (p->step_stream[i]) (void)hipStreamDestroy(p->step_stream[i]);
+    }
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -512,7 +518,13 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         bool replayed = false;
         if (use_graph) {
             if (!(p->graph_exec && p->graph_key == key)) {
-                if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+                dev_free(p->d_step_angles);
+    if (p->step_fork) (void)hipEventDestroy(p->step_fork);
+    for (int i = 0; i < 4; i++) {
+        if (p->step_join[i]) (void)hipEventDestroy(p->step_join[i]);
+        if (p->step_stream[i]) (void)hipStreamDestroy(p->step_stream[i]);
+    }
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
                 p->graph_exec = nullptr;
                 hipGraph_t graph = nullptr;
                 if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {

@@ -132,6 +132,12 @@ struct vrt_plan {
     size_t ws_AA_cap = 0;
     double *ws_cg[4] = {nullptr, nullptr, nullptr, nullptr};   // layer-step coefficient buffers
     size_t ws_cg_cap[4] = {0, 0, 0, 0};
+    // layer-step path: internal streams and the angle groups they advance through the layers
+    int step_groups = 0;
+    int32_t *d_step_angles = nullptr;
+    std::vector<int> step_group_off;
+    hipStream_t step_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t step_fork = nullptr, step_join[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_path = 0;                   // 1 = level kernels, 2 = layer tiles
     // hipGraph of the level-launch sequence, replayed while the arguments stay the same
     hipGraphExec_t graph_exec = nullptr;

@@ -396,6 +396,8 @@ struct StepArgs {
     int layer;                // 1-based BFS layer being solved
     int cg_stride;            // slots per (angle, wavelength) in the coefficient buffers
     double *cg_c, *cg_g1, *cg_g2;   // (loc and vis are λ-independent: read from the table)
+    const int32_t *angle_list;      // the angles this launch works on (one stream's share)
+    int n_list;
     int debug_skip_levels;    // diagnostics only (VRT_DEBUG_SKIP_LEVELS=1): wrong results
 };
 
@@ -413,7 +415,7 @@ k_step_coeffs(StepArgs sa)
 {
     const TileArgs &ta = sa.ta;
     const int ngrp = (ta.nlam + kStepLam - 1) / kStepLam;
-    const int a = blockIdx.y / ngrp;
+    const int a = sa.angle_list[blockIdx.y / ngrp];
     const int l0 = (blockIdx.y % ngrp) * kStepLam;
     const int d = ta.angle_dir[a];
     if (sa.layer > ta.nlayers[d]) return;
@@ -460,8 +462,8 @@ k_step_levels(StepArgs sa)
     extern __shared__ __attribute__((aligned(16))) double tile[];
     const TileArgs &ta = sa.ta;
     const int T = 1024, tid = threadIdx.x;
-    const int task = blockIdx.x;                    // = angle * nlam + wavelength
-    const int a = task / ta.nlam, l = task % ta.nlam;
+    const int a = sa.angle_list[blockIdx.x / ta.nlam], l = blockIdx.x % ta.nlam;
+    const int task = a * ta.nlam + l;
     const int d = ta.angle_dir[a];
     if (sa.layer > ta.nlayers[d]) return;
     const int lo = ta.lay[d][sa.layer - 1], hi = ta.lay[d][sa.layer];
@@ -651,6 +653,36 @@ static int build_task_map(vrt_plan *p, int nlam, hipStream_t st)
     return VRT_OK;
 }
 
+// internal streams + angle groups of the layer-step path
+static int ensure_step_streams(vrt_plan *p, int G)
+{
+    if (p->step_groups == G && p->d_step_angles) return VRT_OK;
+    const int A = p->A;
+    std::vector<int32_t> order((size_t)A);
+    for (int a = 0; a < A; a++) order[(size_t)a] = a;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        return p->angle_visits[(size_t)x] > p->angle_visits[(size_t)y];
+    });
+    std::vector<int32_t> list;
+    p->step_group_off.assign((size_t)G + 1, 0);
+    for (int gi = 0; gi < G; gi++) {
+        p->step_group_off[(size_t)gi] = (int)list.size();
+        for (int j = gi; j < A; j += G) list.push_back(order[(size_t)j]);
+    }
+    p->step_group_off[(size_t)G] = (int)list.size();
+    if (!p->d_step_angles) VRT_HIP_TRY(hipMalloc((void **)&p->d_step_angles, sizeof(int32_t) * (size_t)std::max(A, 1)));
+    VRT_HIP_TRY(hipMemcpy(p->d_step_angles, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice));
+    if (!p->step_fork) VRT_HIP_TRY(hipEventCreateWithFlags(&p->step_fork, hipEventDisableTiming));
+    for (int gi = 0; gi < 4; gi++) {
+        if (gi < G && !p->step_stream[gi]) {
+            VRT_HIP_TRY(hipStreamCreateWithFlags(&p->step_stream[gi], hipStreamNonBlocking));
+            VRT_HIP_TRY(hipEventCreateWithFlags(&p->step_join[gi], hipEventDisableTiming));
+        }
+    }
+    p->step_groups = G;
+    return VRT_OK;
+}
+
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const double *dalpha,
                   int alpha_mode, const double *dI0_up, const double *dI0_down,
                   const double *weights_user, double *dJ, double *dI_out, hipStream_t st)
@@ -740,21 +772,42 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         sa.cg_c = p->ws_cg[0]; sa.cg_g1 = p->ws_cg[1]; sa.cg_g2 = p->ws_cg[2];
         sa.debug_skip_levels = std::getenv("VRT_DEBUG_SKIP_LEVELS") != nullptr;
         const int Lmax = std::max(ta.nlayers[0] * (use_dir[0] ? 1 : 0), ta.nlayers[1] * (use_dir[1] ? 1 : 0));
-        const dim3 g1((unsigned)((p->tile_max_layer_size + 255) / 256),
-                      (unsigned)((size_t)A * (size_t)((nlam + kStepLam - 1) / kStepLam)));
-        const dim3 g2((unsigned)((size_t)A * (size_t)nlam));
         const size_t lds = (size_t)std::max<int64_t>(p->tile_max_layer_size, 1) * sizeof(double);
+        // The angles are dealt (heaviest first) to a few internal streams that advance through
+        // the layers independently: the (angle, wavelength) problems of different streams share
+        // nothing, so one stream's launches fill the tail of the other's (612 level workgroups
+        // are 2.4 rounds of the 256 CUs: a lone launch idles a fifth of the chip in its last round).
+        int G = 2;
+        if (const char *e = std::getenv("VRT_STEP_STREAMS")) G = std::atoi(e);
+        G = std::max(1, std::min({G, 4, A}));
+        if ((rc = ensure_step_streams(p, G))) return rc;
         VRT_HIP_TRY(hipEventRecord(p->ev0, st));
+        VRT_HIP_TRY(hipEventRecord(p->step_fork, st));
         launches = 0;
-        for (int layer = 2; layer <= Lmax; layer++) {
-            sa.layer = layer;
-            hipLaunchKernelGGL(k_step_coeffs, g1, dim3(256), 0, st, sa);
-            switch (p->tile_K) {
-            case 2: hipLaunchKernelGGL(k_step_levels<2>, g2, dim3(1024), lds, st, sa); break;
-            case 4: hipLaunchKernelGGL(k_step_levels<4>, g2, dim3(1024), lds, st, sa); break;
-            default: hipLaunchKernelGGL(k_step_levels<8>, g2, dim3(1024), lds, st, sa); break;
+        for (int gi = 0; gi < G; gi++) {
+            hipStream_t sg = G == 1 ? st : p->step_stream[gi];
+            if (G > 1) VRT_HIP_TRY(hipStreamWaitEvent(sg, p->step_fork, 0));
+            const int n_list = p->step_group_off[gi + 1] - p->step_group_off[gi];
+            if (n_list == 0) continue;
+            sa.angle_list = p->d_step_angles + p->step_group_off[gi];
+            sa.n_list = n_list;
+            const dim3 g1((unsigned)((p->tile_max_layer_size + 255) / 256),
+                          (unsigned)((size_t)n_list * (size_t)((nlam + kStepLam - 1) / kStepLam)));
+            const dim3 g2((unsigned)((size_t)n_list * (size_t)nlam));
+            for (int layer = 2; layer <= Lmax; layer++) {
+                sa.layer = layer;
+                hipLaunchKernelGGL(k_step_coeffs, g1, dim3(256), 0, sg, sa);
+                switch (p->tile_K) {
+                case 2: hipLaunchKernelGGL(k_step_levels<2>, g2, dim3(1024), lds, sg, sa); break;
+                case 4: hipLaunchKernelGGL(k_step_levels<4>, g2, dim3(1024), lds, sg, sa); break;
+                default: hipLaunchKernelGGL(k_step_levels<8>, g2, dim3(1024), lds, sg, sa); break;
+                }
+                launches += 2;
             }
-            launches += 2;
+            if (G > 1) {
+                VRT_HIP_TRY(hipEventRecord(p->step_join[gi], sg));
+                VRT_HIP_TRY(hipStreamWaitEvent(st, p->step_join[gi], 0));
+            }
         }
         VRT_HIP_TRY(hipGetLastError());
         VRT_HIP_TRY(hipEventRecord(p->ev1, st));
