@@ -241,7 +241,9 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         "bytes_per_cell_update": bytes_per_update,
         "note": "duration = HIP events around the whole sequence of sweep launches of one step "
                 "(inter-kernel gaps included; layout transposes and the J reduction are outside "
-                "it but inside ms_per_step)",
+                "it but inside ms_per_step).  On the steps path the launches run on two internal "
+                "streams and overlap, so window / launches is shorter than the per-kernel average "
+                "rocprofv3 reports (VRT_STEP_STREAMS=1 serialises them)",
     }
 
     # ---- CPU baseline: the oracle, threaded the way the reference is (angles serial, λ split
