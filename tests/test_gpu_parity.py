@@ -652,3 +652,23 @@ def test_concurrent_single_solves_on_one_handle(grids):
     for j, (k, S, I0, al, up) in enumerate(jobs):
         ref = (orc.Delaunay_upII if up else orc.Delaunay_downII)(k, S, I0, al, so, 3)
         assert _rel(out[j], ref) < RTOL
+
+
+def test_level_path_with_hipgraph_replay(grids, monkeypatch):
+    """VRT_GRAPH=1: the level-launch sequence is captured once and replayed; same results, also
+    when the buffers (hence the captured arguments) change between calls."""
+    monkeypatch.setenv("VRT_PATH", "levels")
+    monkeypatch.setenv("VRT_GRAPH", "1")
+    hs, so = grids["bcc"]
+    n = so.n
+    rng = np.random.default_rng(31)
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    for nlam in (3, 3, 5):
+        S = 1 + rng.random((n, nlam))
+        al = 1e-6 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+        I0 = rng.random((so.layers_up[1] - 1, nlam))
+        J, _ = plan.execute(S, al, weights=w, I0_up=I0)
+        assert plan.last_path == "levels"
+        assert _rel(J, orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=4)) < RTOL
+    plan.close()
