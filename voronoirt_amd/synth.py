@@ -13,7 +13,8 @@ formats the reference's `read_cell` consumes (src/voronoi_utils.jl:36-63):
                       neighbour row is shuffled (voro++ face order is arbitrary).
   G2  `voronoi_grid`  a true periodic-xy / walled-z Voronoi tessellation from
                       scipy.spatial.Delaunay with periodic and mirror image points, for the
-                      small committed parity fixtures.
+                      small committed parity fixtures; `voronoi_neighbours` does the same for
+                      GIVEN sites (in-process stand-in for the voro++ preprocessing step).
 
 Array conventions follow the reference (Julia, 1-based ids):
   positions  (n, 3) float64 C-order, columns (z, x, y)   == Julia positions[3, n]
@@ -133,35 +134,29 @@ def bcc_grid(a: int, c: int, seed: int, jitter: float = 0.05, box_xy: float = BO
     return positions, neighbours, bounds
 
 
-def voronoi_grid(n: int, seed: int, bounds=(0.0, 1.0, 0.0, 1.0, 0.0, 1.0), scale_height=None,
-                 margin: float = 0.3):
-    """G2: true Voronoi neighbour lists, periodic in x and y, walls at z_min/z_max.
-
-    Sites are uniform in x,y and either uniform in z or (scale_height = H) distributed with
-    density proportional to exp(-(z - z_min)/H), mimicking the reference's density-weighted
-    samplers (src/sample_grids.jl:223-230).
+def voronoi_neighbours(positions: np.ndarray, bounds, margin: float = 0.3, shuffle_seed: int | None = 0):
+    """Neighbour matrix of the Voronoi tessellation of GIVEN sites, periodic in x and y, walls at
+    z_min / z_max: an in-process replacement (scipy/Qhull) for the reference's preprocessing
+    step, which forks the voro++ program `output_sites` and parses its text output
+    (src/functions.jl:13-23, rt_preprocessing/output_sites.cc:35-49, src/voronoi_utils.jl:42-63).
+    positions (n, 3) columns (z, x, y) inside `bounds` = (z_min, z_max, x_min, x_max, y_min, y_max).
+    Returns the (D+1, n) matrix `read_cell` would build (row 0 = count, 1-based ids, -5 / -6 walls).
 
     Periodicity is imposed with image copies of the sites within `margin` (fraction of the box)
     of an x/y edge; the walls with mirror images across z_min / z_max: for a point set that is
     mirror-symmetric about a plane the Voronoi cells never cross the plane, so the cell of a
     site in the augmented set is exactly the wall-cut cell voro++ reports, and a Delaunay edge
-    to any bottom (top) mirror image is a face on the bottom (top) wall.
-    """
+    to any bottom (top) mirror image is a face on the bottom (top) wall.  voro++ lists the faces
+    of a cell in construction order, which is not reproducible here: rows are shuffled with
+    `shuffle_seed` (None keeps ascending ids).  `margin` must exceed a few cell diameters."""
     from scipy.spatial import Delaunay
 
-    rng = np.random.default_rng(seed)
+    base = np.ascontiguousarray(positions, dtype=np.float64)
+    n = base.shape[0]
+    rng = np.random.default_rng(shuffle_seed) if shuffle_seed is not None else None
     z_min, z_max, x_min, x_max, y_min, y_max = bounds
     Lz, Lx, Ly = z_max - z_min, x_max - x_min, y_max - y_min
-    x = x_min + rng.random(n) * Lx
-    y = y_min + rng.random(n) * Ly
-    u = rng.random(n)
-    if scale_height is None:
-        z = z_min + u * Lz
-    else:
-        H = scale_height
-        z = z_min - H * np.log(1.0 - u * (1.0 - np.exp(-Lz / H)))
-    base = np.stack([z, x, y], axis=1)
-
+    x, y = base[:, 1], base[:, 2]
     pts = [base]
     owner = [np.arange(n)]
     kind = [np.zeros(n, dtype=np.int64)]        # 0 site/periodic image, -5/-6 mirror image
@@ -216,13 +211,37 @@ def voronoi_grid(n: int, seed: int, bounds=(0.0, 1.0, 0.0, 1.0, 0.0, 1.0), scale
         if (k == TOP_WALL).any():
             ent.append(TOP_WALL)
         ent = np.array(ent, dtype=np.int64)
-        rng.shuffle(ent)
+        if rng is not None:
+            rng.shuffle(ent)
         rows.append(ent)
         D = max(D, ent.size)
     neighbours = np.zeros((D + 1, n), dtype=np.int64)
     for i, ent in enumerate(rows):
         neighbours[0, i] = ent.size
         neighbours[1:ent.size + 1, i] = ent
+    return neighbours
+
+
+def voronoi_grid(n: int, seed: int, bounds=(0.0, 1.0, 0.0, 1.0, 0.0, 1.0), scale_height=None,
+                 margin: float = 0.3):
+    """G2: random sites + their true Voronoi neighbour lists (`voronoi_neighbours`).
+
+    Sites are uniform in x,y and either uniform in z or (scale_height = H) distributed with
+    density proportional to exp(-(z - z_min)/H), mimicking the reference's density-weighted
+    samplers (src/sample_grids.jl:223-230)."""
+    rng = np.random.default_rng(seed)
+    z_min, z_max, x_min, x_max, y_min, y_max = bounds
+    Lz, Lx, Ly = z_max - z_min, x_max - x_min, y_max - y_min
+    x = x_min + rng.random(n) * Lx
+    y = y_min + rng.random(n) * Ly
+    u = rng.random(n)
+    if scale_height is None:
+        z = z_min + u * Lz
+    else:
+        H = scale_height
+        z = z_min - H * np.log(1.0 - u * (1.0 - np.exp(-Lz / H)))
+    base = np.stack([z, x, y], axis=1)
+    neighbours = voronoi_neighbours(base, bounds, margin=margin, shuffle_seed=int(rng.integers(1 << 31)))
     return np.ascontiguousarray(base), neighbours, tuple(bounds)
 
 
