@@ -672,3 +672,27 @@ def test_level_path_with_hipgraph_replay(grids, monkeypatch):
         assert plan.last_path == "levels"
         assert _rel(J, orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=4)) < RTOL
     plan.close()
+
+
+@pytest.mark.parametrize("a,c,K", [(26, 4, 2), (40, 4, 4), (52, 3, 8)])
+def test_every_sites_per_thread_variant(a, c, K, path):
+    """The LDS-tile kernels are instantiated for 2, 4 and 8 sites per thread (layers up to 2048 /
+    4096 / 8192 sites); each variant against the oracle on every path."""
+    pos, nbr, bounds = synth.bcc_grid(a, c, seed=a)
+    per_layer = 2 * a * a
+    assert (K // 2) * 1024 < per_layer <= K * 1024
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    n = so.n
+    rng = np.random.default_rng(K)
+    nlam = 3
+    S = 1 + rng.random((n, nlam))
+    al = 1e-6 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+    I0 = rng.random((so.layers_up[1] - 1, nlam))
+    w, th, ph, nq = vrt.read_quadrature("ul2n3.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    J, _ = plan.execute(S, al, weights=w, I0_up=I0)
+    assert plan.last_path == path
+    assert _rel(J, orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=4)) < RTOL
+    plan.close()
+    hs.close()
