@@ -80,9 +80,20 @@ int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site)
 }
 
 // ---- layout changes -----------------------------------------------------------------------------
+// Storage-order arrays are wavelength-major in blocks of `lb` wavelengths: element (l, p) lives at
+// ((l / lb) * n + p) * lb + l % lb.  lb = 1 (plain planes [λ][pos]) for the persistent tile
+// kernel; lb = 2 (wavelength PAIRS interleaved per site, [λ/2][pos][2]) for the layer-step
+// kernels, whose 16-byte accesses fetch two wavelengths per gathered cache line.  Planes are
+// padded to a multiple of lb wavelengths.
+__device__ __forceinline__ size_t sw_index(int l, int64_t p, int64_t n, int lb)
+{
+    return lb == 1 ? (size_t)l * (size_t)n + (size_t)p
+                   : (((size_t)(l >> 1) * (size_t)n + (size_t)p) << 1) + (size_t)(l & 1);
+}
+
 // out[l][p] = in[order[p]][l]   (caller's (nλ, n) site-major rows -> wavelength-major sweep order)
 __global__ void __launch_bounds__(256)
-k_to_sweep_order(int64_t n, int nlam, int64_t ld, const int32_t *__restrict__ order,
+k_to_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__restrict__ order,
                  const double *__restrict__ in, double *__restrict__ out)
 {
     __shared__ double tile[64][65];
@@ -101,10 +112,23 @@ k_to_sweep_order(int64_t n, int nlam, int64_t ld, const int32_t *__restrict__ or
 #pragma unroll
     for (int j = 0; j < 16; j++) tile[ty + 4 * j][tx] = v[j];
     __syncthreads();
+    if (lb == 1) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const int l = l0 + ty + 4 * j;
-        if (l < nlam && p0 + tx < n) out[(size_t)l * n + p0 + tx] = tile[tx][ty + 4 * j];
+        for (int j = 0; j < 16; j++) {
+            const int l = l0 + ty + 4 * j;
+            if (l < nlam && p0 + tx < n) out[(size_t)l * n + p0 + tx] = tile[tx][ty + 4 * j];
+        }
+    } else {                                   // one 16-byte store per (site, wavelength pair)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = 2 * (ty + 4 * j), l = l0 + c;
+            if (l < nlam && p0 + tx < n) {
+                double2 v;
+                v.x = tile[tx][c];
+                v.y = l + 1 < nlam ? tile[tx][c + 1] : 0.0;
+                reinterpret_cast<double2 *>(out)[(size_t)(l >> 1) * (size_t)n + (size_t)(p0 + tx)] = v;
+            }
+        }
     }
 }
 
@@ -119,7 +143,7 @@ k_gather_vec(int64_t n, const int32_t *__restrict__ order, const double *__restr
 
 // I[a][l][p] = I0[p][l] for p < n1 (boundary layer, already in sweep order), blockIdx.z = angle slot
 __global__ void __launch_bounds__(256)
-k_boundary_sweep_order(int64_t n, int nlam, int64_t n1, const int32_t *__restrict__ angles,
+k_boundary_sweep_order(int64_t n, int nlam, int lb, int64_t n1, const int32_t *__restrict__ angles,
                        const int32_t *__restrict__ order, const int32_t *__restrict__ srank,
                        const double *__restrict__ I0, double *__restrict__ I)
 {
@@ -133,14 +157,19 @@ k_boundary_sweep_order(int64_t n, int nlam, int64_t n1, const int32_t *__restric
         if (p < n1 && l0 + tx < nlam) tile[r][tx] = I0 ? I0[(size_t)p * nlam + l0 + tx] : 0.0;
     }
     __syncthreads();
-    double *Ia = I + (size_t)a * (size_t)nlam * (size_t)n;
+    const int nl_pad = (nlam + lb - 1) / lb * lb;
+    double *Ia = I + (size_t)a * (size_t)nl_pad * (size_t)n;
     for (int c = ty; c < 64; c += 4) {
         const int l = l0 + c;
         // I_0 is ordered like perm[1:n1] (irregular_ray_tracing.jl:33); storage is Morton order
-        if (l < nlam && p0 + tx < n1) Ia[(size_t)l * n + srank[order[p0 + tx]]] = tile[tx][c];
+        if (l < nlam && p0 + tx < n1) {
+            const int32_t pos = srank[order[p0 + tx]];
+            Ia[sw_index(l, pos, n, lb)] = tile[tx][c];
+            if (l == nlam - 1 && nl_pad > nlam) Ia[sw_index(nlam, pos, n, lb)] = 0.0;   // padding wavelength
+        }
         // the never-visited site perm[n] (storage position n-1) keeps I = 0 (voronoi_utils.jl:266)
         // -- also on a single-layer grid, where no layer kernel ever runs
-        if (blockIdx.x == 0 && tx == 0 && l < nlam) Ia[(size_t)l * n + (n - 1)] = 0.0;
+        if (blockIdx.x == 0 && tx == 0 && l < nl_pad) Ia[sw_index(l, n - 1, n, lb)] = 0.0;
     }
 }
 
@@ -387,36 +416,61 @@ k_sweep_tiles(TileArgs ta)
 // "Layer-step" variant of the same algorithm: the two phases of a layer become two chip-wide
 // launches.  k_step_coeffs has no dependencies inside a layer, so it runs at full occupancy
 // (deep memory-level parallelism for the gathers); the coefficients it leaves in a reused
-// buffer are consumed immediately by k_step_levels, one workgroup per (angle, wavelength),
+// buffer are consumed immediately by k_step_levels, one workgroup per (angle, wavelength PAIR),
 // which only does the LDS Gauss-Seidel levels.  2 launches per BFS layer instead of one per
 // dependency level.
+//
+// Every array of this path holds wavelength PAIRS side by side ([λ/2][pos][2], sw_index with
+// lb = 2): each centre read, upwind gather, coefficient store/load and intensity store is one
+// 16-byte access per lane serving two wavelengths -- half the vector-memory instructions and
+// half the cache lines touched per gathered value of the 8-byte planes (narrow global accesses
+// are issue-bound on gfx950: cdna_hip_programming.md, "under-vectorized global reads").  The
+// in-layer dependency structure (levels, tile slots) is the same for every wavelength of an
+// angle, so a level visit of the pair costs the same LDS instructions (b128) as one wavelength.
 // ---------------------------------------------------------------------------------------------
 struct StepArgs {
-    TileArgs ta;
+    TileArgs ta;              // S, alpha, I in pair layout; ta.nlam = the caller's wavelength count
+    int npair;                // ceil(nlam / 2)
     int layer;                // 1-based BFS layer being solved
-    int cg_stride;            // slots per (angle, wavelength) in the coefficient buffers
-    double *cg_c, *cg_g1, *cg_g2;   // (loc and vis are λ-independent: read from the table)
+    int cg_stride;            // slots (double2 each) per (angle, wavelength pair) in the coefficient buffers
+    double2 *cg_c, *cg_g1, *cg_g2;   // (loc and vis are λ-independent: read from the table)
     const int32_t *angle_list;      // the angles this launch works on (one stream's share)
     int n_list;
     int debug_skip_levels;    // diagnostics only (VRT_DEBUG_SKIP_LEVELS=1): wrong results
+    int debug_flags;          // diagnostics only (VRT_DEBUG_FLAGS bit mask): wrong results, see execute_tiles
 };
+
+__device__ __forceinline__ double2 ld2(const double2 *base, unsigned idx)
+{
+    return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + ((size_t)idx << 4));
+}
+
+// one upwind's share of the visit: t = ((e I_u + a S_u) + b S_c) w  (I_u dropped unless the upwind
+// lies in an earlier layer), g = e w if the upwind lies in the site's own layer
+__device__ __forceinline__ void upwind_term(double r, double w, double a_c, double a_u, double S_c,
+                                            double S_u, double I_u, bool early, bool inl, double &t,
+                                            double &g)
+{
+    double ca, cb, ce;
+    lin_weights(r * (a_c + a_u) / 2.0, ca, cb, ce);                // trapezoidal, functions.jl:393
+    t = early ? ((ce * I_u + ca * S_u) + cb * S_c) * w : (ca * S_u + cb * S_c) * w;
+    g = inl ? ce * w : 0.0;
+}
 
 // block = 256 consecutive slots (a Morton-coherent patch: the upwind gathers of neighbouring
 // slots share lines through L1) of one angle; each thread keeps its slot's upwind-table entry
-// in registers and loops over a group of kStepLam wavelengths, so the 44-byte entry is read once
-// per group instead of once per wavelength and the per-wavelength loads of the group are
-// independent (more memory-level parallelism).  Sharing the table by putting several wavelengths
-// side by side in one block (32 x 8, 64 x 4) measured slower: smaller patches lose the L1 reuse.
-// grid: x = slot chunk, y = angle * ceil(nlam / kStepLam) + wavelength group
-constexpr int kStepLam = 6;
+// in registers and loops over a group of kStepPairs wavelength pairs, so the 44-byte entry is
+// read once per group and the loads of the group's pairs are independent.
+// grid: x = slot chunk, y = angle * ceil(npair / kStepPairs) + pair group
+constexpr int kStepPairs = 3;
 
 __global__ void __launch_bounds__(256)
 k_step_coeffs(StepArgs sa)
 {
     const TileArgs &ta = sa.ta;
-    const int ngrp = (ta.nlam + kStepLam - 1) / kStepLam;
+    const int ngrp = (sa.npair + kStepPairs - 1) / kStepPairs;
     const int a = sa.angle_list[blockIdx.y / ngrp];
-    const int l0 = (blockIdx.y % ngrp) * kStepLam;
+    const int q0 = (blockIdx.y % ngrp) * kStepPairs;
     const int d = ta.angle_dir[a];
     if (sa.layer > ta.nlayers[d]) return;
     const int lo = ta.lay[d][sa.layer - 1], hi = ta.lay[d][sa.layer];
@@ -429,29 +483,42 @@ k_step_coeffs(StepArgs sa)
     const double w1 = ta.t_w1[tab + p], w2 = ta.t_w2[tab + p], r1 = ta.t_r1[tab + p], r2 = ta.t_r2[tab + p];
     const bool early1 = u1 < lo, in1 = (u1 >= lo) & (u1 < hi);
     const bool early2 = u2 < lo, in2 = (u2 >= lo) & (u2 < hi);
-    const int i1 = min(u1, lo - 1), i2 = min(u2, lo - 1);
-    const int lend = min(l0 + kStepLam, ta.nlam);
-    for (int l = l0; l < lend; l++) {
-        const double *__restrict__ S = ta.S[d] + (size_t)l * (size_t)n;
-        const double *__restrict__ Al =
-            ta.alpha_mode == VRT_ALPHA_SITE ? ta.alpha[d]
-            : ta.alpha_mode == VRT_ALPHA_SITE_LAM ? ta.alpha[d] + (size_t)l * (size_t)n
-                                                  : ta.alpha_angle + ((size_t)a * ta.nlam + l) * (size_t)n;
-        const double *I = ta.I + ((size_t)a * ta.nlam + l) * (size_t)n;
-        const double S_c = S[p], a_c = Al[p];
-        const double S_1 = S[u1], a_1 = Al[u1], S_2 = S[u2], a_2 = Al[u2];
-        const double I_1 = I[i1], I_2 = I[i2];
-        double ca, cb, ce;
-        lin_weights(r1 * (a_c + a_1) / 2.0, ca, cb, ce);
-        const double t1 = early1 ? ((ce * I_1 + ca * S_1) + cb * S_c) * w1 : (ca * S_1 + cb * S_c) * w1;
-        const double gg1 = in1 ? ce * w1 : 0.0;
-        lin_weights(r2 * (a_c + a_2) / 2.0, ca, cb, ce);
-        const double t2 = early2 ? ((ce * I_2 + ca * S_2) + cb * S_c) * w2 : (ca * S_2 + cb * S_c) * w2;
-        const double gg2 = in2 ? ce * w2 : 0.0;
-        const size_t o = ((size_t)a * ta.nlam + l) * (size_t)sa.cg_stride + (size_t)slot;
-        sa.cg_c[o] = t1 + t2;
-        sa.cg_g1[o] = gg1;
-        sa.cg_g2[o] = gg2;
+    int i1 = min(u1, lo - 1), i2 = min(u2, lo - 1);
+    const int dbg = sa.debug_flags;
+    int v1 = u1, v2 = u2;
+    if (dbg & 1) { v1 = p; v2 = p; }              // S/alpha gathers -> coalesced centre re-reads
+    if (dbg & 2) { i1 = lo - 1; i2 = lo - 1; }    // I gathers -> one broadcast address
+    const int qend = min(q0 + kStepPairs, sa.npair);
+    for (int q = q0; q < qend; q++) {
+        const double2 *__restrict__ S = reinterpret_cast<const double2 *>(ta.S[d]) + (size_t)q * (size_t)n;
+        const double2 *__restrict__ I = reinterpret_cast<const double2 *>(ta.I) + ((size_t)a * sa.npair + q) * (size_t)n;
+        double2 a_c, a_1, a_2;
+        if (ta.alpha_mode == VRT_ALPHA_SITE) {                      // one opacity per site for every λ
+            const double *__restrict__ Al = ta.alpha[d];
+            const double c0 = Al[p], c1 = Al[v1], c2 = Al[v2];
+            a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
+        } else {
+            const double2 *__restrict__ Al =
+                ta.alpha_mode == VRT_ALPHA_SITE_LAM
+                    ? reinterpret_cast<const double2 *>(ta.alpha[d]) + (size_t)q * (size_t)n
+                    : reinterpret_cast<const double2 *>(ta.alpha_angle) + ((size_t)a * sa.npair + q) * (size_t)n;
+            a_c = ld2(Al, p); a_1 = ld2(Al, v1); a_2 = ld2(Al, v2);
+        }
+        const double2 S_c = ld2(S, p), S_1 = ld2(S, v1), S_2 = ld2(S, v2);
+        const double2 I_1 = ld2(I, i1), I_2 = ld2(I, i2);
+        double2 c, g1, g2;
+        double t1, t2;
+        upwind_term(r1, w1, a_c.x, a_1.x, S_c.x, S_1.x, I_1.x, early1, in1, t1, g1.x);
+        upwind_term(r2, w2, a_c.x, a_2.x, S_c.x, S_2.x, I_2.x, early2, in2, t2, g2.x);
+        c.x = t1 + t2;
+        upwind_term(r1, w1, a_c.y, a_1.y, S_c.y, S_1.y, I_1.y, early1, in1, t1, g1.y);
+        upwind_term(r2, w2, a_c.y, a_2.y, S_c.y, S_2.y, I_2.y, early2, in2, t2, g2.y);
+        c.y = t1 + t2;
+        if ((dbg & 4) && c.x != 1.2345e300) continue;               // no coefficient stores
+        const size_t o = ((size_t)a * sa.npair + q) * (size_t)sa.cg_stride + (size_t)slot;
+        sa.cg_c[o] = c;
+        sa.cg_g1[o] = g1;
+        sa.cg_g2[o] = g2;
     }
 }
 
@@ -459,11 +526,11 @@ template <int K>
 __global__ void __launch_bounds__(1024)
 k_step_levels(StepArgs sa)
 {
-    extern __shared__ __attribute__((aligned(16))) double tile[];
+    extern __shared__ __attribute__((aligned(16))) double2 tile2[];
     const TileArgs &ta = sa.ta;
     const int T = 1024, tid = threadIdx.x;
-    const int a = sa.angle_list[blockIdx.x / ta.nlam], l = blockIdx.x % ta.nlam;
-    const int task = a * ta.nlam + l;
+    const int a = sa.angle_list[blockIdx.x / sa.npair], q = blockIdx.x % sa.npair;
+    const int task = a * sa.npair + q;
     const int d = ta.angle_dir[a];
     if (sa.layer > ta.nlayers[d]) return;
     const int lo = ta.lay[d][sa.layer - 1], hi = ta.lay[d][sa.layer];
@@ -471,31 +538,37 @@ k_step_levels(StepArgs sa)
     const int64_t n = ta.n;
     const uint32_t *__restrict__ tvis = ta.t_vis + (size_t)a * (size_t)n;
     const uint32_t *__restrict__ tloc = ta.t_loc + (size_t)a * (size_t)n;
-    double *I = ta.I + ((size_t)a * ta.nlam + l) * (size_t)n;
+    double2 *I = reinterpret_cast<double2 *>(ta.I) + (size_t)task * (size_t)n;
     const size_t o = (size_t)task * (size_t)sa.cg_stride;
-    double c[K], g1[K], g2[K];
+    double2 c[K], g1[K], g2[K];
     uint32_t loc[K], vis[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int slot = tid + k * T;
         const bool ok = slot < cnt;
         const int s = ok ? slot : cnt - 1;
-        c[k] = sa.cg_c[o + s];
-        g1[k] = sa.cg_g1[o + s];
-        g2[k] = sa.cg_g2[o + s];
+        if (sa.debug_flags & 8) {                  // no coefficient loads
+            c[k] = make_double2(1.0 + s, 2.0 + s); g1[k] = make_double2(0.25, 0.25); g2[k] = make_double2(0.125, 0.125);
+        } else {
+            c[k] = sa.cg_c[o + s];
+            g1[k] = sa.cg_g1[o + s];
+            g2[k] = sa.cg_g2[o + s];
+        }
         loc[k] = tloc[lo + s];
         vis[k] = ok ? tvis[lo + s] : 0u;
-        if (ok) tile[slot] = 0.0;                  // I = zero(S), irregular_ray_tracing.jl:23
+        if (ok) tile2[slot] = make_double2(0.0, 0.0);     // I = zero(S), irregular_ray_tracing.jl:23
     }
     __syncthreads();
     const int nl = sa.debug_skip_levels ? 0 : ta.nlev[(size_t)a * (size_t)(ta.max_layers + 1) + sa.layer];
     for (int t = 1; t <= nl; t++) {
-        // (issuing all 2K LDS reads of a level unconditionally ahead of the branches measured
-        // 19 % slower than this per-site form)
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if ((vis[k] & 0xFFu) == (uint32_t)t) {
-                tile[tid + k * T] = c[k] + g1[k] * tile[loc[k] & 0xFFFFu] + g2[k] * tile[loc[k] >> 16];
+            if ((vis[k] & 0xFFu) == (uint32_t)t) {       // a site's visits come at increasing levels
+                const double2 x = tile2[loc[k] & 0xFFFFu], y = tile2[loc[k] >> 16];
+                double2 r;
+                r.x = c[k].x + g1[k].x * x.x + g2[k].x * y.x;
+                r.y = c[k].y + g1[k].y * x.y + g2[k].y * y.y;
+                tile2[tid + k * T] = r;
                 vis[k] >>= 8;
             }
         }
@@ -504,9 +577,9 @@ k_step_levels(StepArgs sa)
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int slot = tid + k * T;
-        if (slot < cnt) I[lo + slot] = tile[slot];
+        if (slot < cnt && (!(sa.debug_flags & 16) || tile2[slot].x == 1.2345e300)) I[lo + slot] = tile2[slot];
     }
-    if (tid == 0 && sa.layer == ta.nlayers[d]) I[n - 1] = 0.0;   // never-visited site perm[n]
+    if (tid == 0 && sa.layer == ta.nlayers[d]) I[n - 1] = make_double2(0.0, 0.0);   // never-visited site perm[n]
 }
 
 // J_d[l][p] = Σ_{angles of direction d} w_a I_a[l][p], reference's angle order within the direction
@@ -530,7 +603,7 @@ k_reduce_dir(int64_t total, int64_t stride_angle, DirWeights dw, const double *_
 // J[site][l] = J_up[l][rank_up[site]] + J_down[l][rank_down[site]], walking sites in up order so
 // the J_up reads are coalesced and the J_down reads are piecewise contiguous on stratified grids.
 __global__ void __launch_bounds__(256)
-k_combine_J(int64_t n, int nlam, int64_t ldJ, const int32_t *__restrict__ order_up,
+k_combine_J(int64_t n, int nlam, int64_t ldJ, int lb, const int32_t *__restrict__ order_up,
             const int32_t *__restrict__ rank_down, const double *__restrict__ Ju,
             const double *__restrict__ Jdn, double *__restrict__ J)
 {
@@ -548,8 +621,8 @@ k_combine_J(int64_t n, int nlam, int64_t ldJ, const int32_t *__restrict__ order_
         const int l = l0 + c;
         if (l < nlam && p < n) {
             double v = 0.0;
-            if (Ju) v = Ju[(size_t)l * n + p];
-            if (Jdn) v = v + Jdn[(size_t)l * n + pd];
+            if (Ju) v = Ju[sw_index(l, p, n, lb)];
+            if (Jdn) v = v + Jdn[sw_index(l, pd, n, lb)];
             tile[tx][c] = v;
         }
     }
@@ -562,7 +635,7 @@ k_combine_J(int64_t n, int nlam, int64_t ldJ, const int32_t *__restrict__ order_
 
 // out[order[p]][l] = in[l][p]  (sweep order, wavelength-major -> caller's site-major rows)
 __global__ void __launch_bounds__(256)
-k_from_sweep_order(int64_t n, int nlam, int64_t ld, const int32_t *__restrict__ order,
+k_from_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__restrict__ order,
                    const double *__restrict__ in, double *__restrict__ out)
 {
     __shared__ double tile[64][65];
@@ -571,7 +644,7 @@ k_from_sweep_order(int64_t n, int nlam, int64_t ld, const int32_t *__restrict__ 
     const int l0 = blockIdx.y * 64;
     for (int c = ty; c < 64; c += 4) {
         const int l = l0 + c;
-        if (l < nlam && p0 + tx < n) tile[tx][c] = in ? in[(size_t)l * n + p0 + tx] : 0.0;
+        if (l < nlam && p0 + tx < n) tile[tx][c] = in ? in[sw_index(l, p0 + tx, n, lb)] : 0.0;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
@@ -690,7 +763,12 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     vrt_grid *g = p->g;
     const int64_t n = g->n;
     const int A = p->A;
-    const size_t plane = (size_t)nlam * (size_t)n;
+    const bool steps = p->last_path == 3;
+    // storage layout: wavelength pairs side by side on the layer-step path, plain planes on the
+    // persistent tile path (sw_index); planes are padded to a whole number of blocks
+    const int lb = steps ? 2 : 1;
+    const int64_t nl_pad = (nlam + lb - 1) / lb * lb;
+    const size_t plane = (size_t)nl_pad * (size_t)n;
     int rc;
     if ((rc = ensure_dev(p->d_I, p->I_cap, (size_t)std::max(1, A) * plane))) return rc;
     const bool use_dir[2] = {p->n_up > 0, p->n_down > 0};
@@ -721,7 +799,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         ta.S[d] = nullptr;
         ta.alpha[d] = nullptr;
         if (!use_dir[d]) continue;
-        hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_store, dS,
+        hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store, dS,
                            p->ws_S[d]);
         ta.S[d] = p->ws_S[d];
         if (alpha_mode == VRT_ALPHA_SITE) {
@@ -731,14 +809,14 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
             ta.alpha[d] = p->ws_A[d];
         } else if (alpha_mode == VRT_ALPHA_SITE_LAM) {
             if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], plane))) return rc;
-            hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_store,
+            hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
                                dalpha, p->ws_A[d]);
             ta.alpha[d] = p->ws_A[d];
         }
         const int cnt = d == 0 ? p->n_up : p->n_down;
         if (dir.n1 > 0) {
             const dim3 bgrid((unsigned)((dir.n1 + 63) / 64), (unsigned)((nlam + 63) / 64), (unsigned)cnt);
-            hipLaunchKernelGGL(k_boundary_sweep_order, bgrid, dim3(256), 0, st, n, (int)nlam, dir.n1,
+            hipLaunchKernelGGL(k_boundary_sweep_order, bgrid, dim3(256), 0, st, n, (int)nlam, lb, dir.n1,
                                d == 0 ? p->d_angles_up : p->d_angles_down, dir.d_order, dir.d_srank,
                                d == 0 ? dI0_up : dI0_down, p->d_I);
         }
@@ -747,7 +825,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         if ((rc = ensure_dev(p->ws_AA, p->ws_AA_cap, (size_t)A * plane))) return rc;
         for (int a = 0; a < A; a++) {
             const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-            hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_store,
+            hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
                                dalpha + (size_t)a * (size_t)n * (size_t)ld, p->ws_AA + (size_t)a * plane);
         }
         ta.alpha_angle = p->ws_AA;
@@ -757,22 +835,33 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     const bool debug = std::getenv("VRT_TILE_DEBUG") != nullptr;
     long long *d_dbg = nullptr;
     ta.dbg = nullptr;
-    const bool steps = p->last_path == 3;
     int64_t launches = 1;
     if (steps && A > 0) {
         // ---- layer-step variant: 2 launches per BFS layer -------------------------------------
         const int stride = (int)((std::max<int64_t>(p->tile_max_layer_size, 1) + 63) & ~(int64_t)63);
-        const size_t cgn = (size_t)A * (size_t)nlam * (size_t)stride;
+        const int npair = (int)(nl_pad / 2);
+        const size_t cgn = (size_t)A * (size_t)nl_pad * (size_t)stride;   // doubles: npair double2 planes
         if ((rc = ensure_dev(p->ws_cg[0], p->ws_cg_cap[0], cgn))) return rc;
         if ((rc = ensure_dev(p->ws_cg[1], p->ws_cg_cap[1], cgn))) return rc;
         if ((rc = ensure_dev(p->ws_cg[2], p->ws_cg_cap[2], cgn))) return rc;
         StepArgs sa;
         sa.ta = ta;
         sa.cg_stride = stride;
-        sa.cg_c = p->ws_cg[0]; sa.cg_g1 = p->ws_cg[1]; sa.cg_g2 = p->ws_cg[2];
+        sa.npair = npair;
+        sa.cg_c = reinterpret_cast<double2 *>(p->ws_cg[0]);
+        sa.cg_g1 = reinterpret_cast<double2 *>(p->ws_cg[1]);
+        sa.cg_g2 = reinterpret_cast<double2 *>(p->ws_cg[2]);
         sa.debug_skip_levels = std::getenv("VRT_DEBUG_SKIP_LEVELS") != nullptr;
+        // 1: S/alpha gathers off, 2: I gathers off, 4: coefficient stores off, 8: coefficient loads off,
+        // 16: I stores off
+        sa.debug_flags = std::getenv("VRT_DEBUG_FLAGS") ? std::atoi(std::getenv("VRT_DEBUG_FLAGS")) : 0;
         const int Lmax = std::max(ta.nlayers[0] * (use_dir[0] ? 1 : 0), ta.nlayers[1] * (use_dir[1] ? 1 : 0));
-        const size_t lds = (size_t)std::max<int64_t>(p->tile_max_layer_size, 1) * sizeof(double);
+        const size_t lds = (size_t)std::max<int64_t>(p->tile_max_layer_size, 1) * sizeof(double2);
+        // sites per thread of the level kernel: the fewest that cover the largest layer (its
+        // register-resident coefficients are 14 VGPRs per site); VRT_STEP_K forces more (tests)
+        int step_K = (int)((std::max<int64_t>(p->tile_max_layer_size, 1) + 1023) / 1024);
+        if (const char *e = std::getenv("VRT_STEP_K")) step_K = std::max(step_K, std::atoi(e));
+        step_K = std::max(1, std::min(step_K, 8));
         // The angles are dealt (heaviest first) to a few internal streams that advance through
         // the layers independently: the (angle, wavelength) problems of different streams share
         // nothing, so one stream's launches fill the tail of the other's (612 level workgroups
@@ -792,14 +881,19 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
             sa.angle_list = p->d_step_angles + p->step_group_off[gi];
             sa.n_list = n_list;
             const dim3 g1((unsigned)((p->tile_max_layer_size + 255) / 256),
-                          (unsigned)((size_t)n_list * (size_t)((nlam + kStepLam - 1) / kStepLam)));
-            const dim3 g2((unsigned)((size_t)n_list * (size_t)nlam));
+                          (unsigned)((size_t)n_list * (size_t)((npair + kStepPairs - 1) / kStepPairs)));
+            const dim3 g2((unsigned)((size_t)n_list * (size_t)npair));
             for (int layer = 2; layer <= Lmax; layer++) {
                 sa.layer = layer;
                 hipLaunchKernelGGL(k_step_coeffs, g1, dim3(256), 0, sg, sa);
-                switch (p->tile_K) {
+                switch (step_K) {
+                case 1: hipLaunchKernelGGL(k_step_levels<1>, g2, dim3(1024), lds, sg, sa); break;
                 case 2: hipLaunchKernelGGL(k_step_levels<2>, g2, dim3(1024), lds, sg, sa); break;
+                case 3: hipLaunchKernelGGL(k_step_levels<3>, g2, dim3(1024), lds, sg, sa); break;
                 case 4: hipLaunchKernelGGL(k_step_levels<4>, g2, dim3(1024), lds, sg, sa); break;
+                case 5: hipLaunchKernelGGL(k_step_levels<5>, g2, dim3(1024), lds, sg, sa); break;
+                case 6: hipLaunchKernelGGL(k_step_levels<6>, g2, dim3(1024), lds, sg, sa); break;
+                case 7: hipLaunchKernelGGL(k_step_levels<7>, g2, dim3(1024), lds, sg, sa); break;
                 default: hipLaunchKernelGGL(k_step_levels<8>, g2, dim3(1024), lds, sg, sa); break;
                 }
                 launches += 2;
@@ -857,7 +951,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
                                (int64_t)plane, (int64_t)plane, dw, p->d_I, p->ws_J[d]);
             Jd[d] = p->ws_J[d];
         }
-        hipLaunchKernelGGL(k_combine_J, tgrid, dim3(256), 0, st, n, (int)nlam, ld, g->up.d_store,
+        hipLaunchKernelGGL(k_combine_J, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, g->up.d_store,
                            g->down.d_srank, Jd[0], Jd[1], dJ);
         VRT_HIP_TRY(hipGetLastError());
     }
@@ -867,7 +961,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         for (int64_t u = 0; u < p->n_angles_user; u++) {
             const int a = active_of_user[(size_t)u];
             const Direction &dir = (a >= 0 && p->dir_of_active[(size_t)a] < 0) ? g->down : g->up;
-            hipLaunchKernelGGL(k_from_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, dir.d_store,
+            hipLaunchKernelGGL(k_from_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
                                a >= 0 ? p->d_I + (size_t)a * plane : nullptr,
                                dI_out + (size_t)u * (size_t)n * (size_t)ld);
         }
