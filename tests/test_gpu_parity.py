@@ -696,3 +696,54 @@ def test_every_sites_per_thread_variant(a, c, K, path):
     assert _rel(J, orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=4)) < RTOL
     plan.close()
     hs.close()
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_every_level_kernel_instantiation_of_the_step_path(grids, K, monkeypatch):
+    """k_step_levels is instantiated for 1..8 sites per thread (14 VGPRs of register-resident
+    coefficients per site and wavelength pair; K = 8 spills).  VRT_STEP_K forces a larger K than
+    the grid needs, so every instantiation runs on the small fixture; odd nlam pads a pair."""
+    monkeypatch.setenv("VRT_PATH", "steps")
+    monkeypatch.setenv("VRT_STEP_K", str(K))
+    hs, so = grids["voronoi"]
+    n = so.n
+    rng = np.random.default_rng(100 + K)
+    nlam = 5
+    S = 1 + rng.random((n, nlam))
+    al = 1e-6 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+    I0 = rng.random((so.layers_up[1] - 1, nlam))
+    w, th, ph, nq = vrt.read_quadrature("ul2n3.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    J, _ = plan.execute(S, al, weights=w, I0_up=I0)
+    assert plan.last_path == "steps"
+    assert _rel(J, orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=4)) < RTOL
+    plan.close()
+
+
+def test_step_path_thread_assignment_does_not_change_results(grids, monkeypatch):
+    """The level kernel deals a layer's sites to its threads sorted by visit pattern (wave-uniform
+    levels); the storage-order assignment (diagnostic flag 64) and every internal stream count
+    must give bit-identical J: the Gauss-Seidel order lives in the visit levels, not in who holds
+    which site."""
+    monkeypatch.setenv("VRT_PATH", "steps")
+    hs, so = grids["bcc"]
+    n = so.n
+    rng = np.random.default_rng(5)
+    nlam = 4
+    S = 1 + rng.random((n, nlam))
+    al = 1e-6 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    ks = vrt.quadrature_directions(th, ph)
+    out = []
+    for env in ({}, {"VRT_DEBUG_FLAGS": "64"}, {"VRT_STEP_STREAMS": "1"}, {"VRT_STEP_STREAMS": "3", "VRT_STEP_XCD": "0"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        plan = vrt.FormalPlan(hs, ks, 3)
+        J, _ = plan.execute(S, al, weights=w)
+        out.append(J.copy())
+        plan.close()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    assert _rel(out[0], orc.J_voronoi(w, th, ph, S, al, so, nthreads=4)) < RTOL
+    for J in out[1:]:
+        assert np.array_equal(J, out[0])

@@ -168,6 +168,9 @@ static void free_plan(vrt_plan *p)
     dev_free(p->t_w1); dev_free(p->t_w2); dev_free(p->t_r1); dev_free(p->t_r2);
     dev_free(p->t_vis);
     dev_free(p->t_loc);
+    dev_free(p->t_self);
+    dev_free(p->t_vis_s);
+    dev_free(p->t_loc_s);
     dev_free(p->d_nlev); dev_free(p->d_angle_dir); dev_free(p->d_task_map);
     for (int d = 0; d < 2; d++) { dev_free(p->ws_S[d]); dev_free(p->ws_A[d]); dev_free(p->ws_J[d]); }
     dev_free(p->ws_AA);
@@ -392,16 +395,27 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             VRT_TRY_FREE(dev_alloc(&p->t_r2, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_vis, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_loc, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_self, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_vis_s, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_loc_s, tab));
             uint32_t *d_vis_site = nullptr;
             VRT_TRY_FREE(dev_alloc(&d_vis_site, (size_t)n));
             const int maxL = (int)std::max(g->up.reduced.size(), g->down.reduced.size()) - 1;
             p->tile_max_layers = maxL;
             std::vector<int32_t> nlev((size_t)A * (size_t)(maxL + 1), 0), adir((size_t)A);
             p->angle_visits.assign((size_t)A, 0);
+            std::vector<int32_t> h_self;
             for (int a = 0; a < A; a++) {
                 hipError_t e = hipMemcpy(d_vis_site, lsched[(size_t)a].vis.data(), sizeof(uint32_t) * n,
                                          hipMemcpyHostToDevice);
                 int rc2 = e == hipSuccess ? launch_permute_table(p, a, d_vis_site) : VRT_ENODEVICE;
+                if (!rc2) {     // sorted thread assignment of the layer-step level kernel
+                    const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
+                    build_sorted_slots(dir, n, lsched[(size_t)a].vis, h_self);
+                    if (hipMemcpy(p->t_self + (size_t)a * n, h_self.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice) != hipSuccess)
+                        rc2 = VRT_ENODEVICE;
+                    if (!rc2) rc2 = launch_sorted_tables(p, a);
+                }
                 if (!rc2 && hipStreamSynchronize(g->stream) != hipSuccess) rc2 = VRT_ENODEVICE;
                 if (rc2) {
                     dev_free(d_vis_site);

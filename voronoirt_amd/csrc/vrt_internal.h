@@ -120,6 +120,9 @@ struct vrt_plan {
     int32_t *t_u1 = nullptr, *t_u2 = nullptr;
     double *t_w1 = nullptr, *t_w2 = nullptr, *t_r1 = nullptr, *t_r2 = nullptr;
     uint32_t *t_vis = nullptr, *t_loc = nullptr;
+    // layer-step level kernel: sites of a layer dealt to threads sorted by visit pattern
+    int32_t *t_self = nullptr;           // [A][n] sorted index (absolute) -> storage position
+    uint32_t *t_vis_s = nullptr, *t_loc_s = nullptr;   // t_vis / t_loc in sorted order
     int32_t *d_nlev = nullptr, *d_angle_dir = nullptr;
     std::vector<int64_t> angle_visits;   // surviving visits per active angle (task cost)
     std::vector<int32_t> h_task_map;     // block -> angle | wavelength << 8
@@ -180,6 +183,8 @@ struct LayerSchedule {
 };
 void build_layer_schedule(const Direction &dir, bool ascending, int64_t n, int n_sweeps,
                           const int32_t *up1, const int32_t *up2, LayerSchedule &out);
+void build_sorted_slots(const Direction &dir, int64_t n, const std::vector<uint32_t> &vis_site,
+                        std::vector<int32_t> &self);
 
 // ---- device launchers (vrt_kernels.hip) ------------------------------------------------------
 int launch_delaunay_lines(vrt_grid *g);
@@ -204,6 +209,7 @@ int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, 
 
 // ---- layer-tile path (vrt_tiles.hip) ----------------------------------------------------------
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
+int launch_sorted_tables(vrt_plan *p, int a);
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const double *dalpha,
                   int alpha_mode, const double *dI0_up, const double *dI0_down,
                   const double *weights_user, double *dJ, double *dI_out, hipStream_t st);

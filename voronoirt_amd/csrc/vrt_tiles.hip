@@ -79,6 +79,29 @@ int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site)
     return VRT_OK;
 }
 
+// visit levels and tile slots in the sorted thread order of k_step_levels (build_sorted_slots)
+__global__ void __launch_bounds__(256)
+k_sorted_tables(int64_t n, const int32_t *__restrict__ self, const uint32_t *__restrict__ t_vis,
+                const uint32_t *__restrict__ t_loc, uint32_t *__restrict__ vis_s, uint32_t *__restrict__ loc_s)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = self[i];
+    vis_s[i] = t_vis[p];
+    loc_s[i] = t_loc[p];
+}
+
+int launch_sorted_tables(vrt_plan *p, int a)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const size_t o = (size_t)a * (size_t)n;
+    hipLaunchKernelGGL(k_sorted_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g->stream, n,
+                       p->t_self + o, p->t_vis + o, p->t_loc + o, p->t_vis_s + o, p->t_loc_s + o);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 // ---- layout changes -----------------------------------------------------------------------------
 // Storage-order arrays are wavelength-major in blocks of `lb` wavelengths: element (l, p) lives at
 // ((l / lb) * n + p) * lb + l % lb.  lb = 1 (plain planes [λ][pos]) for the persistent tile
@@ -256,6 +279,8 @@ struct TileArgs {
     const double *t_w1, *t_w2, *t_r1, *t_r2;
     const uint32_t *t_vis;
     const uint32_t *t_loc;          // [A][n] packed in-layer tile slots of the two upwinds
+    const int32_t *t_self;          // [A][n] sorted thread order of k_step_levels (build_sorted_slots)
+    const uint32_t *t_vis_s, *t_loc_s;
     const double *S[2];             // per direction [nlam][n]
     const double *alpha[2];         // SITE: [n]; SITE_LAM: [nlam][n] per direction
     const double *alpha_angle;      // ANGLE: [A][nlam][n]
@@ -436,6 +461,9 @@ struct StepArgs {
     double2 *cg_c, *cg_g1, *cg_g2;   // (loc and vis are λ-independent: read from the table)
     const int32_t *angle_list;      // the angles this launch works on (one stream's share)
     int n_list;
+    int pairs_per_thread;     // wavelength pairs one k_step_coeffs thread loops over
+    int chunks;               // 256-slot chunks per layer (k_step_coeffs grid.x / 1)
+    int xcd_map;              // 1: deal contiguous chunk ranges to the XCDs
     int debug_skip_levels;    // diagnostics only (VRT_DEBUG_SKIP_LEVELS=1): wrong results
     int debug_flags;          // diagnostics only (VRT_DEBUG_FLAGS bit mask): wrong results, see execute_tiles
 };
@@ -449,9 +477,11 @@ __device__ __forceinline__ double2 ld2(const double2 *base, unsigned idx)
 // lies in an earlier layer), g = e w if the upwind lies in the site's own layer
 __device__ __forceinline__ void upwind_term(double r, double w, double a_c, double a_u, double S_c,
                                             double S_u, double I_u, bool early, bool inl, double &t,
-                                            double &g)
+                                            double &g, bool cheap = false)
 {
     double ca, cb, ce;
+    if (cheap) { ca = a_c; cb = a_u; ce = r; }                     // diagnostics: no linear_weights
+    else
     lin_weights(r * (a_c + a_u) / 2.0, ca, cb, ce);                // trapezoidal, functions.jl:393
     t = early ? ((ce * I_u + ca * S_u) + cb * S_c) * w : (ca * S_u + cb * S_c) * w;
     g = inl ? ce * w : 0.0;
@@ -462,19 +492,37 @@ __device__ __forceinline__ void upwind_term(double r, double w, double a_c, doub
 // in registers and loops over a group of kStepPairs wavelength pairs, so the 44-byte entry is
 // read once per group and the loads of the group's pairs are independent.
 // grid: x = slot chunk, y = angle * ceil(npair / kStepPairs) + pair group
-constexpr int kStepPairs = 3;
+constexpr int kStepPairs = 3;   // default pairs per thread (VRT_STEP_PAIRS overrides)
 
 __global__ void __launch_bounds__(256)
 k_step_coeffs(StepArgs sa)
 {
     const TileArgs &ta = sa.ta;
-    const int ngrp = (sa.npair + kStepPairs - 1) / kStepPairs;
-    const int a = sa.angle_list[blockIdx.y / ngrp];
-    const int q0 = (blockIdx.y % ngrp) * kStepPairs;
+    const int ppt = sa.pairs_per_thread;
+    const int ngrp = (sa.npair + ppt - 1) / ppt;
+    // 1-D grid of chunks x (angle, pair group).  Workgroups are dealt round-robin to the 8 XCDs
+    // (block b and b + 8 share one: MI355X_MICROARCH.md, speed only), so with xcd_map each XCD
+    // takes a contiguous range of a layer's chunks for every (angle, pair group): neighbouring
+    // Morton patches share their boundary gather lines, and the pair groups of an angle their
+    // table entries, through that XCD's L2.
+    int chunk, grp;
+    if (sa.xcd_map) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int c0 = (sa.chunks * x) >> 3, c1 = (sa.chunks * (x + 1)) >> 3, cx = c1 - c0;
+        if (cx == 0) return;
+        grp = j / cx;
+        chunk = c0 + j % cx;
+        if (grp >= sa.n_list * ngrp) return;
+    } else {
+        chunk = blockIdx.x % sa.chunks;
+        grp = blockIdx.x / sa.chunks;
+    }
+    const int a = sa.angle_list[grp / ngrp];
+    const int q0 = (grp % ngrp) * ppt;
     const int d = ta.angle_dir[a];
     if (sa.layer > ta.nlayers[d]) return;
     const int lo = ta.lay[d][sa.layer - 1], hi = ta.lay[d][sa.layer];
-    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int slot = chunk * 256 + threadIdx.x;
     if (slot >= hi - lo) return;
     const int64_t n = ta.n;
     const size_t tab = (size_t)a * (size_t)n;
@@ -488,37 +536,51 @@ k_step_coeffs(StepArgs sa)
     int v1 = u1, v2 = u2;
     if (dbg & 1) { v1 = p; v2 = p; }              // S/alpha gathers -> coalesced centre re-reads
     if (dbg & 2) { i1 = lo - 1; i2 = lo - 1; }    // I gathers -> one broadcast address
-    const int qend = min(q0 + kStepPairs, sa.npair);
-    for (int q = q0; q < qend; q++) {
+    const int qend = min(q0 + ppt, sa.npair);
+    struct PairIn { double2 a_c, a_1, a_2, S_c, S_1, S_2, I_1, I_2; };
+    auto load_pair = [&](int q) {
+        PairIn in;
         const double2 *__restrict__ S = reinterpret_cast<const double2 *>(ta.S[d]) + (size_t)q * (size_t)n;
         const double2 *__restrict__ I = reinterpret_cast<const double2 *>(ta.I) + ((size_t)a * sa.npair + q) * (size_t)n;
-        double2 a_c, a_1, a_2;
         if (ta.alpha_mode == VRT_ALPHA_SITE) {                      // one opacity per site for every λ
             const double *__restrict__ Al = ta.alpha[d];
             const double c0 = Al[p], c1 = Al[v1], c2 = Al[v2];
-            a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
+            in.a_c = make_double2(c0, c0); in.a_1 = make_double2(c1, c1); in.a_2 = make_double2(c2, c2);
         } else {
             const double2 *__restrict__ Al =
                 ta.alpha_mode == VRT_ALPHA_SITE_LAM
                     ? reinterpret_cast<const double2 *>(ta.alpha[d]) + (size_t)q * (size_t)n
                     : reinterpret_cast<const double2 *>(ta.alpha_angle) + ((size_t)a * sa.npair + q) * (size_t)n;
-            a_c = ld2(Al, p); a_1 = ld2(Al, v1); a_2 = ld2(Al, v2);
+            in.a_c = ld2(Al, p); in.a_1 = ld2(Al, v1); in.a_2 = ld2(Al, v2);
         }
-        const double2 S_c = ld2(S, p), S_1 = ld2(S, v1), S_2 = ld2(S, v2);
-        const double2 I_1 = ld2(I, i1), I_2 = ld2(I, i2);
+        in.S_c = ld2(S, p); in.S_1 = ld2(S, v1); in.S_2 = ld2(S, v2);
+        in.I_1 = ld2(I, i1); in.I_2 = ld2(I, i2);
+        return in;
+    };
+    // software pipeline over the thread's pairs: the 8 loads of pair q + 1 are in flight while pair q
+    // is computed (VRT_DEBUG_FLAGS & 128 switches the prefetch off)
+    const bool prefetch = !(dbg & 128);
+    PairIn cur = load_pair(q0);
+    for (int q = q0; q < qend; q++) {
+        PairIn nxt = cur;
+        if (prefetch && q + 1 < qend) nxt = load_pair(q + 1);
         double2 c, g1, g2;
         double t1, t2;
-        upwind_term(r1, w1, a_c.x, a_1.x, S_c.x, S_1.x, I_1.x, early1, in1, t1, g1.x);
-        upwind_term(r2, w2, a_c.x, a_2.x, S_c.x, S_2.x, I_2.x, early2, in2, t2, g2.x);
+        const bool cheap = dbg & 32;
+        upwind_term(r1, w1, cur.a_c.x, cur.a_1.x, cur.S_c.x, cur.S_1.x, cur.I_1.x, early1, in1, t1, g1.x, cheap);
+        upwind_term(r2, w2, cur.a_c.x, cur.a_2.x, cur.S_c.x, cur.S_2.x, cur.I_2.x, early2, in2, t2, g2.x, cheap);
         c.x = t1 + t2;
-        upwind_term(r1, w1, a_c.y, a_1.y, S_c.y, S_1.y, I_1.y, early1, in1, t1, g1.y);
-        upwind_term(r2, w2, a_c.y, a_2.y, S_c.y, S_2.y, I_2.y, early2, in2, t2, g2.y);
+        upwind_term(r1, w1, cur.a_c.y, cur.a_1.y, cur.S_c.y, cur.S_1.y, cur.I_1.y, early1, in1, t1, g1.y, cheap);
+        upwind_term(r2, w2, cur.a_c.y, cur.a_2.y, cur.S_c.y, cur.S_2.y, cur.I_2.y, early2, in2, t2, g2.y, cheap);
         c.y = t1 + t2;
-        if ((dbg & 4) && c.x != 1.2345e300) continue;               // no coefficient stores
-        const size_t o = ((size_t)a * sa.npair + q) * (size_t)sa.cg_stride + (size_t)slot;
-        sa.cg_c[o] = c;
-        sa.cg_g1[o] = g1;
-        sa.cg_g2[o] = g2;
+        if (!((dbg & 4) && c.x != 1.2345e300)) {                    // (dbg & 4: no coefficient stores)
+            const size_t o = ((size_t)a * sa.npair + q) * (size_t)sa.cg_stride + (size_t)slot;
+            sa.cg_c[o] = c;
+            sa.cg_g1[o] = g1;
+            sa.cg_g2[o] = g2;
+        }
+        if (!prefetch && q + 1 < qend) nxt = load_pair(q + 1);
+        cur = nxt;
     }
 }
 
@@ -536,28 +598,57 @@ k_step_levels(StepArgs sa)
     const int lo = ta.lay[d][sa.layer - 1], hi = ta.lay[d][sa.layer];
     const int cnt = hi - lo;
     const int64_t n = ta.n;
-    const uint32_t *__restrict__ tvis = ta.t_vis + (size_t)a * (size_t)n;
-    const uint32_t *__restrict__ tloc = ta.t_loc + (size_t)a * (size_t)n;
+    const size_t tab = (size_t)a * (size_t)n;
+    const uint32_t *__restrict__ tvis = ta.t_vis_s + tab;
+    const uint32_t *__restrict__ tloc = ta.t_loc_s + tab;
+    const int32_t *__restrict__ tself = ta.t_self + tab;
     double2 *I = reinterpret_cast<double2 *>(ta.I) + (size_t)task * (size_t)n;
     const size_t o = (size_t)task * (size_t)sa.cg_stride;
     double2 c[K], g1[K], g2[K];
-    uint32_t loc[K], vis[K];
+    uint32_t loc[K], vis[K], self[K];   // self: storage slot of the sorted entry this thread owns
+    // coefficients arrive in storage order (coalesced 16-byte loads) ...
+    const bool sorted = !(sa.debug_flags & 64);
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int slot = tid + k * T;
-        const bool ok = slot < cnt;
-        const int s = ok ? slot : cnt - 1;
+        const int i = tid + k * T;
+        const bool ok = i < cnt;
+        const int ii = ok ? i : cnt - 1;
         if (sa.debug_flags & 8) {                  // no coefficient loads
-            c[k] = make_double2(1.0 + s, 2.0 + s); g1[k] = make_double2(0.25, 0.25); g2[k] = make_double2(0.125, 0.125);
+            c[k] = make_double2(1.0 + ii, 2.0 + ii); g1[k] = make_double2(0.25, 0.25); g2[k] = make_double2(0.125, 0.125);
         } else {
-            c[k] = sa.cg_c[o + s];
-            g1[k] = sa.cg_g1[o + s];
-            g2[k] = sa.cg_g2[o + s];
+            c[k] = sa.cg_c[o + ii];
+            g1[k] = sa.cg_g1[o + ii];
+            g2[k] = sa.cg_g2[o + ii];
         }
-        loc[k] = tloc[lo + s];
-        vis[k] = ok ? tvis[lo + s] : 0u;
-        if (ok) tile2[slot] = make_double2(0.0, 0.0);     // I = zero(S), irregular_ray_tracing.jl:23
+        if (sorted) {
+            self[k] = (uint32_t)(tself[lo + ii] - lo);
+            loc[k] = tloc[lo + ii];
+            vis[k] = ok ? tvis[lo + ii] : 0u;
+        } else {                                   // diagnostics (VRT_DEBUG_FLAGS & 64): storage-order assignment
+            self[k] = (uint32_t)ii;
+            loc[k] = ta.t_loc[tab + lo + ii];
+            vis[k] = ok ? ta.t_vis[tab + lo + ii] : 0u;
+        }
     }
+    // ... and are dealt to the threads in visit-pattern order through the (still unused) tile:
+    // written at their storage slot (consecutive, conflict-free), read back at the slot of the
+    // sorted entry tid + k T this thread owns, whose visit levels are nearly wave-uniform
+    if (sorted) {
+#pragma unroll
+        for (int arr = 0; arr < 3; arr++) {
+            double2 *v = arr == 0 ? c : arr == 1 ? g1 : g2;
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (tid + k * T < cnt) tile2[tid + k * T] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < K; k++) v[k] = tile2[self[k]];
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        if (tid + k * T < cnt) tile2[tid + k * T] = make_double2(0.0, 0.0);   // I = zero(S), irregular_ray_tracing.jl:23
     __syncthreads();
     const int nl = sa.debug_skip_levels ? 0 : ta.nlev[(size_t)a * (size_t)(ta.max_layers + 1) + sa.layer];
     for (int t = 1; t <= nl; t++) {
@@ -568,7 +659,7 @@ k_step_levels(StepArgs sa)
                 double2 r;
                 r.x = c[k].x + g1[k].x * x.x + g2[k].x * y.x;
                 r.y = c[k].y + g1[k].y * x.y + g2[k].y * y.y;
-                tile2[tid + k * T] = r;
+                tile2[self[k]] = r;
                 vis[k] >>= 8;
             }
         }
@@ -790,6 +881,8 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     ta.t_w1 = p->t_w1; ta.t_w2 = p->t_w2; ta.t_r1 = p->t_r1; ta.t_r2 = p->t_r2;
     ta.t_vis = p->t_vis;
     ta.t_loc = p->t_loc;
+    ta.t_self = p->t_self;
+    ta.t_vis_s = p->t_vis_s; ta.t_loc_s = p->t_loc_s;
     ta.alpha_angle = nullptr;
     ta.I = p->d_I;
     for (int d = 0; d < 2; d++) {
@@ -851,9 +944,12 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         sa.cg_c = reinterpret_cast<double2 *>(p->ws_cg[0]);
         sa.cg_g1 = reinterpret_cast<double2 *>(p->ws_cg[1]);
         sa.cg_g2 = reinterpret_cast<double2 *>(p->ws_cg[2]);
+        sa.pairs_per_thread = std::getenv("VRT_STEP_PAIRS") ? std::max(1, std::atoi(std::getenv("VRT_STEP_PAIRS"))) : kStepPairs;
+        sa.chunks = (int)((p->tile_max_layer_size + 255) / 256);
+        sa.xcd_map = std::getenv("VRT_STEP_XCD") ? std::atoi(std::getenv("VRT_STEP_XCD")) : 1;
         sa.debug_skip_levels = std::getenv("VRT_DEBUG_SKIP_LEVELS") != nullptr;
         // 1: S/alpha gathers off, 2: I gathers off, 4: coefficient stores off, 8: coefficient loads off,
-        // 16: I stores off
+        // 16: I stores off, 32: no linear_weights arithmetic, 64: level kernel keeps the storage-order thread assignment
         sa.debug_flags = std::getenv("VRT_DEBUG_FLAGS") ? std::atoi(std::getenv("VRT_DEBUG_FLAGS")) : 0;
         const int Lmax = std::max(ta.nlayers[0] * (use_dir[0] ? 1 : 0), ta.nlayers[1] * (use_dir[1] ? 1 : 0));
         const size_t lds = (size_t)std::max<int64_t>(p->tile_max_layer_size, 1) * sizeof(double2);
@@ -880,8 +976,9 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
             if (n_list == 0) continue;
             sa.angle_list = p->d_step_angles + p->step_group_off[gi];
             sa.n_list = n_list;
-            const dim3 g1((unsigned)((p->tile_max_layer_size + 255) / 256),
-                          (unsigned)((size_t)n_list * (size_t)((npair + kStepPairs - 1) / kStepPairs)));
+            const int ngrp = (npair + sa.pairs_per_thread - 1) / sa.pairs_per_thread;
+            const int per_xcd = (sa.chunks + 7) / 8;     // largest chunk range of an XCD
+            const dim3 g1(sa.xcd_map ? (unsigned)(8 * per_xcd * n_list * ngrp) : (unsigned)(sa.chunks * n_list * ngrp));
             const dim3 g2((unsigned)((size_t)n_list * (size_t)npair));
             for (int layer = 2; layer <= Lmax; layer++) {
                 sa.layer = layer;
