@@ -171,6 +171,7 @@ static void free_plan(vrt_plan *p)
     dev_free(p->t_self);
     dev_free(p->t_vis_s);
     dev_free(p->t_loc_s);
+    dev_free(p->t_gpos);
     dev_free(p->d_nlev); dev_free(p->d_angle_dir); dev_free(p->d_task_map);
     for (int d = 0; d < 2; d++) { dev_free(p->ws_S[d]); dev_free(p->ws_A[d]); dev_free(p->ws_J[d]); }
     dev_free(p->ws_AA);
@@ -398,6 +399,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             VRT_TRY_FREE(dev_alloc(&p->t_self, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_vis_s, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_loc_s, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_gpos, tab));
             uint32_t *d_vis_site = nullptr;
             VRT_TRY_FREE(dev_alloc(&d_vis_site, (size_t)n));
             const int maxL = (int)std::max(g->up.reduced.size(), g->down.reduced.size()) - 1;
@@ -415,6 +417,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                     if (hipMemcpy(p->t_self + (size_t)a * n, h_self.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice) != hipSuccess)
                         rc2 = VRT_ENODEVICE;
                     if (!rc2) rc2 = launch_sorted_tables(p, a);
+                    if (!rc2) rc2 = launch_gpos(p, a);
                 }
                 if (!rc2 && hipStreamSynchronize(g->stream) != hipSuccess) rc2 = VRT_ENODEVICE;
                 if (rc2) {

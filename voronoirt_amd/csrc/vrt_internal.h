@@ -123,6 +123,7 @@ struct vrt_plan {
     // layer-step level kernel: sites of a layer dealt to threads sorted by visit pattern
     int32_t *t_self = nullptr;           // [A][n] sorted index (absolute) -> storage position
     uint32_t *t_vis_s = nullptr, *t_loc_s = nullptr;   // t_vis / t_loc in sorted order
+    uint32_t *t_gpos = nullptr;          // [A][n] compact in-layer coupling list (k_gpos)
     int32_t *d_nlev = nullptr, *d_angle_dir = nullptr;
     std::vector<int64_t> angle_visits;   // surviving visits per active angle (task cost)
     std::vector<int32_t> h_task_map;     // block -> angle | wavelength << 8
@@ -210,6 +211,7 @@ int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, 
 // ---- layer-tile path (vrt_tiles.hip) ----------------------------------------------------------
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
 int launch_sorted_tables(vrt_plan *p, int a);
+int launch_gpos(vrt_plan *p, int a);
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const double *dalpha,
                   int alpha_mode, const double *dI0_up, const double *dI0_down,
                   const double *weights_user, double *dJ, double *dI_out, hipStream_t st);

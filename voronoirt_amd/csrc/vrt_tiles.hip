@@ -102,6 +102,68 @@ int launch_sorted_tables(vrt_plan *p, int a)
     return VRT_OK;
 }
 
+// Compact list of the in-layer couplings of a layer.  g_r = e_r w_r is nonzero only when upwind r
+// lies in the site's own layer (C4: 1.17 of the 2 per site on average), so the layer-step
+// kernels exchange the couplings as a dense list per (angle, wavelength pair, layer):
+//   t_gpos[a][p] = position of the site's first in-layer coupling in that list (exclusive prefix
+//                  count over the layer's storage order) | in1 << 30 | in2 << 31
+// one workgroup per (layer, angle); a thread scans 8 consecutive slots (layers <= 8192 sites).
+__global__ void __launch_bounds__(1024)
+k_gpos(int64_t n, const int32_t *__restrict__ lay, int nlayers, const int32_t *__restrict__ t_u1,
+       const int32_t *__restrict__ t_u2, uint32_t *__restrict__ gpos)
+{
+    __shared__ int part[1024];
+    const int layer = blockIdx.x + 1;              // 1-based; layer 1 (boundary) has no visits
+    if (layer > nlayers) return;
+    const int lo = lay[layer - 1], hi = lay[layer], cnt = hi - lo;
+    const int tid = threadIdx.x;
+    uint32_t fl[8];
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int s = tid * 8 + j;
+        fl[j] = 0;
+        if (s < cnt) {
+            const int u1 = t_u1[lo + s], u2 = t_u2[lo + s];
+            const uint32_t in1 = (u1 >= lo) & (u1 < hi), in2 = (u2 >= lo) & (u2 < hi);
+            fl[j] = in1 | (in2 << 1);
+            sum += (int)(in1 + in2);
+        }
+    }
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {     // inclusive Hillis-Steele scan of the thread sums
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - sum;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int s = tid * 8 + j;
+        if (s < cnt) {
+            gpos[lo + s] = (uint32_t)pos | (fl[j] << 30);
+            pos += (int)((fl[j] & 1u) + (fl[j] >> 1));
+        }
+    }
+}
+
+int launch_gpos(vrt_plan *p, int a)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
+    const size_t o = (size_t)a * (size_t)n;
+    const int nlayers = (int)dir.reduced.size() - 1;
+    VRT_HIP_TRY(hipMemsetAsync(p->t_gpos + o, 0, sizeof(uint32_t) * (size_t)n, g->stream));
+    if (nlayers >= 1)
+        hipLaunchKernelGGL(k_gpos, dim3((unsigned)nlayers), dim3(1024), 0, g->stream, n, dir.d_lay, nlayers,
+                           p->t_u1 + o, p->t_u2 + o, p->t_gpos + o);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 // ---- layout changes -----------------------------------------------------------------------------
 // Storage-order arrays are wavelength-major in blocks of `lb` wavelengths: element (l, p) lives at
 // ((l / lb) * n + p) * lb + l % lb.  lb = 1 (plain planes [λ][pos]) for the persistent tile
@@ -281,6 +343,7 @@ struct TileArgs {
     const uint32_t *t_loc;          // [A][n] packed in-layer tile slots of the two upwinds
     const int32_t *t_self;          // [A][n] sorted thread order of k_step_levels (build_sorted_slots)
     const uint32_t *t_vis_s, *t_loc_s;
+    const uint32_t *t_gpos;         // [A][n] compact in-layer coupling list positions (k_gpos)
     const double *S[2];             // per direction [nlam][n]
     const double *alpha[2];         // SITE: [n]; SITE_LAM: [nlam][n] per direction
     const double *alpha_angle;      // ANGLE: [A][nlam][n]
@@ -458,7 +521,8 @@ struct StepArgs {
     int npair;                // ceil(nlam / 2)
     int layer;                // 1-based BFS layer being solved
     int cg_stride;            // slots (double2 each) per (angle, wavelength pair) in the coefficient buffers
-    double2 *cg_c, *cg_g1, *cg_g2;   // (loc and vis are λ-independent: read from the table)
+    double2 *cg_c;            // constant terms, cg_stride per (angle, pair)
+    double2 *cg_g;            // in-layer couplings, compact list (t_gpos), 2 cg_stride per (angle, pair)
     const int32_t *angle_list;      // the angles this launch works on (one stream's share)
     int n_list;
     int pairs_per_thread;     // wavelength pairs one k_step_coeffs thread loops over
@@ -529,8 +593,9 @@ k_step_coeffs(StepArgs sa)
     const int p = lo + slot;
     const int u1 = ta.t_u1[tab + p], u2 = ta.t_u2[tab + p];
     const double w1 = ta.t_w1[tab + p], w2 = ta.t_w2[tab + p], r1 = ta.t_r1[tab + p], r2 = ta.t_r2[tab + p];
-    const bool early1 = u1 < lo, in1 = (u1 >= lo) & (u1 < hi);
-    const bool early2 = u2 < lo, in2 = (u2 >= lo) & (u2 < hi);
+    const uint32_t gp = ta.t_gpos[tab + p];
+    const bool early1 = u1 < lo, in1 = (gp >> 30) & 1u;      // in = upwind inside [lo, hi)
+    const bool early2 = u2 < lo, in2 = gp >> 31;
     int i1 = min(u1, lo - 1), i2 = min(u2, lo - 1);
     const int dbg = sa.debug_flags;
     int v1 = u1, v2 = u2;
@@ -576,8 +641,9 @@ k_step_coeffs(StepArgs sa)
         if (!((dbg & 4) && c.x != 1.2345e300)) {                    // (dbg & 4: no coefficient stores)
             const size_t o = ((size_t)a * sa.npair + q) * (size_t)sa.cg_stride + (size_t)slot;
             sa.cg_c[o] = c;
-            sa.cg_g1[o] = g1;
-            sa.cg_g2[o] = g2;
+            double2 *gl = sa.cg_g + 2 * (o - (size_t)slot) + (gp & 0xFFFFu);
+            if (in1) gl[0] = g1;
+            if (in2) gl[in1 ? 1 : 0] = g2;
         }
         if (!prefetch && q + 1 < qend) nxt = load_pair(q + 1);
         cur = nxt;
@@ -617,8 +683,11 @@ k_step_levels(StepArgs sa)
             c[k] = make_double2(1.0 + ii, 2.0 + ii); g1[k] = make_double2(0.25, 0.25); g2[k] = make_double2(0.125, 0.125);
         } else {
             c[k] = sa.cg_c[o + ii];
-            g1[k] = sa.cg_g1[o + ii];
-            g2[k] = sa.cg_g2[o + ii];
+            const uint32_t gp = ta.t_gpos[tab + lo + ii];
+            const double2 *gl = sa.cg_g + 2 * o + (gp & 0xFFFFu);
+            const bool in1 = (gp >> 30) & 1u, in2 = gp >> 31;
+            g1[k] = in1 ? gl[0] : make_double2(0.0, 0.0);
+            g2[k] = in2 ? gl[in1 ? 1 : 0] : make_double2(0.0, 0.0);
         }
         if (sorted) {
             self[k] = (uint32_t)(tself[lo + ii] - lo);
@@ -883,6 +952,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     ta.t_loc = p->t_loc;
     ta.t_self = p->t_self;
     ta.t_vis_s = p->t_vis_s; ta.t_loc_s = p->t_loc_s;
+    ta.t_gpos = p->t_gpos;
     ta.alpha_angle = nullptr;
     ta.I = p->d_I;
     for (int d = 0; d < 2; d++) {
@@ -935,15 +1005,13 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         const int npair = (int)(nl_pad / 2);
         const size_t cgn = (size_t)A * (size_t)nl_pad * (size_t)stride;   // doubles: npair double2 planes
         if ((rc = ensure_dev(p->ws_cg[0], p->ws_cg_cap[0], cgn))) return rc;
-        if ((rc = ensure_dev(p->ws_cg[1], p->ws_cg_cap[1], cgn))) return rc;
-        if ((rc = ensure_dev(p->ws_cg[2], p->ws_cg_cap[2], cgn))) return rc;
+        if ((rc = ensure_dev(p->ws_cg[1], p->ws_cg_cap[1], 2 * cgn))) return rc;
         StepArgs sa;
         sa.ta = ta;
         sa.cg_stride = stride;
         sa.npair = npair;
         sa.cg_c = reinterpret_cast<double2 *>(p->ws_cg[0]);
-        sa.cg_g1 = reinterpret_cast<double2 *>(p->ws_cg[1]);
-        sa.cg_g2 = reinterpret_cast<double2 *>(p->ws_cg[2]);
+        sa.cg_g = reinterpret_cast<double2 *>(p->ws_cg[1]);
         sa.pairs_per_thread = std::getenv("VRT_STEP_PAIRS") ? std::max(1, std::atoi(std::getenv("VRT_STEP_PAIRS"))) : kStepPairs;
         sa.chunks = (int)((p->tile_max_layer_size + 255) / 256);
         sa.xcd_map = std::getenv("VRT_STEP_XCD") ? std::atoi(std::getenv("VRT_STEP_XCD")) : 1;
