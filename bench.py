@@ -223,6 +223,20 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         },
         "setup_s": {"grid_generate": t_gen, "grid_create": t_grid, "plan_create": t_plan},
     }
+    # practical ceiling of this box beside the vendor peak: a device triad b = a + b
+    # over 2 x 1 GB (2 reads + 1 write per element), measured live
+    triad_gbs = None
+    if rank == 0 and world == 1:
+        ta_ = torch.rand(1 << 27, device=dev, dtype=torch.float64)
+        tb_ = torch.rand(1 << 27, device=dev, dtype=torch.float64)
+        torch.add(ta_, tb_, out=tb_)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            torch.add(ta_, tb_, out=tb_)
+        torch.cuda.synchronize()
+        triad_gbs = 10 * 3 * ta_.numel() * 8 / (time.perf_counter() - t0) / 1e9
+        del ta_, tb_
     # roofline of the dominant kernel (k_sweep_level): algorithmic bytes / event-timed duration
     bytes_per_update = (20.0 if f32 else 40.0) + 40.0 / nlam
     local_updates = n * A * nlam
@@ -239,6 +253,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         "sweep_ms_per_step": sweep_ms, "avg_launch_us": sweep_ms * 1e3 / max(launches, 1),
         "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
         "bytes_per_cell_update": bytes_per_update,
+        "triad_ceiling_GBs": triad_gbs,
         "note": "duration = HIP events around the whole sequence of sweep launches of one step "
                 "(inter-kernel gaps included; layout transposes and the J reduction are outside "
                 "it but inside ms_per_step).  On the steps path the launches run on two internal "

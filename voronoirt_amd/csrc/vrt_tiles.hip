@@ -527,7 +527,7 @@ struct StepArgs {
     int n_list;
     int pairs_per_thread;     // wavelength pairs one k_step_coeffs thread loops over
     int chunks;               // 256-slot chunks per layer (k_step_coeffs grid.x / 1)
-    int xcd_map;              // 1: deal contiguous chunk ranges to the XCDs
+    int xcd_map;              // 0: plain grid; 1, 2: contiguous chunk ranges per XCD (2: angle fastest)
     int debug_skip_levels;    // diagnostics only (VRT_DEBUG_SKIP_LEVELS=1): wrong results
     int debug_flags;          // diagnostics only (VRT_DEBUG_FLAGS bit mask): wrong results, see execute_tiles
 };
@@ -556,7 +556,7 @@ __device__ __forceinline__ void upwind_term(double r, double w, double a_c, doub
 // in registers and loops over a group of kStepPairs wavelength pairs, so the 44-byte entry is
 // read once per group and the loads of the group's pairs are independent.
 // grid: x = slot chunk, y = angle * ceil(npair / kStepPairs) + pair group
-constexpr int kStepPairs = 3;   // default pairs per thread (VRT_STEP_PAIRS overrides)
+constexpr int kStepPairs = 4;   // default pairs per thread (VRT_STEP_PAIRS overrides)
 
 __global__ void __launch_bounds__(256)
 k_step_coeffs(StepArgs sa)
@@ -581,8 +581,9 @@ k_step_coeffs(StepArgs sa)
         chunk = blockIdx.x % sa.chunks;
         grp = blockIdx.x / sa.chunks;
     }
-    const int a = sa.angle_list[grp / ngrp];
-    const int q0 = (grp % ngrp) * ppt;
+    // angle fastest: the angles of a direction read the same S lines for a (chunk, pair group)
+    const int a = sa.xcd_map == 2 ? sa.angle_list[grp % sa.n_list] : sa.angle_list[grp / ngrp];
+    const int q0 = (sa.xcd_map == 2 ? grp / sa.n_list : grp % ngrp) * ppt;
     const int d = ta.angle_dir[a];
     if (sa.layer > ta.nlayers[d]) return;
     const int lo = ta.lay[d][sa.layer - 1], hi = ta.lay[d][sa.layer];
@@ -1014,7 +1015,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         sa.cg_g = reinterpret_cast<double2 *>(p->ws_cg[1]);
         sa.pairs_per_thread = std::getenv("VRT_STEP_PAIRS") ? std::max(1, std::atoi(std::getenv("VRT_STEP_PAIRS"))) : kStepPairs;
         sa.chunks = (int)((p->tile_max_layer_size + 255) / 256);
-        sa.xcd_map = std::getenv("VRT_STEP_XCD") ? std::atoi(std::getenv("VRT_STEP_XCD")) : 1;
+        sa.xcd_map = std::getenv("VRT_STEP_XCD") ? std::atoi(std::getenv("VRT_STEP_XCD")) : 2;
         sa.debug_skip_levels = std::getenv("VRT_DEBUG_SKIP_LEVELS") != nullptr;
         // 1: S/alpha gathers off, 2: I gathers off, 4: coefficient stores off, 8: coefficient loads off,
         // 16: I stores off, 32: no linear_weights arithmetic, 64: level kernel keeps the storage-order thread assignment
@@ -1037,19 +1038,23 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         VRT_HIP_TRY(hipEventRecord(p->ev0, st));
         VRT_HIP_TRY(hipEventRecord(p->step_fork, st));
         launches = 0;
-        for (int gi = 0; gi < G; gi++) {
-            hipStream_t sg = G == 1 ? st : p->step_stream[gi];
-            if (G > 1) VRT_HIP_TRY(hipStreamWaitEvent(sg, p->step_fork, 0));
-            const int n_list = p->step_group_off[gi + 1] - p->step_group_off[gi];
-            if (n_list == 0) continue;
-            sa.angle_list = p->d_step_angles + p->step_group_off[gi];
-            sa.n_list = n_list;
-            const int ngrp = (npair + sa.pairs_per_thread - 1) / sa.pairs_per_thread;
-            const int per_xcd = (sa.chunks + 7) / 8;     // largest chunk range of an XCD
-            const dim3 g1(sa.xcd_map ? (unsigned)(8 * per_xcd * n_list * ngrp) : (unsigned)(sa.chunks * n_list * ngrp));
-            const dim3 g2((unsigned)((size_t)n_list * (size_t)npair));
-            for (int layer = 2; layer <= Lmax; layer++) {
-                sa.layer = layer;
+        // Launches are enqueued layer by layer across the streams (not stream by stream): the host
+        // needs ~3.5 us per launch, so a stream whose 2 (L - 1) launches were queued behind all of
+        // another stream's would start a millisecond late and finish alone.
+        const int ngrp = (npair + sa.pairs_per_thread - 1) / sa.pairs_per_thread;
+        const int per_xcd = (sa.chunks + 7) / 8;     // largest chunk range of an XCD
+        if (G > 1)
+            for (int gi = 0; gi < G; gi++) VRT_HIP_TRY(hipStreamWaitEvent(p->step_stream[gi], p->step_fork, 0));
+        for (int layer = 2; layer <= Lmax; layer++) {
+            sa.layer = layer;
+            for (int gi = 0; gi < G; gi++) {
+                hipStream_t sg = G == 1 ? st : p->step_stream[gi];
+                const int n_list = p->step_group_off[gi + 1] - p->step_group_off[gi];
+                if (n_list == 0) continue;
+                sa.angle_list = p->d_step_angles + p->step_group_off[gi];
+                sa.n_list = n_list;
+                const dim3 g1(sa.xcd_map ? (unsigned)(8 * per_xcd * n_list * ngrp) : (unsigned)(sa.chunks * n_list * ngrp));
+                const dim3 g2((unsigned)((size_t)n_list * (size_t)npair));
                 hipLaunchKernelGGL(k_step_coeffs, g1, dim3(256), 0, sg, sa);
                 switch (step_K) {
                 case 1: hipLaunchKernelGGL(k_step_levels<1>, g2, dim3(1024), lds, sg, sa); break;
@@ -1063,11 +1068,12 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
                 }
                 launches += 2;
             }
-            if (G > 1) {
-                VRT_HIP_TRY(hipEventRecord(p->step_join[gi], sg));
+        }
+        if (G > 1)
+            for (int gi = 0; gi < G; gi++) {
+                VRT_HIP_TRY(hipEventRecord(p->step_join[gi], p->step_stream[gi]));
                 VRT_HIP_TRY(hipStreamWaitEvent(st, p->step_join[gi], 0));
             }
-        }
         VRT_HIP_TRY(hipGetLastError());
         VRT_HIP_TRY(hipEventRecord(p->ev1, st));
     } else {
