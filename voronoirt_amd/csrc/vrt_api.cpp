@@ -483,12 +483,16 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         //   "tiles"   ONE launch: each (angle, wavelength) workgroup walks all layers itself.
         // steps/tiles need layers of at most 8192 sites and <= 255 levels per layer.  Default when
         // that holds: tiles while the (angle, wavelength) problems fit one round of workgroups
-        // (<= 256: one launch, no per-layer launch cost -- C2: 1.4 ms vs 7.6 ms on levels), steps
-        // beyond (C4: 21.7 vs 27.2 ms on tiles); levels otherwise and for the fp32 value path.
+        // (<= 256) AND the layers are small (<= 4096 sites: the one launch has no per-layer launch
+        // cost -- C2, 2738-site layers: 1.2 ms vs 1.8 ms on steps, which is host-launch-bound
+        // there); steps otherwise (its chip-wide coefficient kernel wins once a layer holds more
+        // than a few sites per thread -- 1M sites x 12 angles x 1 λ: 5.1 vs 7.8 ms; C4: 11.8 vs
+        // 20.5 ms); levels when the grid does not fit and for the fp32 value path.
         // VRT_PATH selects one explicitly.
         const char *force = std::getenv("VRT_PATH");
         int path = 1;
-        if (p->tile_ok && !f32) path = (int64_t)p->A * nlam <= 256 ? 2 : 3;
+        if (p->tile_ok && !f32)
+            path = ((int64_t)p->A * nlam <= 256 && p->tile_max_layer_size <= 4096) ? 2 : 3;
         if (force && std::strcmp(force, "levels") == 0) path = 1;
         if (force && std::strcmp(force, "tiles") == 0) path = 2;
         if (force && std::strcmp(force, "steps") == 0) path = 3;
