@@ -180,6 +180,21 @@ int vrt_short_characteristics(int64_t nz, int64_t nx, int64_t ny, const double *
                               int64_t alpha_stride, const double *I0, int n_sweeps, int device,
                               double *I_out);
 
+/* Device-resident form: a handle owns the grid axes and the workspaces; dS, dalpha, dI0, dI_out are
+ * device pointers in the layouts above, k and up stay on the host; asynchronous on `stream`.
+ * field_period > 0: solve s reads the S / alpha array number s % field_period (solves ordered
+ * direction-major with the wavelength fastest share one array per wavelength); 0: array s.
+ * vrt_regular_last_solve_ms: HIP-event time of the last execute's solve kernel (synchronise first). */
+typedef struct vrt_regular vrt_regular;
+int vrt_regular_create(int64_t nz, int64_t nx, int64_t ny, const double *z, const double *x,
+                       const double *y, int device, vrt_regular **out);
+void vrt_regular_destroy(vrt_regular *r);
+int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const double *k, const int *up,
+                            const double *dS, int64_t S_stride, const double *dalpha,
+                            int64_t alpha_stride, int64_t field_period, const double *dI0,
+                            int n_sweeps, double *dI_out, void *stream);
+int vrt_regular_last_solve_ms(const vrt_regular *r, double *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,49 @@ def test_gpu_regular_errors():
         vrt.short_characteristics_up([0.5, 0.5, 0.5], S, I0, al, z, x, y)      # not a unit vector
     with pytest.raises(ValueError):
         vrt.short_characteristics_up(vrt.direction(150, 20), S[:-1], I0, al, z, x, y)
+
+
+@pytest.mark.gpu
+def test_gpu_regular_device_resident_handle():
+    """vrt_regular_*: device pointers in, device pointers out, handle reused across calls with a
+    growing batch (grow-only workspaces), same numbers as the host-pointer entry and the oracle."""
+    import torch
+    z, x, y, S, al, I0 = _random_problem(10, 13, 11, 7)
+    angles = [(170.0, 30.0), (100.0, 10.0), (80.0, 100.0), (10.0, 200.0)]
+    ks = np.stack([vrt.direction(t, p) for t, p in angles])
+    ups = [t > 90 for t, _ in angles]
+    rng = np.random.default_rng(8)
+    I0s = rng.random((len(angles),) + I0.shape)
+    dev = torch.device("cuda", 0)
+    dS, dA = torch.as_tensor(S, device=dev), torch.as_tensor(al, device=dev)
+    solver = vrt.RegularSolver(z, x, y, device=0)
+    for ns in (1, 4, 2):
+        dI0 = torch.as_tensor(I0s[:ns].copy(), device=dev)
+        dI = torch.full((ns,) + S.shape, np.nan, device=dev, dtype=torch.float64)
+        solver.execute_dev(ks[:ns], ups[:ns], dS.data_ptr(), 0, dA.data_ptr(), 0, dI0.data_ptr(), dI.data_ptr(),
+                           3, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert solver.last_solve_ms() > 0
+        got = dI.cpu().numpy()
+        for j in range(ns):
+            f = orc.short_characteristics_up if ups[j] else orc.short_characteristics_down
+            ref = f(ks[j], S, I0s[j], al, z, x, y, 3)
+            assert np.abs(got[j] - ref).max() / np.abs(ref).max() < 1e-12
+    # field_period: solves ordered direction-major share one (S, alpha) pair per wavelength
+    Ss = np.stack([S * (1 + 0.1 * j) for j in range(2)])
+    als = np.stack([al * (1 + 0.3 * j) for j in range(2)])
+    dSs, dAs = torch.as_tensor(Ss, device=dev), torch.as_tensor(als, device=dev)
+    k4 = np.repeat(ks[:2], 2, axis=0)
+    up4 = [ups[0], ups[0], ups[1], ups[1]]
+    dI0 = torch.as_tensor(I0s[:4].copy(), device=dev)
+    dI = torch.full((4,) + S.shape, np.nan, device=dev, dtype=torch.float64)
+    vol = S.size
+    solver.execute_dev(k4, up4, dSs.data_ptr(), vol, dAs.data_ptr(), vol, dI0.data_ptr(), dI.data_ptr(), 3,
+                       torch.cuda.current_stream().cuda_stream, field_period=2)
+    torch.cuda.synchronize()
+    got = dI.cpu().numpy()
+    for j in range(4):
+        f = orc.short_characteristics_up if up4[j] else orc.short_characteristics_down
+        ref = f(k4[j], Ss[j % 2], I0s[j], als[j % 2], z, x, y, 3)
+        assert np.abs(got[j] - ref).max() / np.abs(ref).max() < 1e-12
+    solver.close()

@@ -66,6 +66,12 @@ PROTOTYPES = {
     "vrt_short_characteristics": (ctypes.c_int, [c_i64, c_i64, c_i64, p_dbl, p_dbl, p_dbl, c_i64, p_dbl,
                                                  p_int, p_dbl, c_i64, p_dbl, c_i64, p_dbl, ctypes.c_int,
                                                  ctypes.c_int, p_dbl]),
+    "vrt_regular_create": (ctypes.c_int, [c_i64, c_i64, c_i64, p_dbl, p_dbl, p_dbl, ctypes.c_int,
+                                          ctypes.POINTER(vp)]),
+    "vrt_regular_destroy": (None, [vp]),
+    "vrt_regular_execute_dev": (ctypes.c_int, [vp, c_i64, p_dbl, p_int, vp, c_i64, vp, c_i64, c_i64, vp,
+                                               ctypes.c_int, vp, vp]),
+    "vrt_regular_last_solve_ms": (ctypes.c_int, [vp, p_dbl]),
     "vrt_delaunay_up": (ctypes.c_int, [vp, p_dbl, p_dbl, p_dbl, c_i64, p_dbl, ctypes.c_int, p_dbl]),
     "vrt_delaunay_down": (ctypes.c_int, [vp, p_dbl, p_dbl, p_dbl, c_i64, p_dbl, ctypes.c_int, p_dbl]),
 }

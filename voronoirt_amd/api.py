@@ -390,6 +390,45 @@ def short_characteristics_down(k, S_0, I_0, alpha, z, x, y, n_sweeps: int = 3, d
     return short_characteristics_batch([k], [False], S_0, I_0, alpha, z, x, y, n_sweeps, device)[0]
 
 
+class RegularSolver:
+    """Device-resident regular-grid short characteristics (`vrt_regular_*`): the handle owns the
+    grid axes and workspaces; `execute_dev` takes device pointers (torch `data_ptr()`) to S, alpha
+    (Julia (nz, nx, ny) order, shared or per solve), I_0 (nx, ny, n_solve) and the output
+    (nz, nx, ny, n_solve), and is asynchronous on `stream`."""
+
+    def __init__(self, z, x, y, device: int = 0):
+        z, x, y = _f64(z), _f64(x), _f64(y)
+        self.nz, self.nx, self.ny = z.size, x.size, y.size
+        self._h = ctypes.c_void_p()
+        check(_lib.load().vrt_regular_create(self.nz, self.nx, self.ny, _d(z), _d(x), _d(y), int(device),
+                                             ctypes.byref(self._h)))
+
+    def execute_dev(self, k, up, dS: int, S_stride: int, dalpha: int, alpha_stride: int, dI0: int,
+                    dI_out: int, n_sweeps: int = 3, stream: int = 0, field_period: int = 0):
+        k = _f64(np.atleast_2d(k))
+        ns = k.shape[0]
+        upv = np.ascontiguousarray(np.asarray(up, dtype=bool).reshape(ns), dtype=np.int32)
+        check(_lib.load().vrt_regular_execute_dev(self._h, ns, _d(k), upv.ctypes.data_as(_lib.p_int), dS,
+                                                  int(S_stride), dalpha, int(alpha_stride), int(field_period),
+                                                  dI0, int(n_sweeps), dI_out, stream or None))
+
+    def last_solve_ms(self) -> float:
+        out = ctypes.c_double()
+        check(_lib.load().vrt_regular_last_solve_ms(self._h, ctypes.byref(out)))
+        return out.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.load().vrt_regular_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def lambda_update_dev(sites: VoronoiSites, nlam: int, ld: int, dJ: int, dB: int, deps: int, dS_old: int,
                       dS_new: int, stream: int = 0) -> float:
     """Device-resident Λ-iteration epilogue: S_new = (1 - ε) J + ε B (src/lambda_iteration.jl:261-263)

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "vrt_internal.h"
@@ -76,6 +77,17 @@ __device__ __forceinline__ double reg_bilinear(double xm, double ym, double x1, 
     return ((y2 - ym) * f1 + (ym - y1) * f2) / dy;
 }
 
+// the same interpolation with the two interval lengths inverted once per plane and thread: the
+// row march is a dependent chain per row, and an fp64 division costs as much as the rest of a step.
+// Differs from reg_bilinear in the last bits only (parity contract of the regular solver: 1e-12).
+__device__ __forceinline__ double reg_bilinear_rcp(double wx2, double wx1, double wy2, double wy1, double rdx,
+                                                   double rdy, double Q11, double Q12, double Q21, double Q22)
+{
+    const double f1 = (wx2 * Q11 + wx1 * Q21) * rdx;       // wx2 = x2 - xm, wx1 = xm - x1
+    const double f2 = (wx2 * Q12 + wx1 * Q22) * rdx;
+    return (wy2 * f1 + wy1 * f2) * rdy;                     // wy2 = y2 - ym, wy1 = ym - y1
+}
+
 struct RegArgs {
     int nz, nx, ny, n_sweeps;
     const double *z, *x, *y;
@@ -83,24 +95,108 @@ struct RegArgs {
     const int *up;            // 1 = up, 0 = down
     const double *S, *alpha;  // plane-major, per solve stride below (0 = shared)
     int64_t S_stride, A_stride;
+    int64_t field_period;     // solve s reads field s % field_period (0: field s)
     const double *I0;         // (nx, ny) Julia order per solve: I0[ix + nx*iy]
     double *I;                // plane-major [solve][iz][iy][ix]
 };
 
 #define PL(p, ix, iy) (p)[(ix) + nx * (iy)]
 
+// Row march of the yz_/xz_ kernels for rows that fit one point per thread: the rows of a plane are
+// solved one after the other (each interpolates in the row solved just before: `I_upper`), so the
+// time of a plane is n_ser dependent steps.  Everything of a step that does not depend on the
+// carried row -- the interpolated upwind opacity and source function, linear_weights, the
+// upwind-plane intensities -- is prepared one row ahead from loads issued two rows ahead, so a
+// step's critical path is two LDS reads, a dozen flops, one LDS write and one barrier.
+//   YZ: serial index = ix, parallel index = iy (yz_up_ray :383-487, yz_down_ray :497-604)
+//   XZ: serial index = iy, parallel index = ix (xz_up_ray :614-716, xz_down_ray :726-835)
+// The arithmetic is the reference's ((e I_u + a S_u) + b S_c with the two products formed a row
+// early) except that the bilinear interpolations multiply by reciprocals (reg_bilinear_rcp).
+template <bool YZ>
+__device__ __forceinline__ void row_march(int nx, int n_ser, int n_par, int s0, int sgn, int h, bool up, double r,
+                                          double z_up, double inc, double zb1, double zb2, const double *__restrict__ par,
+                                          const double *__restrict__ A_lo, const double *__restrict__ A_hi,
+                                          const double *__restrict__ A_cen, const double *__restrict__ S_lo,
+                                          const double *__restrict__ S_hi, const double *__restrict__ S_cen,
+                                          const double *__restrict__ Ip, double *__restrict__ Ic, double *&row,
+                                          double *&row_nxt, int n_sweeps, bool ghost_in_sweeps, int tid, int T)
+{
+#define AT(arr, sidx, pidx) (YZ ? (arr)[(sidx) + nx * (pidx)] : (arr)[(pidx) + nx * (sidx)])
+    const bool act = tid < n_par - 2;
+    const int p = 1 + (act ? tid : 0);
+    const int pl = p - h, pu = pl + 1;
+    const double c_up = par[p] + inc, c_l = par[pl], c_u = par[pu];
+    const double wz2 = zb2 - z_up, wz1 = z_up - zb1, wc2 = c_u - c_up, wc1 = c_up - c_l;
+    const double rdz = 1.0 / (zb2 - zb1), rdc = 1.0 / (c_u - c_l);
+    struct Raw { double a[5], s[5], q[2]; };
+    struct Pre { double e, aS, bS, q1, q2; };
+    auto load = [&](int qq, Raw &w) {
+        const int sc = s0 + qq * sgn, su = sc + sgn;
+        w.a[0] = AT(A_lo, su, pl); w.a[1] = AT(A_lo, su, pu); w.a[2] = AT(A_hi, su, pl); w.a[3] = AT(A_hi, su, pu);
+        w.a[4] = AT(A_cen, sc, p);
+        w.s[0] = AT(S_lo, su, pl); w.s[1] = AT(S_lo, su, pu); w.s[2] = AT(S_hi, su, pl); w.s[3] = AT(S_hi, su, pu);
+        w.s[4] = AT(S_cen, sc, p);
+        w.q[0] = AT(Ip, su, pl); w.q[1] = AT(Ip, su, pu);
+    };
+    auto prepare = [&](const Raw &w, Pre &o) {
+        const double a_u = reg_bilinear_rcp(wz2, wz1, wc2, wc1, rdz, rdc, w.a[0], w.a[1], w.a[2], w.a[3]);
+        const double dtau = r * (w.a[4] + a_u) / 2.0;
+        const double S_u = reg_bilinear_rcp(wz2, wz1, wc2, wc1, rdz, rdc, w.s[0], w.s[1], w.s[2], w.s[3]);
+        double a, b, e;
+        reg_linear_weights(dtau, a, b, e);
+        o.e = e; o.aS = a * S_u; o.bS = b * w.s[4]; o.q1 = w.q[0]; o.q2 = w.q[1];
+    };
+    for (int sweep = 0; sweep < n_sweeps; sweep++) {
+        Raw raw;
+        Pre cur, nxt;
+        load(0, raw);
+        prepare(raw, cur);
+        if (n_ser > 1) load(1, raw);
+        for (int q = 0; q < n_ser; q++) {
+            const int sc = s0 + q * sgn;
+            if (act) {
+                const double I_u = up ? reg_bilinear_rcp(wz2, wz1, wc2, wc1, rdz, rdc, cur.q1, cur.q2, row[pl], row[pu])
+                                      : reg_bilinear_rcp(wz2, wz1, wc2, wc1, rdz, rdc, row[pl], row[pu], cur.q1, cur.q2);
+                const double v = (cur.e * I_u + cur.aS) + cur.bS;
+                // the new row goes to the plane and, with its periodic ghost zones, straight into
+                // the carried row in LDS (I_upper = I[idx, :] without a round trip through memory)
+                AT(Ic, sc, p) = v;
+                row_nxt[p] = v;
+                if (p == n_par - 2) { AT(Ic, sc, 0) = v; row_nxt[0] = v; }
+                if (p == 1) { AT(Ic, sc, n_par - 1) = v; row_nxt[n_par - 1] = v; }
+            }
+            if (q + 1 < n_ser) prepare(raw, nxt);          // row q + 1 from the loads of the previous step
+            if (q + 2 < n_ser) load(q + 2, raw);           // in flight across the barrier
+            __syncthreads();
+            { double *t_ = row; row = row_nxt; row_nxt = t_; }
+            cur = nxt;
+        }
+        if (YZ && ghost_in_sweeps) {                        // yz_up_ray only: inside the sweeps :480-482
+            for (int iy = tid; iy < n_par; iy += T) {
+                Ic[0 + nx * iy] = Ic[(nx - 2) + nx * iy];
+                Ic[(nx - 1) + nx * iy] = Ic[1 + nx * iy];
+            }
+            __syncthreads();
+        }
+    }
+#undef AT
+}
+
 __global__ void __launch_bounds__(1024)
 k_regular_solve(RegArgs ra)
 {
-    extern __shared__ __attribute__((aligned(16))) double row[];   // carried row / column
+    extern __shared__ __attribute__((aligned(16))) double rows[];  // carried row / column, double-buffered
+    const int rlen = ra.nx > ra.ny ? ra.nx : ra.ny;
+    double *row = rows, *row_nxt = rows + rlen;
     const int nz = ra.nz, nx = ra.nx, ny = ra.ny;
     const int tid = threadIdx.x, T = blockDim.x;
     const int solve = blockIdx.x;
     const double k0 = ra.k[3 * solve], k1 = ra.k[3 * solve + 1], k2 = ra.k[3 * solve + 2];
     const bool up = ra.up[solve] != 0;
     const int64_t plane = (int64_t)nx * ny;
-    const double *S = ra.S + (int64_t)solve * ra.S_stride;
-    const double *Al = ra.alpha + (int64_t)solve * ra.A_stride;
+    const int64_t field = ra.field_period > 0 ? solve % ra.field_period : solve;
+    const double *S = ra.S + field * ra.S_stride;
+    const double *Al = ra.alpha + field * ra.A_stride;
     double *I = ra.I + (int64_t)solve * plane * nz;
     const double *x = ra.x, *y = ra.y, *z = ra.z;
 
@@ -184,6 +280,10 @@ k_regular_solve(RegArgs ra)
             const double r = fabs((x[1] - x[0]) / k1);
             const double z_up = z[idz] + r * k0, y_inc = r * k2;
             const int sx0 = sign_x == 1 ? 1 : nx - 2;
+            if (ny - 2 <= T) {
+                row_march<true>(nx, nx - 2, ny, sx0, sign_x, hy, up, r, z_up, y_inc, zb1, zb2, y, A_lo, A_hi, Ac, S_lo,
+                                S_hi, Sc, Ip, Ic, row, row_nxt, ra.n_sweeps, up, tid, T);
+            } else
             for (int sweep = 0; sweep < ra.n_sweeps; sweep++) {
                 for (int q = 0; q < nx - 2; q++) {
                     const int idx = sx0 + q * sign_x, xu = idx + sign_x;
@@ -201,16 +301,17 @@ k_regular_solve(RegArgs ra)
                                                              PL(Ip, xu, yu), row[yl], row[yu])
                                               : reg_bilinear(z_up, y_up, zb1, zb2, y[yl], y[yu], row[yl], row[yu],
                                                              PL(Ip, xu, yl), PL(Ip, xu, yu));
-                        PL(Ic, idx, idy) = (e * I_u + a * S_u) + b * PL(Sc, idx, idy);
+                        const double v = (e * I_u + a * S_u) + b * PL(Sc, idx, idy);
+                        // the new row goes to the plane and, with its ghost zones (I[idx, 1] =
+                        // I[idx, end-1], I[idx, end] = I[idx, 2]), straight into the carried row
+                        // in LDS: I_upper = I[idx, :] without a round trip through memory
+                        PL(Ic, idx, idy) = v;
+                        row_nxt[idy] = v;
+                        if (idy == ny - 2) { PL(Ic, idx, 0) = v; row_nxt[0] = v; }
+                        if (idy == 1) { PL(Ic, idx, ny - 1) = v; row_nxt[ny - 1] = v; }
                     }
                     __syncthreads();
-                    if (tid == 0) {                               // ghost zones of the row
-                        PL(Ic, idx, 0) = PL(Ic, idx, ny - 2);
-                        PL(Ic, idx, ny - 1) = PL(Ic, idx, 1);
-                    }
-                    __syncthreads();
-                    for (int j = tid; j < ny; j += T) row[j] = PL(Ic, idx, j);   // I_upper = I[idx, :]
-                    __syncthreads();
+                    { double *t_ = row; row = row_nxt; row_nxt = t_; }
                 }
                 if (up) {                                         // yz_up_ray only: inside the sweeps :480-482
                     for (int idy = tid; idy < ny; idy += T) {
@@ -235,6 +336,10 @@ k_regular_solve(RegArgs ra)
             // centre values from α_upper / S_upper in BOTH variants (:672, :794): for the down
             // ray that is plane idz+1 (reference quirk)
             const double *A_cen = A_hi, *S_cen = S_hi;
+            if (nx - 2 <= T) {
+                row_march<false>(nx, ny - 2, nx, sy0, sign_y, hx, up, r, z_up, x_inc, zb1, zb2, x, A_lo, A_hi, A_cen,
+                                 S_lo, S_hi, S_cen, Ip, Ic, row, row_nxt, ra.n_sweeps, false, tid, T);
+            } else
             for (int sweep = 0; sweep < ra.n_sweeps; sweep++) {
                 for (int q = 0; q < ny - 2; q++) {
                     const int idy = sy0 + q * sign_y, yu = idy + sign_y;
@@ -252,16 +357,14 @@ k_regular_solve(RegArgs ra)
                                                              PL(Ip, xu, yu), row[xl], row[xu])
                                               : reg_bilinear(z_up, x_up, zb1, zb2, x[xl], x[xu], row[xl], row[xu],
                                                              PL(Ip, xl, yu), PL(Ip, xu, yu));
-                        PL(Ic, idx, idy) = (e * I_u + a * S_u) + b * PL(S_cen, idx, idy);
+                        const double v = (e * I_u + a * S_u) + b * PL(S_cen, idx, idy);
+                        PL(Ic, idx, idy) = v;                     // + ghost zones :704-705 / :822-823
+                        row_nxt[idx] = v;
+                        if (idx == nx - 2) { PL(Ic, 0, idy) = v; row_nxt[0] = v; }
+                        if (idx == 1) { PL(Ic, nx - 1, idy) = v; row_nxt[nx - 1] = v; }
                     }
                     __syncthreads();
-                    if (tid == 0) {                               // :704-705 / :822-823
-                        PL(Ic, 0, idy) = PL(Ic, nx - 2, idy);
-                        PL(Ic, nx - 1, idy) = PL(Ic, 1, idy);
-                    }
-                    __syncthreads();
-                    for (int i = tid; i < nx; i += T) row[i] = PL(Ic, i, idy);   // I_upper = I[:, idy]
-                    __syncthreads();
+                    { double *t_ = row; row = row_nxt; row_nxt = t_; }
                 }
             }
             for (int idx = tid; idx < nx; idx += T) {             // after the sweeps :713-714 / :831-832
@@ -279,16 +382,82 @@ k_regular_solve(RegArgs ra)
 
 using namespace vrt;
 
-extern "C" int vrt_short_characteristics(int64_t nz, int64_t nx, int64_t ny, const double *z,
-                                         const double *x, const double *y, int64_t n_solve,
-                                         const double *k, const int *up, const double *S,
-                                         int64_t S_stride, const double *alpha, int64_t alpha_stride,
-                                         const double *I0, int n_sweeps, int device, double *I_out)
+// ---- device-resident form: a handle owns the grid axes and the (grow-only) workspaces -----------
+struct vrt_regular {
+    int device = 0;
+    int64_t nz = 0, nx = 0, ny = 0;
+    double *d_g = nullptr;                 // z | x | y
+    double *d_S = nullptr, *d_A = nullptr, *d_I = nullptr, *d_k = nullptr;
+    int *d_up = nullptr;
+    int64_t cap_S = 0, cap_A = 0, cap_I = 0, cap_k = 0;      // in solves
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool timed = false;
+};
+
+static void regular_free(vrt_regular *r)
 {
-    if (!z || !x || !y || !k || !up || !S || !alpha || !I0 || !I_out) return fail(VRT_EINVAL, "NULL argument");
-    if (nz < 2 || nx < 3 || ny < 3 || n_solve < 1 || n_sweeps < 1) return fail(VRT_EINVAL, "bad sizes");
+    if (!r) return;
+    for (void *p : {(void *)r->d_g, (void *)r->d_S, (void *)r->d_A, (void *)r->d_I, (void *)r->d_k, (void *)r->d_up})
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : r->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete r;
+}
+
+extern "C" int vrt_regular_create(int64_t nz, int64_t nx, int64_t ny, const double *z, const double *x,
+                                  const double *y, int device, vrt_regular **out)
+{
+    if (!z || !x || !y || !out) return fail(VRT_EINVAL, "NULL argument");
+    if (nz < 2 || nx < 3 || ny < 3) return fail(VRT_EINVAL, "bad sizes");
     if (nx > 16384 || ny > 16384) return fail(VRT_EINVAL, "nx, ny must be at most 16384");
-    const int64_t vol = nz * nx * ny, plane = nx * ny;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+        return fail(VRT_ENODEVICE, "no HIP device available (libvrt_hip has no CPU fallback)");
+    if (device < 0 || device >= cnt) return fail(VRT_EINVAL, "device ordinal out of range");
+    VRT_HIP_TRY(hipSetDevice(device));
+    vrt_regular *r = new vrt_regular;
+    r->device = device;
+    r->nz = nz; r->nx = nx; r->ny = ny;
+    hipError_t e = hipMalloc((void **)&r->d_g, sizeof(double) * (size_t)(nz + nx + ny));
+    if (e == hipSuccess) e = hipMemcpy(r->d_g, z, sizeof(double) * nz, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(r->d_g + nz, x, sizeof(double) * nx, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(r->d_g + nz + nx, y, sizeof(double) * ny, hipMemcpyHostToDevice);
+    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&r->ev[i]);
+    if (e != hipSuccess) {
+        regular_free(r);
+        return fail(VRT_ENODEVICE, std::string("vrt_regular_create: ") + hipGetErrorString(e));
+    }
+    *out = r;
+    return VRT_OK;
+}
+
+extern "C" void vrt_regular_destroy(vrt_regular *r) { regular_free(r); }
+
+static int regular_grow(double *&buf, int64_t &cap, int64_t need, size_t per)
+{
+    if (buf && need <= cap) return VRT_OK;
+    if (buf) (void)hipFree(buf);
+    buf = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void **)&buf, sizeof(double) * per * (size_t)need);
+    if (e != hipSuccess) {
+        buf = nullptr;
+        return fail(e == hipErrorOutOfMemory ? VRT_ENOMEM : VRT_ENODEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    cap = need;
+    return VRT_OK;
+}
+
+// dS, dalpha, dI0, dI_out: device pointers in the caller's (Julia) layouts; k, up: host
+extern "C" int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const double *k, const int *up,
+                                       const double *dS, int64_t S_stride, const double *dalpha,
+                                       int64_t alpha_stride, int64_t field_period, const double *dI0,
+                                       int n_sweeps, double *dI_out, void *stream)
+{
+    if (field_period < 0 || field_period > n_solve) return fail(VRT_EINVAL, "field_period must be in [0, n_solve]");
+    if (!r || !k || !up || !dS || !dalpha || !dI0 || !dI_out) return fail(VRT_EINVAL, "NULL argument");
+    if (n_solve < 1 || n_sweeps < 1) return fail(VRT_EINVAL, "bad sizes");
+    const int64_t nz = r->nz, nx = r->nx, ny = r->ny, vol = nz * nx * ny;
     if ((S_stride != 0 && S_stride != vol) || (alpha_stride != 0 && alpha_stride != vol))
         return fail(VRT_EINVAL, "S_stride / alpha_stride must be 0 (shared) or nz*nx*ny");
     for (int64_t s = 0; s < n_solve; s++) {
@@ -298,19 +467,84 @@ extern "C" int vrt_short_characteristics(int64_t nz, int64_t nx, int64_t ny, con
             return fail(VRT_EINVAL, "direction " + std::to_string(s + 1) + " is not a unit vector");
         if (ks[0] == 0.0) return fail(VRT_EINVAL, "horizontal ray (k_z = 0) has no upwind plane");
     }
-    int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
-        return fail(VRT_ENODEVICE, "no HIP device available (libvrt_hip has no CPU fallback)");
-    if (device < 0 || device >= cnt) return fail(VRT_EINVAL, "device ordinal out of range");
-    VRT_HIP_TRY(hipSetDevice(device));
+    VRT_HIP_TRY(hipSetDevice(r->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nfield = field_period > 0 ? field_period : n_solve;
+    const int64_t nS = S_stride ? nfield : 1, nA = alpha_stride ? nfield : 1;
+    int rc;
+    if ((rc = regular_grow(r->d_S, r->cap_S, nS, (size_t)vol))) return rc;
+    if ((rc = regular_grow(r->d_A, r->cap_A, nA, (size_t)vol))) return rc;
+    if ((rc = regular_grow(r->d_I, r->cap_I, n_solve, (size_t)vol))) return rc;
+    if (n_solve > r->cap_k) {
+        if (r->d_k) (void)hipFree(r->d_k);
+        if (r->d_up) (void)hipFree(r->d_up);
+        r->d_k = nullptr; r->d_up = nullptr; r->cap_k = 0;
+        VRT_HIP_TRY(hipMalloc((void **)&r->d_k, sizeof(double) * 3 * (size_t)n_solve));
+        VRT_HIP_TRY(hipMalloc((void **)&r->d_up, sizeof(int) * (size_t)n_solve));
+        r->cap_k = n_solve;
+    }
+    VRT_HIP_TRY(hipMemcpyAsync(r->d_k, k, sizeof(double) * 3 * (size_t)n_solve, hipMemcpyHostToDevice, st));
+    VRT_HIP_TRY(hipMemcpyAsync(r->d_up, up, sizeof(int) * (size_t)n_solve, hipMemcpyHostToDevice, st));
+    VRT_HIP_TRY(hipEventRecord(r->ev[0], st));
+    const unsigned tb = (unsigned)((vol + 255) / 256);
+    for (int64_t s = 0; s < nS; s++)
+        hipLaunchKernelGGL(k_reg_to_planes, dim3(tb), dim3(256), 0, st, (int)nz, (int)nx, (int)ny, dS + s * vol, r->d_S + s * vol);
+    for (int64_t s = 0; s < nA; s++)
+        hipLaunchKernelGGL(k_reg_to_planes, dim3(tb), dim3(256), 0, st, (int)nz, (int)nx, (int)ny, dalpha + s * vol, r->d_A + s * vol);
+    RegArgs ra;
+    ra.nz = (int)nz; ra.nx = (int)nx; ra.ny = (int)ny; ra.n_sweeps = n_sweeps;
+    ra.z = r->d_g; ra.x = r->d_g + nz; ra.y = r->d_g + nz + nx;
+    ra.k = r->d_k; ra.up = r->d_up;
+    ra.S = r->d_S; ra.alpha = r->d_A; ra.S_stride = S_stride; ra.A_stride = alpha_stride;
+    ra.field_period = field_period;
+    ra.I0 = dI0; ra.I = r->d_I;
+    const size_t lds = 2 * sizeof(double) * (size_t)std::max(nx, ny);
+    VRT_HIP_TRY(hipEventRecord(r->ev[1], st));
+    // one thread per point of a row (the yz/xz planes march row by row), at least two waves; many
+    // such workgroups share a CU, which is where the batch's throughput comes from
+    int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(128, (std::max(nx, ny) - 2 + 63) / 64 * 64));
+    if (const char *e = std::getenv("VRT_REG_THREADS")) threads = std::max(64, std::min(1024, std::atoi(e) / 64 * 64));
+    hipLaunchKernelGGL(k_regular_solve, dim3((unsigned)n_solve), dim3((unsigned)threads), lds, st, ra);
+    VRT_HIP_TRY(hipEventRecord(r->ev[2], st));
+    for (int64_t s = 0; s < n_solve; s++)
+        hipLaunchKernelGGL(k_reg_from_planes, dim3(tb), dim3(256), 0, st, (int)nz, (int)nx, (int)ny, r->d_I + s * vol, dI_out + s * vol);
+    VRT_HIP_TRY(hipGetLastError());
+    r->timed = true;
+    return VRT_OK;
+}
+
+// milliseconds of the last execute's solve kernel alone (HIP events on its stream); the stream
+// must have been synchronised
+extern "C" int vrt_regular_last_solve_ms(const vrt_regular *r, double *ms)
+{
+    if (!r || !ms || !r->timed) return fail(VRT_EINVAL, "no timed execute yet");
+    float f = 0;
+    VRT_HIP_TRY(hipEventElapsedTime(&f, r->ev[1], r->ev[2]));
+    *ms = f;
+    return VRT_OK;
+}
+
+// Host-pointer form: stages the arrays through the device around vrt_regular_execute_dev.
+extern "C" int vrt_short_characteristics(int64_t nz, int64_t nx, int64_t ny, const double *z,
+                                         const double *x, const double *y, int64_t n_solve,
+                                         const double *k, const int *up, const double *S,
+                                         int64_t S_stride, const double *alpha, int64_t alpha_stride,
+                                         const double *I0, int n_sweeps, int device, double *I_out)
+{
+    if (!z || !x || !y || !k || !up || !S || !alpha || !I0 || !I_out) return fail(VRT_EINVAL, "NULL argument");
+    if (nz < 2 || nx < 3 || ny < 3 || n_solve < 1 || n_sweeps < 1) return fail(VRT_EINVAL, "bad sizes");
+    const int64_t vol = nz * nx * ny, plane = nx * ny;
+    if ((S_stride != 0 && S_stride != vol) || (alpha_stride != 0 && alpha_stride != vol))
+        return fail(VRT_EINVAL, "S_stride / alpha_stride must be 0 (shared) or nz*nx*ny");
+    vrt_regular *r = nullptr;
+    int rc = vrt_regular_create(nz, nx, ny, z, x, y, device, &r);
+    if (rc) return rc;
     const int64_t nS = S_stride ? n_solve : 1, nA = alpha_stride ? n_solve : 1;
-    double *d_in = nullptr, *d_S = nullptr, *d_A = nullptr, *d_I = nullptr, *d_I0 = nullptr, *d_g = nullptr,
-           *d_k = nullptr;
-    int *d_up = nullptr;
+    double *d_S = nullptr, *d_A = nullptr, *d_I0 = nullptr, *d_out = nullptr;
     auto cleanup = [&]() {
-        for (void *p : {(void *)d_in, (void *)d_S, (void *)d_A, (void *)d_I, (void *)d_I0, (void *)d_g,
-                        (void *)d_k, (void *)d_up})
+        for (void *p : {(void *)d_S, (void *)d_A, (void *)d_I0, (void *)d_out})
             if (p) (void)hipFree(p);
+        regular_free(r);
     };
 #define REG_TRY(expr)                                                                      \
     do {                                                                                   \
@@ -321,45 +555,20 @@ extern "C" int vrt_short_characteristics(int64_t nz, int64_t nx, int64_t ny, con
                         std::string(#expr) + ": " + hipGetErrorString(_e));                \
         }                                                                                  \
     } while (0)
-    REG_TRY(hipMalloc((void **)&d_in, sizeof(double) * vol));
     REG_TRY(hipMalloc((void **)&d_S, sizeof(double) * vol * nS));
     REG_TRY(hipMalloc((void **)&d_A, sizeof(double) * vol * nA));
-    REG_TRY(hipMalloc((void **)&d_I, sizeof(double) * vol * n_solve));
     REG_TRY(hipMalloc((void **)&d_I0, sizeof(double) * plane * n_solve));
-    REG_TRY(hipMalloc((void **)&d_g, sizeof(double) * (nz + nx + ny)));
-    REG_TRY(hipMalloc((void **)&d_k, sizeof(double) * 3 * n_solve));
-    REG_TRY(hipMalloc((void **)&d_up, sizeof(int) * n_solve));
-    const unsigned tb = (unsigned)((vol + 255) / 256);
-    for (int64_t s = 0; s < nS; s++) {
-        REG_TRY(hipMemcpy(d_in, S + s * vol, sizeof(double) * vol, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_reg_to_planes, dim3(tb), dim3(256), 0, 0, (int)nz, (int)nx, (int)ny, d_in, d_S + s * vol);
-        REG_TRY(hipDeviceSynchronize());
-    }
-    for (int64_t s = 0; s < nA; s++) {
-        REG_TRY(hipMemcpy(d_in, alpha + s * vol, sizeof(double) * vol, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_reg_to_planes, dim3(tb), dim3(256), 0, 0, (int)nz, (int)nx, (int)ny, d_in, d_A + s * vol);
-        REG_TRY(hipDeviceSynchronize());
-    }
+    REG_TRY(hipMalloc((void **)&d_out, sizeof(double) * vol * n_solve));
+    REG_TRY(hipMemcpy(d_S, S, sizeof(double) * vol * nS, hipMemcpyHostToDevice));
+    REG_TRY(hipMemcpy(d_A, alpha, sizeof(double) * vol * nA, hipMemcpyHostToDevice));
     REG_TRY(hipMemcpy(d_I0, I0, sizeof(double) * plane * n_solve, hipMemcpyHostToDevice));
-    REG_TRY(hipMemcpy(d_g, z, sizeof(double) * nz, hipMemcpyHostToDevice));
-    REG_TRY(hipMemcpy(d_g + nz, x, sizeof(double) * nx, hipMemcpyHostToDevice));
-    REG_TRY(hipMemcpy(d_g + nz + nx, y, sizeof(double) * ny, hipMemcpyHostToDevice));
-    REG_TRY(hipMemcpy(d_k, k, sizeof(double) * 3 * n_solve, hipMemcpyHostToDevice));
-    REG_TRY(hipMemcpy(d_up, up, sizeof(int) * n_solve, hipMemcpyHostToDevice));
-    RegArgs ra;
-    ra.nz = (int)nz; ra.nx = (int)nx; ra.ny = (int)ny; ra.n_sweeps = n_sweeps;
-    ra.z = d_g; ra.x = d_g + nz; ra.y = d_g + nz + nx;
-    ra.k = d_k; ra.up = d_up;
-    ra.S = d_S; ra.alpha = d_A; ra.S_stride = S_stride; ra.A_stride = alpha_stride;
-    ra.I0 = d_I0; ra.I = d_I;
-    const size_t lds = sizeof(double) * (size_t)std::max(nx, ny);
-    hipLaunchKernelGGL(k_regular_solve, dim3((unsigned)n_solve), dim3(1024), lds, 0, ra);
-    REG_TRY(hipGetLastError());
-    REG_TRY(hipDeviceSynchronize());
-    for (int64_t s = 0; s < n_solve; s++) {
-        hipLaunchKernelGGL(k_reg_from_planes, dim3(tb), dim3(256), 0, 0, (int)nz, (int)nx, (int)ny, d_I + s * vol, d_in);
-        REG_TRY(hipMemcpy(I_out + s * vol, d_in, sizeof(double) * vol, hipMemcpyDeviceToHost));
+    rc = vrt_regular_execute_dev(r, n_solve, k, up, d_S, S_stride, d_A, alpha_stride, 0, d_I0, n_sweeps, d_out, nullptr);
+    if (rc) {
+        cleanup();
+        return rc;
     }
+    REG_TRY(hipDeviceSynchronize());
+    REG_TRY(hipMemcpy(I_out, d_out, sizeof(double) * vol * n_solve, hipMemcpyDeviceToHost));
 #undef REG_TRY
     cleanup();
     return VRT_OK;
