@@ -539,13 +539,7 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         bool replayed = false;
         if (use_graph) {
             if (!(p->graph_exec && p->graph_key == key)) {
-                dev_free(p->d_step_angles);
-    if (p->step_fork) (void)hipEventDestroy(p->step_fork);
-    for (int i = 0; i < 4; i++) {
-        if (p->step_join[i]) (void)hipEventDestroy(p->step_join[i]);
-        if (p->step_stream[i]) (void)hipStreamDestroy(p->step_stream[i]);
-    }
-    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+                if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
                 p->graph_exec = nullptr;
                 hipGraph_t graph = nullptr;
                 if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
