@@ -337,6 +337,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
     p->h_up1.swap(up1);
     p->h_up2.swap(up2);
     std::vector<LayerSchedule> lsched((size_t)A);
+    std::vector<std::vector<int32_t>> sorted_self((size_t)A);   // thread assignment of k_step_levels
     {
         unsigned hw = std::thread::hardware_concurrency();
         int nthr = (int)std::min<unsigned>(hw ? hw : 4, 16);
@@ -349,6 +350,8 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                     build_layer_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
                                          p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n,
                                          lsched[(size_t)a]);
+                    if (lsched[(size_t)a].ok)
+                        build_sorted_slots(up ? g->up : g->down, n, lsched[(size_t)a].vis, sorted_self[(size_t)a]);
                 }
             });
         for (auto &th : pool) th.join();
@@ -406,16 +409,15 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             p->tile_max_layers = maxL;
             std::vector<int32_t> nlev((size_t)A * (size_t)(maxL + 1), 0), adir((size_t)A);
             p->angle_visits.assign((size_t)A, 0);
-            std::vector<int32_t> h_self;
             for (int a = 0; a < A; a++) {
                 hipError_t e = hipMemcpy(d_vis_site, lsched[(size_t)a].vis.data(), sizeof(uint32_t) * n,
                                          hipMemcpyHostToDevice);
                 int rc2 = e == hipSuccess ? launch_permute_table(p, a, d_vis_site) : VRT_ENODEVICE;
                 if (!rc2) {     // sorted thread assignment of the layer-step level kernel
-                    const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-                    build_sorted_slots(dir, n, lsched[(size_t)a].vis, h_self);
-                    if (hipMemcpy(p->t_self + (size_t)a * n, h_self.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice) != hipSuccess)
+                    if (hipMemcpy(p->t_self + (size_t)a * n, sorted_self[(size_t)a].data(), sizeof(int32_t) * n,
+                                  hipMemcpyHostToDevice) != hipSuccess)
                         rc2 = VRT_ENODEVICE;
+                    std::vector<int32_t>().swap(sorted_self[(size_t)a]);
                     if (!rc2) rc2 = launch_sorted_tables(p, a);
                     if (!rc2) rc2 = launch_gpos(p, a);
                 }
