@@ -145,6 +145,11 @@ void vrt_schedule_destroy(vrt_schedule *s);
  * of each layer (index = 1-based layer).  VRT_EINVAL if it does not fit that encoding. */
 int vrt_layer_schedule(const vrt_grid *g, int dir, const int64_t *up, int n_sweeps, uint32_t *vis,
                        int32_t *nlev, int64_t *n_visits);
+/* Thread assignment of the layer-step level kernel for such a `vis` (introspection, host only):
+ * store[n] = 1-based site id at each storage position (layers contiguous, Morton order inside);
+ * self[n] = 0-based storage position held by each sorted index: inside every layer the
+ * positions are sorted (stably) by visit pattern -- first, then second, ... visit level. */
+int vrt_layer_sorted_slots(const vrt_grid *g, int dir, const uint32_t *vis, int64_t *store, int64_t *self);
 
 /* ---- single solves: drop-in bodies for Delaunay_upII / Delaunay_downII --------------------
  * (src/irregular_ray_tracing.jl:15-20,96-101).  nI0 must equal layers[2]-1 of the direction.

@@ -457,3 +457,46 @@ def test_header_is_valid_c_and_c_caller_links(tmp_path):
                            os.path.join(ROOT, "examples", "c_caller.c"), "-o", str(exe),
                            "-L", libdir, "-lvrt_hip", f"-Wl,-rpath,{libdir}", "-lm"])
     assert exe.exists()
+
+
+def test_sorted_thread_assignment_of_the_level_kernel(bcc_small, voro_small):
+    """build_sorted_slots (k_step_levels' thread assignment): inside every layer `self` is a
+    permutation of the layer's storage positions, stably sorted by visit pattern (first visit
+    level, then second, ...), so a wave's 64 consecutive entries share their levels; the storage
+    order itself keeps the layers contiguous and the never-visited site perm[n] last."""
+    from voronoirt_amd.api import layer_sorted_slots
+    for pos, nbr, bounds in (bcc_small, voro_small):
+        so = orc.make_sites(pos, nbr, bounds)
+        hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)
+        n = so.n
+        for t, p, dirn in ((109.7, 193.6, 1), (70.3, 346.4, -1), (152.7, 45.0, 1)):
+            up, _, _, _, _ = orc.upwind_table(so, orc.direction(t, p))
+            vis, nlev, nv = build_layer_schedule(hs, dirn, up, 3)
+            store, self_ = layer_sorted_slots(hs, dirn, vis)
+            perm = so.perm_up if dirn > 0 else so.perm_down
+            lay = so.layers_up if dirn > 0 else so.layers_down
+            assert sorted(store.tolist()) == list(range(1, n + 1))
+            assert store[n - 1] == perm[n - 1]
+            groups_sorted = groups_plain = 0
+            for layer in range(1, len(lay)):
+                lo, hi = lay[layer - 1] - 1, lay[layer] - 1
+                assert sorted(store[lo:hi].tolist()) == sorted(perm[lo:hi].tolist())   # same layer, other order
+                s = self_[lo:hi]
+                assert sorted(s.tolist()) == list(range(lo, hi))
+                v = vis[store[s] - 1]
+                key = [tuple(int((x >> (8 * j)) & 0xFF) for j in range(4)) for x in v]
+                assert key == sorted(key)
+                for a, b, ka, kb in zip(s[:-1], s[1:], key[:-1], key[1:]):
+                    if ka == kb:
+                        assert a < b                                                  # stable
+                if layer >= 2:
+                    plain = vis[store[lo:hi] - 1]
+                    for arr, tot in ((v, "s"), (plain, "p")):
+                        g = sum(len({int((x >> (8 * j)) & 0xFF) for x in arr[w:w + 64] for j in range(4)} - {0})
+                                for w in range(0, hi - lo, 64))
+                        if tot == "s":
+                            groups_sorted += g
+                        else:
+                            groups_plain += g
+            assert groups_sorted <= groups_plain          # fewer (wave, level) pairs to execute
+        hs.close()

@@ -351,6 +351,18 @@ def build_layer_schedule(sites: VoronoiSites, dir: int, up, n_sweeps: int = 3):
     return vis, nlev, nv.value
 
 
+def layer_sorted_slots(sites: VoronoiSites, dir: int, vis):
+    """Thread assignment of the layer-step level kernel for a layer schedule `vis` (host only):
+    (store, self) = 1-based site id per storage position, 0-based storage position per sorted
+    index (inside each layer sorted stably by visit pattern)."""
+    vis = np.ascontiguousarray(vis, dtype=np.uint32)
+    store = np.zeros(sites.n, dtype=np.int64)
+    self_ = np.zeros(sites.n, dtype=np.int64)
+    check(_lib.load().vrt_layer_sorted_slots(sites.handle, int(dir), vis.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                             _i(store), _i(self_)))
+    return store, self_
+
+
 # ---- regular grid (SURVEY 8f row 1) ---------------------------------------------------------------
 def short_characteristics_batch(k, up, S_0, I_0, alpha, z, x, y, n_sweeps: int = 3, device: int = 0):
     """Batched regular-grid formal solve.  k (n_solve, 3); up (n_solve,) bools; S_0 / alpha either

@@ -840,6 +840,25 @@ int vrt_layer_schedule(const vrt_grid *g, int dir, const int64_t *up, int n_swee
     }
 }
 
+int vrt_layer_sorted_slots(const vrt_grid *g, int dir, const uint32_t *vis, int64_t *store, int64_t *self)
+{
+    if (!g || !vis || !store || !self) return fail(VRT_EINVAL, "NULL argument");
+    try {
+        const int64_t n = g->n;
+        const Direction &d = direction_of(g, dir);
+        std::vector<uint32_t> v(vis, vis + n);
+        std::vector<int32_t> s32;
+        build_sorted_slots(d, n, v, s32);
+        for (int64_t i = 0; i < n; i++) {
+            store[i] = (int64_t)d.store[(size_t)i] + 1;
+            self[i] = (int64_t)s32[(size_t)i];
+        }
+        return VRT_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    }
+}
+
 int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS,
                          const double *dalpha, int alpha_mode, const double *dI0_up,
                          const double *dI0_down, const double *weights_host, double *dJ,
