@@ -96,6 +96,7 @@ struct RegArgs {
     const double *S, *alpha;  // plane-major, per solve stride below (0 = shared)
     int64_t S_stride, A_stride;
     int64_t field_period;     // solve s reads field s % field_period (0: field s)
+    double *coef;             // per solve 5 * nx * ny doubles: row-march coefficients of one plane
     const double *I0;         // (nx, ny) Julia order per solve: I0[ix + nx*iy]
     double *I;                // plane-major [solve][iz][iy][ix]
 };
@@ -106,8 +107,10 @@ struct RegArgs {
 // solved one after the other (each interpolates in the row solved just before: `I_upper`), so the
 // time of a plane is n_ser dependent steps.  Everything of a step that does not depend on the
 // carried row -- the interpolated upwind opacity and source function, linear_weights, the
-// upwind-plane intensities -- is prepared one row ahead from loads issued two rows ahead, so a
-// step's critical path is two LDS reads, a dozen flops, one LDS write and one barrier.
+// upwind-plane intensities -- is the same in every sweep and is computed once per plane in a
+// row-parallel pass into a per-solve scratch (5 doubles per point); a step of the sweeps then
+// streams those (two rows ahead) and its critical path is two LDS reads, a dozen flops, one LDS
+// write and one barrier.
 //   YZ: serial index = ix, parallel index = iy (yz_up_ray :383-487, yz_down_ray :497-604)
 //   XZ: serial index = iy, parallel index = ix (xz_up_ray :614-716, xz_down_ray :726-835)
 // The arithmetic is the reference's ((e I_u + a S_u) + b S_c with the two products formed a row
@@ -119,7 +122,8 @@ __device__ __forceinline__ void row_march(int nx, int n_ser, int n_par, int s0, 
                                           const double *__restrict__ A_cen, const double *__restrict__ S_lo,
                                           const double *__restrict__ S_hi, const double *__restrict__ S_cen,
                                           const double *__restrict__ Ip, double *__restrict__ Ic, double *&row,
-                                          double *&row_nxt, int n_sweeps, bool ghost_in_sweeps, int tid, int T)
+                                          double *&row_nxt, int n_sweeps, bool ghost_in_sweeps, int tid, int T,
+                                          double *__restrict__ coef)
 {
 #define AT(arr, sidx, pidx) (YZ ? (arr)[(sidx) + nx * (pidx)] : (arr)[(pidx) + nx * (sidx)])
     const bool act = tid < n_par - 2;
@@ -146,15 +150,41 @@ __device__ __forceinline__ void row_march(int nx, int n_ser, int n_par, int s0, 
         reg_linear_weights(dtau, a, b, e);
         o.e = e; o.aS = a * S_u; o.bS = b * w.s[4]; o.q1 = w.q[0]; o.q2 = w.q[1];
     };
-    for (int sweep = 0; sweep < n_sweeps; sweep++) {
-        Raw raw;
-        Pre cur, nxt;
+    // ---- pass 0: the coefficients of every row of the plane.  They do not depend on the carried
+    // row, so the rows are independent here (the loads of row q + 1 fly while row q is computed),
+    // and they are the same in every sweep: written once to a per-solve scratch, [5][n_ser][n_par - 2].
+    const size_t cs = (size_t)n_ser * (size_t)(n_par - 2);
+    double *__restrict__ sc_e = coef, *__restrict__ sc_aS = coef + cs, *__restrict__ sc_bS = coef + 2 * cs,
+           *__restrict__ sc_q1 = coef + 3 * cs, *__restrict__ sc_q2 = coef + 4 * cs;
+    if (act) {
+        Raw raw, raw2;
         load(0, raw);
-        prepare(raw, cur);
-        if (n_ser > 1) load(1, raw);
+        for (int q = 0; q < n_ser; q++) {
+            if (q + 1 < n_ser) load(q + 1, raw2);
+            Pre o;
+            prepare(raw, o);
+            const size_t at = (size_t)q * (size_t)(n_par - 2) + (size_t)tid;
+            sc_e[at] = o.e; sc_aS[at] = o.aS; sc_bS[at] = o.bS; sc_q1[at] = o.q1; sc_q2[at] = o.q2;
+            raw = raw2;
+        }
+    }
+    // (each thread reads back only what it wrote itself: no barrier needed)
+    auto fetch = [&](int qq, Pre &o) {
+        const size_t at = (size_t)qq * (size_t)(n_par - 2) + (size_t)tid;
+        o.e = sc_e[at]; o.aS = sc_aS[at]; o.bS = sc_bS[at]; o.q1 = sc_q1[at]; o.q2 = sc_q2[at];
+    };
+    // ---- the sweeps: per row two LDS reads, a dozen flops, one LDS write, one barrier; the
+    // coefficients of row q + 2 are in flight across the barrier
+    for (int sweep = 0; sweep < n_sweeps; sweep++) {
+        Pre cur, nxt, nxt2;
+        if (act) {
+            fetch(0, cur);
+            if (n_ser > 1) fetch(1, nxt);
+        }
         for (int q = 0; q < n_ser; q++) {
             const int sc = s0 + q * sgn;
             if (act) {
+                if (q + 2 < n_ser) fetch(q + 2, nxt2);
                 const double I_u = up ? reg_bilinear_rcp(wz2, wz1, wc2, wc1, rdz, rdc, cur.q1, cur.q2, row[pl], row[pu])
                                       : reg_bilinear_rcp(wz2, wz1, wc2, wc1, rdz, rdc, row[pl], row[pu], cur.q1, cur.q2);
                 const double v = (cur.e * I_u + cur.aS) + cur.bS;
@@ -164,12 +194,11 @@ __device__ __forceinline__ void row_march(int nx, int n_ser, int n_par, int s0, 
                 row_nxt[p] = v;
                 if (p == n_par - 2) { AT(Ic, sc, 0) = v; row_nxt[0] = v; }
                 if (p == 1) { AT(Ic, sc, n_par - 1) = v; row_nxt[n_par - 1] = v; }
+                cur = nxt;
+                nxt = nxt2;
             }
-            if (q + 1 < n_ser) prepare(raw, nxt);          // row q + 1 from the loads of the previous step
-            if (q + 2 < n_ser) load(q + 2, raw);           // in flight across the barrier
             __syncthreads();
             { double *t_ = row; row = row_nxt; row_nxt = t_; }
-            cur = nxt;
         }
         if (YZ && ghost_in_sweeps) {                        // yz_up_ray only: inside the sweeps :480-482
             for (int iy = tid; iy < n_par; iy += T) {
@@ -198,6 +227,7 @@ k_regular_solve(RegArgs ra)
     const double *S = ra.S + field * ra.S_stride;
     const double *Al = ra.alpha + field * ra.A_stride;
     double *I = ra.I + (int64_t)solve * plane * nz;
+    double *coef = ra.coef + (int64_t)solve * 5 * plane;
     const double *x = ra.x, *y = ra.y, *z = ra.z;
 
     int sign_x, sign_y;                                           // xy_intersect, functions.jl:430-457
@@ -282,7 +312,7 @@ k_regular_solve(RegArgs ra)
             const int sx0 = sign_x == 1 ? 1 : nx - 2;
             if (ny - 2 <= T) {
                 row_march<true>(nx, nx - 2, ny, sx0, sign_x, hy, up, r, z_up, y_inc, zb1, zb2, y, A_lo, A_hi, Ac, S_lo,
-                                S_hi, Sc, Ip, Ic, row, row_nxt, ra.n_sweeps, up, tid, T);
+                                S_hi, Sc, Ip, Ic, row, row_nxt, ra.n_sweeps, up, tid, T, coef);
             } else
             for (int sweep = 0; sweep < ra.n_sweeps; sweep++) {
                 for (int q = 0; q < nx - 2; q++) {
@@ -338,7 +368,7 @@ k_regular_solve(RegArgs ra)
             const double *A_cen = A_hi, *S_cen = S_hi;
             if (nx - 2 <= T) {
                 row_march<false>(nx, ny - 2, nx, sy0, sign_y, hx, up, r, z_up, x_inc, zb1, zb2, x, A_lo, A_hi, A_cen,
-                                 S_lo, S_hi, S_cen, Ip, Ic, row, row_nxt, ra.n_sweeps, false, tid, T);
+                                 S_lo, S_hi, S_cen, Ip, Ic, row, row_nxt, ra.n_sweeps, false, tid, T, coef);
             } else
             for (int sweep = 0; sweep < ra.n_sweeps; sweep++) {
                 for (int q = 0; q < ny - 2; q++) {
@@ -387,9 +417,9 @@ struct vrt_regular {
     int device = 0;
     int64_t nz = 0, nx = 0, ny = 0;
     double *d_g = nullptr;                 // z | x | y
-    double *d_S = nullptr, *d_A = nullptr, *d_I = nullptr, *d_k = nullptr;
+    double *d_S = nullptr, *d_A = nullptr, *d_I = nullptr, *d_k = nullptr, *d_coef = nullptr;
     int *d_up = nullptr;
-    int64_t cap_S = 0, cap_A = 0, cap_I = 0, cap_k = 0;      // in solves
+    int64_t cap_S = 0, cap_A = 0, cap_I = 0, cap_k = 0, cap_coef = 0;      // in solves
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timed = false;
 };
@@ -397,7 +427,8 @@ struct vrt_regular {
 static void regular_free(vrt_regular *r)
 {
     if (!r) return;
-    for (void *p : {(void *)r->d_g, (void *)r->d_S, (void *)r->d_A, (void *)r->d_I, (void *)r->d_k, (void *)r->d_up})
+    for (void *p : {(void *)r->d_g, (void *)r->d_S, (void *)r->d_A, (void *)r->d_I, (void *)r->d_k, (void *)r->d_up,
+                    (void *)r->d_coef})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : r->ev)
         if (e) (void)hipEventDestroy(e);
@@ -475,6 +506,7 @@ extern "C" int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const do
     if ((rc = regular_grow(r->d_S, r->cap_S, nS, (size_t)vol))) return rc;
     if ((rc = regular_grow(r->d_A, r->cap_A, nA, (size_t)vol))) return rc;
     if ((rc = regular_grow(r->d_I, r->cap_I, n_solve, (size_t)vol))) return rc;
+    if ((rc = regular_grow(r->d_coef, r->cap_coef, n_solve, (size_t)(5 * nx * ny)))) return rc;
     if (n_solve > r->cap_k) {
         if (r->d_k) (void)hipFree(r->d_k);
         if (r->d_up) (void)hipFree(r->d_up);
@@ -498,6 +530,7 @@ extern "C" int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const do
     ra.S = r->d_S; ra.alpha = r->d_A; ra.S_stride = S_stride; ra.A_stride = alpha_stride;
     ra.field_period = field_period;
     ra.I0 = dI0; ra.I = r->d_I;
+    ra.coef = r->d_coef;
     const size_t lds = 2 * sizeof(double) * (size_t)std::max(nx, ny);
     VRT_HIP_TRY(hipEventRecord(r->ev[1], st));
     // one thread per point of a row (the yz/xz planes march row by row), at least two waves; many
