@@ -174,3 +174,21 @@ def test_gpu_regular_device_resident_handle():
         ref = f(k4[j], Ss[j % 2], I0s[j], als[j % 2], z, x, y, 3)
         assert np.abs(got[j] - ref).max() / np.abs(ref).max() < 1e-12
     solver.close()
+
+
+@pytest.mark.gpu
+def test_gpu_regular_rows_longer_than_the_workgroup(monkeypatch):
+    """Rows with more points than threads take the strided (non-pipelined) row loop of the
+    yz/xz kernels; VRT_REG_THREADS=64 forces that on a 70 x 75 plane."""
+    monkeypatch.setenv("VRT_REG_THREADS", "64")
+    z, x, y, S, al, I0 = _random_problem(6, 72, 77, 11)
+    angles = [(100.0, 10.0), (100.0, 80.0), (80.0, 190.0), (80.0, 100.0), (170.0, 30.0)]
+    ks = np.stack([vrt.direction(t, p) for t, p in angles])
+    ups = [t > 90 for t, _ in angles]
+    rng = np.random.default_rng(12)
+    I0s = rng.random((len(angles),) + I0.shape)
+    got = vrt.short_characteristics_batch(ks, ups, S, I0s, al, z, x, y, 3)
+    for j in range(len(angles)):
+        f = orc.short_characteristics_up if ups[j] else orc.short_characteristics_down
+        ref = f(ks[j], S, I0s[j], al, z, x, y, 3)
+        assert np.abs(got[j] - ref).max() / np.abs(ref).max() < 1e-12
