@@ -189,7 +189,8 @@ int vrt_short_characteristics(int64_t nz, int64_t nx, int64_t ny, const double *
  * device pointers in the layouts above, k and up stay on the host; asynchronous on `stream`.
  * field_period > 0: solve s reads the S / alpha array number s % field_period (solves ordered
  * direction-major with the wavelength fastest share one array per wavelength); 0: array s.
- * vrt_regular_last_solve_ms: HIP-event time of the last execute's solve kernel (synchronise first). */
+ * vrt_regular_last_solve_ms: HIP-event time of the last execute's solve kernel (synchronise first).
+ * A handle serves one caller at a time (its workspaces are reused by every execute). */
 typedef struct vrt_regular vrt_regular;
 int vrt_regular_create(int64_t nz, int64_t nx, int64_t ny, const double *z, const double *x,
                        const double *y, int device, vrt_regular **out);

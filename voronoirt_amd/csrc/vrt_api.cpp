@@ -175,7 +175,7 @@ static void free_plan(vrt_plan *p)
     dev_free(p->d_nlev); dev_free(p->d_angle_dir); dev_free(p->d_task_map);
     for (int d = 0; d < 2; d++) { dev_free(p->ws_S[d]); dev_free(p->ws_A[d]); dev_free(p->ws_J[d]); }
     dev_free(p->ws_AA);
-    for (int i = 0; i < 4; i++) dev_free(p->ws_cg[i]);
+    for (int i = 0; i < 2; i++) dev_free(p->ws_cg[i]);
     dev_free(p->d_step_angles);
     if (p->step_fork) (void)hipEventDestroy(p->step_fork);
     for (int i = 0; i < 4; i++) {

@@ -134,8 +134,8 @@ struct vrt_plan {
     size_t ws_S_cap[2] = {0, 0}, ws_A_cap[2] = {0, 0}, ws_J_cap[2] = {0, 0};
     double *ws_AA = nullptr;
     size_t ws_AA_cap = 0;
-    double *ws_cg[4] = {nullptr, nullptr, nullptr, nullptr};   // layer-step coefficient buffers
-    size_t ws_cg_cap[4] = {0, 0, 0, 0};
+    double *ws_cg[2] = {nullptr, nullptr};   // layer-step coefficient buffers: constant terms, compact couplings
+    size_t ws_cg_cap[2] = {0, 0};
     // layer-step path: internal streams and the angle groups they advance through the layers
     int step_groups = 0;
     int32_t *d_step_angles = nullptr;

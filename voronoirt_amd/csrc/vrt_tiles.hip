@@ -1020,6 +1020,11 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         // 1: S/alpha gathers off, 2: I gathers off, 4: coefficient stores off, 8: coefficient loads off,
         // 16: I stores off, 32: no linear_weights arithmetic, 64: level kernel keeps the storage-order thread assignment
         sa.debug_flags = std::getenv("VRT_DEBUG_FLAGS") ? std::atoi(std::getenv("VRT_DEBUG_FLAGS")) : 0;
+        if ((sa.debug_flags & ~(64 | 128)) || sa.debug_skip_levels) {
+            static bool warned = false;
+            if (!warned) std::fprintf(stderr, "[vrt] VRT_DEBUG_FLAGS / VRT_DEBUG_SKIP_LEVELS set: timing diagnostics, the results are WRONG\n");
+            warned = true;
+        }
         const int Lmax = std::max(ta.nlayers[0] * (use_dir[0] ? 1 : 0), ta.nlayers[1] * (use_dir[1] ? 1 : 0));
         const size_t lds = (size_t)std::max<int64_t>(p->tile_max_layer_size, 1) * sizeof(double2);
         // sites per thread of the level kernel: the fewest that cover the largest layer (its
