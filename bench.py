@@ -223,6 +223,18 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         },
         "setup_s": {"grid_generate": t_gen, "grid_create": t_grid, "plan_create": t_plan},
     }
+    # secondary bound: the dependency critical path of the sweep -- the same plan with
+    # ONE wavelength pair, where bandwidth plays no role and only the per-layer launch + Gauss-Seidel
+    # level chain of the most inclined angle is left
+    floor_ms = None
+    if rank == 0 and world == 1 and groups is None and not f32 and nlam > 2:
+        for _ in range(3):
+            plan.execute_dev(2, nlam, S.data_ptr(), alpha.data_ptr(), alpha_mode, w_mine,
+                             dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=False)
+        torch.cuda.synchronize()
+        floor_ms = plan.last_sweep_timing()[0]
+        step()                     # restore J of the full problem (parity check below)
+        torch.cuda.synchronize()
     # practical ceiling of this box beside the vendor peak: a device triad b = a + b
     # over 2 x 1 GB (2 reads + 1 write per element), measured live
     triad_gbs = None
@@ -254,6 +266,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
         "bytes_per_cell_update": bytes_per_update,
         "triad_ceiling_GBs": triad_gbs,
+        "critical_path_ms": floor_ms,
         "note": "duration = HIP events around the whole sequence of sweep launches of one step "
                 "(inter-kernel gaps included; layout transposes and the J reduction are outside "
                 "it but inside ms_per_step).  On the steps path the launches run on two internal "
