@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--shard", default="lambda", choices=["lambda", "angle"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary C2 measurement")
+    ap.add_argument("--no-critical-path", action="store_true",
+                    help="skip the one-wavelength-pair latency-floor measurement (profiling runs)")
     ap.add_argument("--cpu-lam", type=int, default=0, help="wavelengths in the CPU sample")
     ap.add_argument("--angle-groups", type=int, default=1,
                     help="diagnostics: run the angles in this many sequential groups (separate plans)")
@@ -227,7 +229,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     # ONE wavelength pair, where bandwidth plays no role and only the per-layer launch + Gauss-Seidel
     # level chain of the most inclined angle is left
     floor_ms = None
-    if rank == 0 and world == 1 and groups is None and not f32 and nlam > 2:
+    if rank == 0 and world == 1 and groups is None and not f32 and nlam > 2 and not args.no_critical_path:
         for _ in range(3):
             plan.execute_dev(2, nlam, S.data_ptr(), alpha.data_ptr(), alpha_mode, w_mine,
                              dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=False)
