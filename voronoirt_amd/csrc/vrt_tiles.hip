@@ -1026,12 +1026,8 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
             warned = true;
         }
         const int Lmax = std::max(ta.nlayers[0] * (use_dir[0] ? 1 : 0), ta.nlayers[1] * (use_dir[1] ? 1 : 0));
-        const size_t lds = (size_t)std::max<int64_t>(p->tile_max_layer_size, 1) * sizeof(double2);
-        // sites per thread of the level kernel: the fewest that cover the largest layer (its
-        // register-resident coefficients are 14 VGPRs per site); VRT_STEP_K forces more (tests)
-        int step_K = (int)((std::max<int64_t>(p->tile_max_layer_size, 1) + 1023) / 1024);
-        if (const char *e = std::getenv("VRT_STEP_K")) step_K = std::max(step_K, std::atoi(e));
-        step_K = std::max(1, std::min(step_K, 8));
+        const size_t lds_max = (size_t)std::max<int64_t>(p->tile_max_layer_size, 1) * sizeof(double2);
+        const int force_K = std::getenv("VRT_STEP_K") ? std::atoi(std::getenv("VRT_STEP_K")) : 0;
         // The angles are dealt (heaviest first) to a few internal streams that advance through
         // the layers independently: the (angle, wavelength) problems of different streams share
         // nothing, so one stream's launches fill the tail of the other's (612 level workgroups
@@ -1047,11 +1043,24 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         // needs ~3.5 us per launch, so a stream whose 2 (L - 1) launches were queued behind all of
         // another stream's would start a millisecond late and finish alone.
         const int ngrp = (npair + sa.pairs_per_thread - 1) / sa.pairs_per_thread;
-        const int per_xcd = (sa.chunks + 7) / 8;     // largest chunk range of an XCD
         if (G > 1)
             for (int gi = 0; gi < G; gi++) VRT_HIP_TRY(hipStreamWaitEvent(p->step_stream[gi], p->step_fork, 0));
         for (int layer = 2; layer <= Lmax; layer++) {
             sa.layer = layer;
+            // launch geometry from THIS layer's size (the larger of the two directions'): layers
+            // of a stratified tessellation differ severalfold
+            int64_t cnt_l = 1;
+            for (int d = 0; d < 2; d++) {
+                const Direction &dir = d == 0 ? g->up : g->down;
+                if (use_dir[d] && layer <= ta.nlayers[d])
+                    cnt_l = std::max<int64_t>(cnt_l, dir.reduced[(size_t)layer] - dir.reduced[(size_t)layer - 1]);
+            }
+            sa.chunks = (int)((cnt_l + 255) / 256);
+            const int per_xcd = (sa.chunks + 7) / 8;     // largest chunk range of an XCD
+            const size_t lds = std::min(lds_max, (size_t)cnt_l * sizeof(double2));
+            // sites per thread of the level kernel: the fewest that cover the layer (14 VGPRs of
+            // register-resident coefficients per site); VRT_STEP_K forces more (tests)
+            const int step_K = std::max(1, std::min(8, std::max(force_K, (int)((cnt_l + 1023) / 1024))));
             for (int gi = 0; gi < G; gi++) {
                 hipStream_t sg = G == 1 ? st : p->step_stream[gi];
                 const int n_list = p->step_group_off[gi + 1] - p->step_group_off[gi];
