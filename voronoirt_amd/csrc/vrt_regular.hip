@@ -157,15 +157,17 @@ __device__ __forceinline__ void row_march(int nx, int n_ser, int n_par, int s0, 
     double *__restrict__ sc_e = coef, *__restrict__ sc_aS = coef + cs, *__restrict__ sc_bS = coef + 2 * cs,
            *__restrict__ sc_q1 = coef + 3 * cs, *__restrict__ sc_q2 = coef + 4 * cs;
     if (act) {
-        Raw raw, raw2;
+        Raw raw, raw2, raw3;
         load(0, raw);
+        if (n_ser > 1) load(1, raw2);
         for (int q = 0; q < n_ser; q++) {
-            if (q + 1 < n_ser) load(q + 1, raw2);
+            if (q + 2 < n_ser) load(q + 2, raw3);          // two rows of loads in flight
             Pre o;
             prepare(raw, o);
             const size_t at = (size_t)q * (size_t)(n_par - 2) + (size_t)tid;
             sc_e[at] = o.e; sc_aS[at] = o.aS; sc_bS[at] = o.bS; sc_q1[at] = o.q1; sc_q2[at] = o.q2;
             raw = raw2;
+            raw2 = raw3;
         }
     }
     // (each thread reads back only what it wrote itself: no barrier needed)
@@ -188,12 +190,19 @@ __device__ __forceinline__ void row_march(int nx, int n_ser, int n_par, int s0, 
                 const double I_u = up ? reg_bilinear_rcp(wz2, wz1, wc2, wc1, rdz, rdc, cur.q1, cur.q2, row[pl], row[pu])
                                       : reg_bilinear_rcp(wz2, wz1, wc2, wc1, rdz, rdc, row[pl], row[pu], cur.q1, cur.q2);
                 const double v = (cur.e * I_u + cur.aS) + cur.bS;
-                // the new row goes to the plane and, with its periodic ghost zones, straight into
-                // the carried row in LDS (I_upper = I[idx, :] without a round trip through memory)
-                AT(Ic, sc, p) = v;
+                // the new row goes, with its periodic ghost zones, straight into the carried row in
+                // LDS (I_upper = I[idx, :] without a round trip through memory).  The plane in
+                // memory is only read back after the last sweep (as the next plane's upwind plane
+                // and by the ghost-column refresh), except that yz_up_ray refreshes its ghost
+                // columns from columns 1 and nx - 2 inside the sweeps: earlier sweeps store only those.
                 row_nxt[p] = v;
-                if (p == n_par - 2) { AT(Ic, sc, 0) = v; row_nxt[0] = v; }
-                if (p == 1) { AT(Ic, sc, n_par - 1) = v; row_nxt[n_par - 1] = v; }
+                if (p == n_par - 2) row_nxt[0] = v;
+                if (p == 1) row_nxt[n_par - 1] = v;
+                if (sweep == n_sweeps - 1 || (YZ && ghost_in_sweeps && (sc == 1 || sc == nx - 2))) {
+                    AT(Ic, sc, p) = v;
+                    if (p == n_par - 2) AT(Ic, sc, 0) = v;
+                    if (p == 1) AT(Ic, sc, n_par - 1) = v;
+                }
                 cur = nxt;
                 nxt = nxt2;
             }
@@ -211,7 +220,10 @@ __device__ __forceinline__ void row_march(int nx, int n_ser, int n_par, int s0, 
 #undef AT
 }
 
-__global__ void __launch_bounds__(1024)
+// MAXT = 256: the usual case (rows of up to 256 points: one thread per point, one wave per SIMD, so
+// the register allocator has the whole file and nothing spills); MAXT = 1024 for longer rows.
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT)
 k_regular_solve(RegArgs ra)
 {
     extern __shared__ __attribute__((aligned(16))) double rows[];  // carried row / column, double-buffered
@@ -537,7 +549,10 @@ extern "C" int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const do
     // such workgroups share a CU, which is where the batch's throughput comes from
     int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(128, (std::max(nx, ny) - 2 + 63) / 64 * 64));
     if (const char *e = std::getenv("VRT_REG_THREADS")) threads = std::max(64, std::min(1024, std::atoi(e) / 64 * 64));
-    hipLaunchKernelGGL(k_regular_solve, dim3((unsigned)n_solve), dim3((unsigned)threads), lds, st, ra);
+    if (threads <= 256)
+        hipLaunchKernelGGL(k_regular_solve<256>, dim3((unsigned)n_solve), dim3((unsigned)threads), lds, st, ra);
+    else
+        hipLaunchKernelGGL(k_regular_solve<1024>, dim3((unsigned)n_solve), dim3((unsigned)threads), lds, st, ra);
     VRT_HIP_TRY(hipEventRecord(r->ev[2], st));
     for (int64_t s = 0; s < n_solve; s++)
         hipLaunchKernelGGL(k_reg_from_planes, dim3(tb), dim3(256), 0, st, (int)nz, (int)nx, (int)ny, r->d_I + s * vol, dI_out + s * vol);
