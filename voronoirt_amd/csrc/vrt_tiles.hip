@@ -351,13 +351,14 @@ struct TileArgs {
     long long *dbg;                 // diagnostics (VRT_TILE_DEBUG=1): per task phase cycles, else NULL
 };
 
-template <int K>
-__global__ void __launch_bounds__(1024)
+// K sites per thread, phase-1 batches of B sites (their 12 B loads are in flight together), T threads
+// (768 = 3 waves per SIMD leaves 168 VGPRs per thread for B = 4; 1024 allows B = 2)
+template <int K, int B, int T>
+__global__ void __launch_bounds__(T)
 k_sweep_tiles(TileArgs ta)
 {
     extern __shared__ __attribute__((aligned(16))) double tile[];   // I of the current layer, then the constant terms
     double *cst = tile + ta.tile_stride;
-    const int T = 1024;
     const int tid = threadIdx.x;
     const int task = blockIdx.x;
     const int a = ta.task_map[task] & 0xFF;
@@ -392,16 +393,16 @@ k_sweep_tiles(TileArgs ta)
         uint32_t loc[K];        // in-layer tile slots of the two upwinds, 16 bits each
         uint32_t vis[K];
         // ---- phase 1: coefficients of every site of the layer (global reads -> registers).
-        // Straight-line, branch-free batches of two sites so that the 24 independent loads of a
+        // Straight-line, branch-free batches of B sites so that the 12 B independent loads of a
         // batch are in flight together (the dependent chain table -> gathers is paid per batch,
         // not per site); invalid slots are clamped to the layer's last site and masked via vis.
         // software pipeline: the table entries (upwind positions) of batch b+1 are requested
         // while batch b's data loads are in flight, so only the first batch of a layer pays the
         // dependent table -> gather latency.
-        int nu1[2], nu2[2];
-        uint32_t nvis[2];
+        int nu1[B], nu2[B];
+        uint32_t nvis[B];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < B; j++) {
             const int slot = tid + j * T;
             const int p = lo + min(slot, cnt - 1);
             nu1[j] = ldi(tu1, p);
@@ -409,19 +410,19 @@ k_sweep_tiles(TileArgs ta)
             nvis[j] = slot < cnt ? ldu(tvis, p) : 0u;
         }
 #pragma unroll
-        for (int kb = 0; kb < K; kb += 2) {
-            int pp[2], uu1[2], uu2[2];
+        for (int kb = 0; kb < K; kb += B) {
+            int pp[B], uu1[B], uu2[B];
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < B; j++) {
                 const int slot = tid + (kb + j) * T;
                 pp[j] = lo + min(slot, cnt - 1);
                 uu1[j] = nu1[j];
                 uu2[j] = nu2[j];
                 vis[kb + j] = nvis[j];
             }
-            double w1[2], w2[2], r1[2], r2[2], S_c[2], a_c[2], S_1[2], a_1[2], S_2[2], a_2[2], I_1[2], I_2[2];
+            double w1[B], w2[B], r1[B], r2[B], S_c[B], a_c[B], S_1[B], a_1[B], S_2[B], a_2[B], I_1[B], I_2[B];
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < B; j++) {
                 const int p = pp[j], u1 = uu1[j], u2 = uu2[j];
                 w1[j] = ldd(tw1, p); w2[j] = ldd(tw2, p); r1[j] = ldd(tr1, p); r2[j] = ldd(tr2, p);
                 S_c[j] = ldd(S, p); a_c[j] = ldd(Al, p);
@@ -430,10 +431,10 @@ k_sweep_tiles(TileArgs ta)
                 I_1[j] = ldd(I, min(u1, lo - 1));  // only used when u1 < lo (earlier layer: final)
                 I_2[j] = ldd(I, min(u2, lo - 1));
             }
-            if (kb + 2 < K) {
+            if (kb + B < K) {
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int slot = tid + (kb + 2 + j) * T;
+                for (int j = 0; j < B; j++) {
+                    const int slot = tid + (kb + B + j) * T;
                     const int p = lo + min(slot, cnt - 1);
                     nu1[j] = ldi(tu1, p);
                     nu2[j] = ldi(tu2, p);
@@ -441,7 +442,7 @@ k_sweep_tiles(TileArgs ta)
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < B; j++) {
                 const int u1 = uu1[j], u2 = uu2[j];
                 double ca, cb, ce;
                 lin_weights(r1[j] * (a_c[j] + a_1[j]) / 2.0, ca, cb, ce);   // trapezoidal, functions.jl:393
@@ -1096,10 +1097,18 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     if (A > 0) {
         const size_t lds = 2 * (size_t)ta.tile_stride * sizeof(double);
         const dim3 grid((unsigned)((size_t)A * (size_t)nlam));
+        // layers of up to 3072 sites: 768 threads x 4 sites in ONE phase-1 batch (the 168 VGPRs of
+        // 3 waves per SIMD hold its 48 loads); larger layers: 1024 threads, batches of two
+        const bool wide = p->tile_max_layer_size <= 3072 && !(std::getenv("VRT_TILE_WIDE") && std::atoi(std::getenv("VRT_TILE_WIDE")) == 0);
+        if (wide && p->tile_max_layer_size <= 1536)
+            hipLaunchKernelGGL((k_sweep_tiles<2, 2, 768>), grid, dim3(768), lds, st, ta);
+        else if (wide)
+            hipLaunchKernelGGL((k_sweep_tiles<4, 4, 768>), grid, dim3(768), lds, st, ta);
+        else
         switch (p->tile_K) {
-        case 2: hipLaunchKernelGGL(k_sweep_tiles<2>, grid, dim3(1024), lds, st, ta); break;
-        case 4: hipLaunchKernelGGL(k_sweep_tiles<4>, grid, dim3(1024), lds, st, ta); break;
-        default: hipLaunchKernelGGL(k_sweep_tiles<8>, grid, dim3(1024), lds, st, ta); break;
+        case 2: hipLaunchKernelGGL((k_sweep_tiles<2, 2, 1024>), grid, dim3(1024), lds, st, ta); break;
+        case 4: hipLaunchKernelGGL((k_sweep_tiles<4, 2, 1024>), grid, dim3(1024), lds, st, ta); break;
+        default: hipLaunchKernelGGL((k_sweep_tiles<8, 2, 1024>), grid, dim3(1024), lds, st, ta); break;
         }
         VRT_HIP_TRY(hipGetLastError());
     }
