@@ -674,10 +674,11 @@ def test_level_path_with_hipgraph_replay(grids, monkeypatch):
     plan.close()
 
 
-@pytest.mark.parametrize("a,c,K", [(26, 4, 2), (40, 4, 4), (52, 3, 8)])
+@pytest.mark.parametrize("a,c,K", [(26, 4, 2), (36, 3, 4), (40, 4, 4), (52, 3, 8)])
 def test_every_sites_per_thread_variant(a, c, K, path):
     """The LDS-tile kernels are instantiated for 2, 4 and 8 sites per thread (layers up to 2048 /
-    4096 / 8192 sites); each variant against the oracle on every path."""
+    4096 / 8192 sites; the persistent tile kernel also as 768 threads x 2 or 4 sites for layers up
+    to 1536 / 3072 sites: a = 26 and a = 36); each variant against the oracle on every path."""
     pos, nbr, bounds = synth.bcc_grid(a, c, seed=a)
     per_layer = 2 * a * a
     assert (K // 2) * 1024 < per_layer <= K * 1024
