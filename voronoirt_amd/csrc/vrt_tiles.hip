@@ -900,8 +900,16 @@ static int ensure_step_streams(vrt_plan *p, int G)
     });
     std::vector<int32_t> list;
     p->step_group_off.assign((size_t)G + 1, 0);
+    // two streams and as many up as down angles: one direction per stream, whose angles share the
+    // S planes and the storage order (C4 11.85 -> 11.70 ms); otherwise dealt heaviest first
+    const bool by_dir = G == 2 && p->n_up > 0 && std::abs(p->n_up - p->n_down) <= 1 &&
+                        !(std::getenv("VRT_STEP_GROUP_DIR") && std::atoi(std::getenv("VRT_STEP_GROUP_DIR")) == 0);
     for (int gi = 0; gi < G; gi++) {
         p->step_group_off[(size_t)gi] = (int)list.size();
+        if (by_dir) {                              // one direction per stream: its angles share the S planes
+            for (int j = 0; j < A; j++)
+                if ((p->dir_of_active[(size_t)order[(size_t)j]] > 0) == (gi == 0)) list.push_back(order[(size_t)j]);
+        } else
         for (int j = gi; j < A; j += G) list.push_back(order[(size_t)j]);
     }
     p->step_group_off[(size_t)G] = (int)list.size();
