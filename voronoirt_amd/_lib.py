@@ -10,6 +10,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvrt_hip.so")
+if os.environ.get("VRT_LIB_PATH"):      # host-only sanitizer build of the same sources (tools/asan_host.sh)
+    LIB_PATH = os.environ["VRT_LIB_PATH"]
 
 c_i64 = ctypes.c_int64
 c_dbl = ctypes.c_double
