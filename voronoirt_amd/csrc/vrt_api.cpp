@@ -160,6 +160,8 @@ static void free_plan(vrt_plan *p)
     dev_free(p->d_r2);
     dev_free(p->d_node_site);
     dev_free(p->d_node_meta);
+    dev_free(p->d_node_u1);
+    dev_free(p->d_node_u2);
     dev_free(p->d_angles_up);
     dev_free(p->d_angles_down);
     dev_free(p->d_I);
@@ -224,6 +226,8 @@ static int ensure_level_schedule(vrt_plan *p)
     std::vector<int32_t> srank_up((size_t)n);
     for (int64_t i = 0; i < n; i++) srank_up[(size_t)g->up.store[(size_t)i]] = (int32_t)i;
     std::vector<uint32_t> node_site((size_t)total), node_meta((size_t)total);
+    std::vector<int32_t> node_u1((size_t)total), node_u2((size_t)total);   // the node's upwind ids ride along:
+                                                                           // one dependent load less per launch
     p->level_off.assign((size_t)max_levels + 1, 0);
     int64_t at = 0;
     for (int64_t t = 0; t < max_levels; t++) {
@@ -243,6 +247,8 @@ static int ensure_level_schedule(vrt_plan *p)
                 const int64_t x = kv.second;
                 node_site[(size_t)at] = s.site[(size_t)x];
                 node_meta[(size_t)at] = (uint32_t)a | ((uint32_t)s.zflags[(size_t)x] << 8);
+                node_u1[(size_t)at] = p->h_up1[(size_t)a * (size_t)n + s.site[(size_t)x]];
+                node_u2[(size_t)at] = p->h_up2[(size_t)a * (size_t)n + s.site[(size_t)x]];
                 at++;
             }
         }
@@ -252,7 +258,11 @@ static int ensure_level_schedule(vrt_plan *p)
     int rc;
     if ((rc = dev_alloc(&p->d_node_site, (size_t)total))) return rc;
     if ((rc = dev_alloc(&p->d_node_meta, (size_t)total))) return rc;
+    if ((rc = dev_alloc(&p->d_node_u1, (size_t)total))) return rc;
+    if ((rc = dev_alloc(&p->d_node_u2, (size_t)total))) return rc;
     if (total) {
+        VRT_HIP_TRY(hipMemcpy(p->d_node_u1, node_u1.data(), sizeof(int32_t) * total, hipMemcpyHostToDevice));
+        VRT_HIP_TRY(hipMemcpy(p->d_node_u2, node_u2.data(), sizeof(int32_t) * total, hipMemcpyHostToDevice));
         VRT_HIP_TRY(hipMemcpy(p->d_node_site, node_site.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
         VRT_HIP_TRY(hipMemcpy(p->d_node_meta, node_meta.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
     }

@@ -97,6 +97,7 @@ struct vrt_plan {
     // level schedule, merged over the active angles
     uint32_t *d_node_site = nullptr;    // site id (0-based)
     uint32_t *d_node_meta = nullptr;    // active angle | zero-read flags
+    int32_t *d_node_u1 = nullptr, *d_node_u2 = nullptr;   // the node's upwind site ids (copied next to it)
     std::vector<int64_t> level_off;     // nodes of level t are [level_off[t], level_off[t+1])
     bool level_ready = false;           // the level schedule is built on first use
     std::vector<int32_t> h_up1, h_up2;  // host copies of the upwind ids (schedule building)

@@ -279,7 +279,7 @@ template <typename T, int ALPHA_MODE>
 __global__ void __launch_bounds__(256)
 k_sweep_level(int64_t first, int count, int nlam, int64_t n, int64_t ldS, int64_t ldA, int64_t ldI,
               const uint32_t *__restrict__ node_site, const uint32_t *__restrict__ node_meta,
-              const int32_t *__restrict__ up1, const int32_t *__restrict__ up2,
+              const int32_t *__restrict__ node_u1, const int32_t *__restrict__ node_u2,
               const double *__restrict__ w1, const double *__restrict__ w2,
               const double *__restrict__ r1, const double *__restrict__ r2,
               const T *__restrict__ S, const T *__restrict__ alpha, T *I)
@@ -299,7 +299,7 @@ k_sweep_level(int64_t first, int count, int nlam, int64_t n, int64_t ldS, int64_
     const uint32_t meta = node_meta[first + q];
     const unsigned a = meta & 0xFFu;
     const size_t row = (size_t)a * (size_t)n + site;
-    const int32_t u1 = up1[row], u2 = up2[row];
+    const int32_t u1 = node_u1[first + q], u2 = node_u2[first + q];   // (= up1[row], up2[row]: no dependent lookup)
     const double W1 = w1[row], W2 = w2[row], R1 = r1[row], R2 = r2[row];
 
     const T *Aa = alpha;
@@ -343,7 +343,7 @@ int launch_sweep_levels(vrt_plan *p, const SweepArgs &sa, hipStream_t st, int64_
 #define VRT_LAUNCH_SWEEP_T(TT, MODE)                                                               \
     hipLaunchKernelGGL((k_sweep_level<TT, MODE>), dim3((unsigned)blocks), dim3(256), 0, st, first, \
                        (int)cnt, (int)sa.nlam, sa.n, sa.ldS, sa.ldA, sa.ldI, p->d_node_site,       \
-                       p->d_node_meta, p->d_up1, p->d_up2, p->d_w1, p->d_w2, p->d_r1, p->d_r2,     \
+                       p->d_node_meta, p->d_node_u1, p->d_node_u2, p->d_w1, p->d_w2, p->d_r1, p->d_r2, \
                        (const TT *)sa.S, (const TT *)sa.alpha, (TT *)sa.I)
 #define VRT_LAUNCH_SWEEP(MODE)                                                                     \
     do {                                                                                           \
