@@ -80,6 +80,24 @@ function J_voronoi(S_λ::AbstractMatrix, α_tot::AbstractArray, I0_up::AbstractM
     return J * unit(eltype(S_λ))
 end
 
+# regular-grid short characteristics (src/characteristics.jl:19-95, :110-180): S_0, α are
+# (nz, nx, ny) Julia arrays, I_0 is (nx, ny); `atmos` contributes its three axes only
+function regular_solve(up::Bool, k, S_0::AbstractArray{<:Any,3}, I_0::AbstractMatrix, α::AbstractArray{<:Any,3},
+                       atmos; n_sweeps::Int=3, device::Integer=0)
+    z = Vector{Float64}(ustrip.(u"m", atmos.z)); x = Vector{Float64}(ustrip.(u"m", atmos.x))
+    y = Vector{Float64}(ustrip.(u"m", atmos.y))
+    S = Array{Float64,3}(ustrip.(S_0)); A = Array{Float64,3}(ustrip.(α)); I0 = Matrix{Float64}(ustrip.(I_0))
+    I = similar(S)
+    kk = Vector{Float64}(k); upv = Cint[up ? 1 : 0]
+    GC.@preserve z x y S A I0 I kk upv begin
+        check(ccall((:vrt_short_characteristics, libvrt), Cint,
+                    (Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Cint},
+                     Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Cint, Cint, Ptr{Float64}),
+                    length(z), length(x), length(y), z, x, y, 1, kk, upv, S, 0, A, 0, I0, n_sweeps, device, I))
+    end
+    return I * unit(eltype(S_0))
+end
+
 end # module
 
 # ---- drop-in redefinitions ----------------------------------------------------------------------
@@ -87,3 +105,9 @@ VoronoiRT.Delaunay_upII(k::Vector{Float64}, S, I_0, α, sites::VoronoiRT.Voronoi
     VoronoiRTHip.solve(:vrt_delaunay_up, k, S, I_0, α, sites, n_sweeps)
 VoronoiRT.Delaunay_downII(k::Vector{Float64}, S, I_0, α, sites::VoronoiRT.VoronoiSites, n_sweeps::Int) =
     VoronoiRTHip.solve(:vrt_delaunay_down, k, S, I_0, α, sites, n_sweeps)
+VoronoiRT.short_characteristics_up(k::Vector{Float64}, S_0, I_0, α, atmos::VoronoiRT.Atmosphere;
+                                   pt::Bool=false, n_sweeps::Int=3) =
+    VoronoiRTHip.regular_solve(true, k, S_0, I_0, α, atmos; n_sweeps=n_sweeps)
+VoronoiRT.short_characteristics_down(k::Vector{Float64}, S_0, I_0, α, atmos::VoronoiRT.Atmosphere;
+                                     pt::Bool=false, n_sweeps::Int=3) =
+    VoronoiRTHip.regular_solve(false, k, S_0, I_0, α, atmos; n_sweeps=n_sweeps)
