@@ -8,20 +8,31 @@ A "step" is one evaluation of the angle x wavelength loop of J_λ_voronoi
 already resident in HBM and the per-angle upwind tables / sweep schedule built beforehand (they
 depend on the grid and the quadrature only; their one-time cost is reported separately).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C4|C2|C3|tiny] [--nlam L]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C4|C2|C3|C5|tiny] [--nlam L]
+                    [--shard lambda|lambda-strong|angle]
 
-N > 1 is launched by torchrun (one rank per GPU, RCCL).  Default sharding is by wavelength
-block (each rank owns whole rows of J: no data-path collective, weak scaling: every rank solves
-`nlam` wavelengths of a global N*nlam problem).  `--shard angle` splits the angles instead and
-all-reduces J over RCCL each step (strong scaling).
+N > 1: one rank per GPU over RCCL.  Launched by `python -m torch.distributed.run ...` (RANK /
+WORLD_SIZE in the environment) the script joins that job; launched bare (`python bench.py --gpus 8`)
+it starts its own N ranks through torch.distributed.run BEFORE anything touches a GPU and relays
+rank 0's JSON line.  Sharding:
+  lambda         weak scaling, the default: every rank owns a block of `nlam` wavelengths of a global
+                 N x nlam problem and all angles for it, i.e. whole rows of J: no data-path collective
+  lambda-strong  the FIXED problem of the workload: its nlam wavelengths are split into contiguous
+                 blocks (51 over 8 ranks -> 7,7,7,6,6,6,6,6), every rank solves all angles for its
+                 block, J is all-gathered over RCCL each step
+  angle          strong scaling over the angles (needed when nlam < N): partial J's summed with one
+                 RCCL all-reduce per step -- the scheme BASELINE.json's north star names
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E vendor peak, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_ROUND = "r2"
 
 WORKLOADS = {
     # name: (a, c, quadrature, nlam, alpha per angle, seed)   -- SURVEY.md 8d, BASELINE.md sec. 3
@@ -42,14 +54,14 @@ WORKLOADS = {
 }
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
-    ap.add_argument("--nlam", type=int, default=0, help="override wavelengths per rank")
-    ap.add_argument("--shard", default="lambda", choices=["lambda", "angle"])
+    ap.add_argument("--nlam", type=int, default=0, help="override the workload's wavelength count")
+    ap.add_argument("--shard", default="lambda", choices=["lambda", "lambda-strong", "angle"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary C2 measurement")
     ap.add_argument("--no-critical-path", action="store_true",
@@ -59,41 +71,79 @@ def parse_args():
                     help="diagnostics: run the angles in this many sequential groups (separate plans)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
                     help="storage type of S, alpha, I, J (arithmetic is always fp64)")
+    ap.add_argument("--alpha-layout", default="native", choices=["native", "caller"],
+                    help="per-angle alpha handed over in the library's native storage-pair layout "
+                         "(converted once before the timed region, the way a producer such as the "
+                         "opacity prologue writes it) or in the caller's (n_angles, n, nlam) layout "
+                         "(transposed inside every step)")
     ap.add_argument("--alpha0", type=float, default=1.0e-2,
                     help="opacity scale at z_min [1/m] (diagnostics: tiny values take the Taylor branch)")
-    return ap.parse_args()
+    ap.add_argument("--dump-J", default="", help="rank 0 saves the (gathered) J of the last step as .npy")
+    return ap.parse_args(argv)
 
 
-def pmc_traffic_per_launch(workload, path, nlam, world, launches):
-    """HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes of this same
-    command (profiles/r1/c4_summary.json; PMC counters cannot be read from inside the run).
-    bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B): on gfx950 FETCH_SIZE tallies the 128-B
-    requests of these streams at 64 B (MI355X_MICROARCH.md, HBM section).  None when the
-    configuration differs from the profiled one."""
+def source_digest() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources: ties a committed PMC profile to the
+    library it was taken with."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "voronoirt_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+ONE_TIME_KERNELS = ("k_upwind_table", "k_permute_table", "k_delaunay_lines", "k_sorted_tables", "k_gpos")
+
+
+def pmc_traffic_per_step(workload, path, nlam, world, alpha_layout):
+    """Fabric-side bytes of ONE step from the committed rocprofv3 PMC passes of this same command
+    (profiles/<round>/c4_summary.json; PMC counters cannot be read from inside the run).
+    bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B): on gfx950 FETCH_SIZE tallies the 128-B requests
+    of these streams at 64 B (MI355X_MICROARCH.md, HBM section).  None unless the profile was
+    taken with exactly this library (source digest), workload, path and layout."""
     if workload != "C4" or nlam != WORKLOADS["C4"][3] or world != 1:
         return None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r1", "c4_summary.json")))
-        tag = {"steps": "steps_default", "levels": "levels", "tiles": "tiles"}[path]
-        kernels = {"steps": ("k_step_coeffs", "k_step_levels"), "levels": ("k_sweep_level",),
-                   "tiles": ("k_sweep_tiles",)}[path]
+        prof = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "c4_summary.json")))
+        if prof.get("source_digest") != source_digest() or prof.get("alpha_layout") != alpha_layout \
+                or prof.get("path") != path:
+            return None
         total = 0.0
-        for name, c in prof["pmc_one_step"][tag].items():
-            if any(k in name for k in kernels):
-                total += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-        return total / max(launches, 1) if total > 0 else None
+        for name, c in prof["pmc_one_step"].items():
+            if name.startswith(("vrt::", "void vrt::")) and not any(k in name for k in ONE_TIME_KERNELS):
+                total += (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0
+        return total if total > 0 else None
     except Exception:
         return None
+
+
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, world, local, dev, rehearse,
             steps, warmup, cpu_baseline):
     """One workload: setup, warm-up, timed steps, roofline, optional CPU baseline.  Returns the
     result dict (rank 0 holds the CPU baseline / parity fields)."""
-    a, c, quad, nlam, per_angle, seed = WORKLOADS[workload]
+    a, c, quad, nlam_total, per_angle, seed = WORKLOADS[workload]
     if args.nlam > 0 and workload == args.workload:
-        nlam = args.nlam
+        nlam_total = args.nlam
+    shard = args.shard if world > 1 else "lambda"
     weights, theta, phi, n_angles = vrt.read_quadrature(quad)
+
+    # wavelengths this rank solves: its own block of `nlam_total` (weak), or its part of the fixed set
+    lam_lo, lam_hi = 0, nlam_total
+    if shard == "lambda-strong":
+        lam_lo, lam_hi = distributed.partition(nlam_total, world, rank)
+    nlam = lam_hi - lam_lo
 
     # ---- one-time setup (untimed; reported) --------------------------------------------------
     t0 = time.time()
@@ -105,7 +155,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     n = sites.n
 
     my_angles = np.arange(n_angles)
-    if args.shard == "angle" and world > 1:
+    if shard == "angle":
         my_angles = distributed.angle_assignment(theta, world)[rank]
     k_all = vrt.quadrature_directions(theta, phi)
     dirs_all = np.array([1 if t > 90 else (-1 if t < 90 else 0) for t in theta])
@@ -115,28 +165,37 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     A = len(my_angles)
 
     # ---- synthetic fields, generated on the device (SURVEY 8d shapes) -------------------------
+    # the fixed-problem modes (lambda-strong, angle) generate the SAME global field on every rank
+    # (same seed) and keep their part of it, so the N-rank J can be compared with the 1-rank J
     gen = torch.Generator(device=dev)
-    gen.manual_seed(seed + 1000 * rank)
+    gen.manual_seed(seed + (1000 * rank if shard == "lambda" else 0))
     z = torch.as_tensor(pos[:, 0], device=dev)
     z_min, z_max = bounds[0], bounds[1]
-    lam = torch.arange(nlam, device=dev, dtype=torch.float64)
-    centre, sigma = 0.5 * (nlam - 1), max(nlam / 6.0, 1.0)
+    lam = torch.arange(nlam_total, device=dev, dtype=torch.float64)
+    centre, sigma = 0.5 * (nlam_total - 1), max(nlam_total / 6.0, 1.0)
     S = 1.0 + 0.5 * torch.sin(2 * np.pi * (z - z_min) / (z_max - z_min))[:, None] \
-        + 0.1 * torch.rand((n, nlam), generator=gen, device=dev, dtype=torch.float64)
+        + 0.1 * torch.rand((n, nlam_total), generator=gen, device=dev, dtype=torch.float64)
     strat = args.alpha0 * torch.exp(-(z - z_min) / 0.7e6)
     if per_angle:
         alpha = torch.empty((A, n, nlam), device=dev, dtype=torch.float64)
-        for j, ai in enumerate(my_angles):
+        mine = {int(x): j for j, x in enumerate(my_angles)}
+        for ai in range(n_angles):           # every rank draws the same stream and keeps its angles
+            if ai not in mine and shard == "lambda":
+                continue
             shift = 0.15 * sigma * np.cos(2 * np.pi * ai / n_angles)
             psi = 1.0 + 9.0 * torch.exp(-((lam - centre - shift) / sigma) ** 2)
-            alpha[j] = strat[:, None] * (1.0 + 0.1 * torch.rand((n, nlam), generator=gen, device=dev,
-                                                                 dtype=torch.float64)) * psi[None, :]
+            noise = torch.rand((n, nlam_total), generator=gen, device=dev, dtype=torch.float64)
+            if ai in mine:
+                alpha[mine[ai]] = (strat[:, None] * (1.0 + 0.1 * noise) * psi[None, :])[:, lam_lo:lam_hi]
+            del noise
         alpha_mode = _lib.ALPHA_ANGLE_SITE_LAM
     else:
         psi = 1.0 + 9.0 * torch.exp(-((lam - centre) / sigma) ** 2)
-        alpha = strat[:, None] * (1.0 + 0.1 * torch.rand((n, nlam), generator=gen, device=dev,
-                                                         dtype=torch.float64)) * psi[None, :]
+        alpha = (strat[:, None] * (1.0 + 0.1 * torch.rand((n, nlam_total), generator=gen, device=dev,
+                                                          dtype=torch.float64)) * psi[None, :])[:, lam_lo:lam_hi]
+        alpha = alpha.contiguous()
         alpha_mode = _lib.ALPHA_SITE_LAM
+    S = S[:, lam_lo:lam_hi].contiguous()
     n1_up = int(sites.layers_up[1] - 1)
     bottom = torch.as_tensor(sites.perm_up[:n1_up] - 1, device=dev)
     I0_up = S[bottom].contiguous()          # I_0 = S at the bottom layer for up rays; down: zeros
@@ -146,8 +205,15 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         S, alpha, I0_up, J = (t.to(torch.float32).contiguous() for t in (S, alpha, I0_up, J))
     w_mine = weights[my_angles]
     torch.cuda.synchronize()
-
     stream = torch.cuda.current_stream().cuda_stream
+
+    alpha_native = None
+    if per_angle and not f32 and args.alpha_layout == "native" and args.angle_groups == 1:
+        # one-time layout change outside the timed region: per-angle alpha is produced once per
+        # Λ-iteration (lambda_iteration.jl:89-96) -- by vrt_line_opacity_dev directly in this layout
+        alpha_native = torch.empty(plan.native_alpha_count(nlam), device=dev, dtype=torch.float64)
+        plan.alpha_to_native_dev(nlam, nlam, alpha.data_ptr(), alpha_native.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
 
     groups = None
     if args.angle_groups > 1:
@@ -162,21 +228,29 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
             ga = alpha[ch].contiguous() if per_angle else alpha
             groups.append((gp, ga, w_mine[ch], torch.zeros_like(J)))
 
+    gathered = {}     # lambda-strong: the gathered (n, nlam_total) J of the last step
+
     def step():
         if groups is not None:
             for gp, ga, gw, gJ in groups:
                 gp.execute_dev(nlam, nlam, S.data_ptr(), ga.data_ptr(), alpha_mode, gw,
                                dJ=gJ.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
             return
-        plan.execute_dev(nlam, nlam, S.data_ptr(), alpha.data_ptr(), alpha_mode, w_mine,
-                         dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
-        if args.shard == "angle" and world > 1:
+        if alpha_native is not None:
+            plan.execute_dev(nlam, nlam, S.data_ptr(), alpha_native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE,
+                             w_mine, dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream)
+        else:
+            plan.execute_dev(nlam, nlam, S.data_ptr(), alpha.data_ptr(), alpha_mode, w_mine,
+                             dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
+        if world > 1 and shard == "angle":
             if rehearse:       # gloo reduces host tensors
                 Jh = J.cpu()
                 distributed.allreduce_J(Jh)
                 J.copy_(Jh)
             else:
                 distributed.allreduce_J(J)
+        elif world > 1 and shard == "lambda-strong":
+            gathered["J"] = distributed.allgather_J_lambda(J.cpu() if rehearse else J, nlam_total)
 
     def barrier():
         if world > 1:
@@ -186,42 +260,47 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         step()
     torch.cuda.synchronize()
     barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    ev0.record()              # on the stream the library launches on (its internal streams fork from and
+    for _ in range(steps):    # join back into it, so the pair brackets every kernel of the steps)
         step()
+    ev1.record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_event_ms = ev0.elapsed_time(ev1) / steps
     if groups is not None:
         tl = [gp.last_sweep_timing() for gp, _, _, _ in groups]
         sweep_ms, launches = sum(t[0] for t in tl), sum(t[1] for t in tl)
     else:
-        sweep_ms, launches = plan.last_sweep_timing()    # HIP events on the launch stream, last step
+        sweep_ms, launches = plan.last_sweep_timing()    # HIP events around the sweep launches, last step
     if world > 1:
         tmax = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     # cell-updates: one (site, direction, wavelength) intensity incl. its 3 sweeps
-    if args.shard == "angle":
-        updates_per_step = n * n_angles * nlam            # strong: the whole job, split by angle
-    else:
+    if shard == "lambda":
         updates_per_step = n * n_angles * nlam * world    # weak: every rank adds a λ block
+    else:
+        updates_per_step = n * n_angles * nlam_total      # strong: the whole fixed job
     ms_per_step = elapsed / steps * 1e3
     value = updates_per_step / (elapsed / steps)
 
     out = {
         "metric": "formal-solve cell-updates/sec", "value": value, "unit": "cell-updates/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "strong" if args.shard == "angle" else "weak",
+        "higher_is_better": True, "scaling": "weak" if shard == "lambda" else "strong",
         "vs_baseline": None, "dtype": "f64", "storage_dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": f"{workload}: jittered-BCC Voronoi grid a={a} c={c} ({n} sites, "
                         f"L_up={len(sites.layers_up) - 1} layers), {quad} ({n_angles} angles), "
-                        f"nlam={nlam} per rank, alpha per "
-                        f"{'angle,site,lambda' if per_angle else 'site,lambda'}, n_sweeps=3",
-            "sites": n, "angles": n_angles, "nlam_per_rank": nlam, "shard": args.shard,
-            "schedule_levels": plan.num_levels, "live_visits_per_site_angle": plan.num_nodes / (n * A),
+                        f"nlam={nlam} on this rank of {nlam * world if shard == 'lambda' else nlam_total} in the job, "
+                        f"alpha per {'angle,site,lambda' if per_angle else 'site,lambda'}"
+                        f"{' (native storage-pair layout)' if alpha_native is not None else ''}, n_sweeps=3",
+            "sites": n, "angles": n_angles, "nlam_per_rank": nlam, "shard": shard,
+            "alpha_layout": "native" if alpha_native is not None else "caller",
         },
         "setup_s": {"grid_generate": t_gen, "grid_create": t_grid, "plan_create": t_plan},
     }
@@ -251,36 +330,47 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         torch.cuda.synchronize()
         triad_gbs = 10 * 3 * ta_.numel() * 8 / (time.perf_counter() - t0) / 1e9
         del ta_, tb_
-    # roofline of the dominant kernel (k_sweep_level): algorithmic bytes / event-timed duration
-    bytes_per_update = (20.0 if f32 else 40.0) + 40.0 / nlam
+    # ---- roofline: algorithmic bytes of the WHOLE step / HIP-event time of the whole step -------
+    # read S_c, α_c + write I + read-modify-write J = 40 B (20 B for fp32 values) per
+    # cell-update, + the 40-B upwind-table entry per (site, angle) amortised over the wavelengths
+    v = 4.0 if f32 else 8.0
+    bytes_per_update = 5.0 * v + 40.0 / nlam
     local_updates = n * A * nlam
     alg_bytes = local_updates * bytes_per_update
-    achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (step_event_ms * 1e-3) / 1e9
+    sweep_bytes = local_updates * (3.0 * v + 40.0 / nlam)        # without the J read-modify-write
     out["roofline"] = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": pmc_traffic_per_launch(workload, plan.last_path, nlam, world, launches),
+        "traffic": pmc_traffic_per_step(workload, plan.last_path, nlam, world,
+                                        "native" if alpha_native is not None else "caller"),
         "kernel": {"levels": "k_sweep_level (one launch per dependency level)",
                    "steps": "k_step_coeffs + k_step_levels (two launches per BFS layer)",
                    "tiles": "k_sweep_tiles (one persistent launch)"}.get(plan.last_path, plan.last_path),
         "path": plan.last_path, "launches_per_step": launches,
-        "sweep_ms_per_step": sweep_ms, "avg_launch_us": sweep_ms * 1e3 / max(launches, 1),
+        "step_event_ms": step_event_ms,
+        "algorithmic_bytes_per_step": alg_bytes,
         "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
+        "avg_launch_us": step_event_ms * 1e3 / max(launches, 1),
         "bytes_per_cell_update": bytes_per_update,
         "triad_ceiling_GBs": triad_gbs,
         "critical_path_ms": floor_ms,
-        "note": "duration = HIP events around the whole sequence of sweep launches of one step "
-                "(inter-kernel gaps included; layout transposes and the J reduction are outside "
-                "it but inside ms_per_step).  On the steps path the launches run on two internal "
-                "streams and overlap, so window / launches is shorter than the per-kernel average "
-                "rocprofv3 reports (VRT_STEP_STREAMS=1 serialises them)",
+        "sweep_only": {"ms": sweep_ms, "bytes_per_cell_update": 3.0 * v + 40.0 / nlam,
+                       "achieved": sweep_bytes / (sweep_ms * 1e-3) / 1e9,
+                       "frac": sweep_bytes / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "note": "achieved = algorithmic bytes of one whole step (sweep + layout changes + J reduction) / "
+                "HIP-event time of the whole step on the launch stream (traffic and achieved are per "
+                "step; per launch = / launches_per_step); `traffic` = fabric-side bytes of one step from "
+                "the committed rocprofv3 PMC passes, quoted only when that profile was taken with this "
+                "exact library; sweep_only = the sweep launches alone, with bytes that exclude the "
+                "16 B/update J read-modify-write done outside that window",
     }
 
     # ---- CPU baseline: the oracle, threaded the way the reference is (angles serial, λ split
     # over threads), on a bounded sample of the same workload; also a full-size parity check ----
     if rank == 0 and world == 1 and cpu_baseline:      # reported at N = 1 only
         from oracle import oracle as orc
-        cores = min(len(os.sched_getaffinity(0)), 16)
+        cores = len(os.sched_getaffinity(0))
         lam_s = args.cpu_lam if args.cpu_lam > 0 else min(nlam, cores)
         t0 = time.time()
         so = orc.make_sites(pos, nbr, bounds)
@@ -296,25 +386,47 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
                               nthreads=cores)
         t_cpu = time.time() - t0
         cpu_updates = n * A * lam_s
+        # T = 1: one wavelength, all angles, one thread (T = 1 and T = all cores)
+        al1 = np.ascontiguousarray(al_h[:, :, :1] if per_angle else al_h[:, :1])
+        t0 = time.time()
+        orc.J_voronoi(w_mine, theta[my_angles], phi[my_angles], np.ascontiguousarray(S_h[:, :1]), al1, so,
+                      I0_up=np.ascontiguousarray(I0_h[:, :1]), nthreads=1)
+        t_cpu1 = time.time() - t0
         J_gpu = J[:, :lam_s].cpu().numpy().astype(np.float64)
-        if args.shard == "angle" and world > 1:
-            parity = None    # J holds the all-reduced sum of every rank's angles
-        else:
-            parity = float(np.abs(J_gpu - J_ref).max() / np.abs(J_ref).max())
+        parity = float(np.abs(J_gpu - J_ref).max() / np.abs(J_ref).max())
         out["cpu_baseline"] = {
-            "value": cpu_updates / t_cpu, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "value": cpu_updates / t_cpu, "unit": "cell-updates/s", "cores": min(cores, lam_s), "kind": "port",
             "sample": f"same grid and fields, all {A} angles x the first {lam_s} of {nlam} "
                       f"wavelengths ({cpu_updates} cell-updates in {t_cpu:.1f} s wall); oracle "
                       f"restatement threaded over wavelengths like Threads.@threads; its grid "
                       f"prep (read_cell equivalent) took {t_osites:.1f} s and is not counted",
             "seconds": t_cpu,
+            "single_thread": {"value": n * A / t_cpu1, "unit": "cell-updates/s", "cores": 1, "seconds": t_cpu1,
+                              "sample": f"all {A} angles x 1 wavelength ({n * A} cell-updates)"},
+            "cpu_model": cpu_model(), "host_cores": cores,
         }
         out["parity_vs_oracle_max_rel_err"] = parity
+    if args.dump_J and rank == 0:
+        np.save(args.dump_J, (gathered["J"] if "J" in gathered else J).cpu().numpy())
     return out
+
+
+def launch_own_ranks(args) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves, before
+    this process has touched a GPU, and exit with the job's code (rank 0 prints the JSON line)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_own_ranks(args))
+
     import torch
     import torch.distributed as dist
 
@@ -328,7 +440,7 @@ def main():
     rehearse = os.environ.get("VRT_BENCH_REHEARSE") == "1"
     rank, world = distributed.init_process_group("gloo" if rehearse else None)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = 0 if rehearse else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -1,6 +1,13 @@
 /* Plain-C caller of libvrt_hip.so: plays the role of the reference's Julia host (which cannot be
- * run in the build image) -- builds a tiny periodic lattice grid, runs Delaunay_upII through the
- * C ABI and prints the intensities.  Build:
+ * run in the build image).
+ *   scenario 1 (default):   a tiny periodic lattice grid, Delaunay_upII through the C ABI, prints
+ *                           the intensities -- the direct call sites of compare_searchlight.jl
+ *   scenario 2 (argv[1]=2): exactly the caller julia/VoronoiRT_hip.jl's J_line is -- the body of
+ *                           J_λ_voronoi (src/lambda_iteration.jl:60-113) with the formal solves
+ *                           batched: ul7n12's 12 angles, 5 wavelengths, alpha_tot per (λ, site,
+ *                           angle), I_0 of the bottom layer for the up rays, ONE
+ *                           vrt_plan_execute, prints J (nλ, n)
+ * Build:
  *   gcc -std=c99 -I include examples/c_caller.c -o c_caller -L voronoirt_amd -lvrt_hip \
  *       -Wl,-rpath,$PWD/voronoirt_amd -lm
  * Needs a HIP device at run time (the library has no CPU fallback). */
@@ -10,11 +17,66 @@
 
 #include "voronoirt.h"
 
-int main(void)
+/* quadratures/ul7n12.dat: weight, θ [deg], ϕ [deg] */
+static const double UL7N12[12][3] = {
+    {0.062174023651822, 70.292581108446825, 346.412955051617416},
+    {0.062174023651822, 109.707418891553175, 193.587044948382584},
+    {0.078304613457687, 152.666292044518485, 315.475247829748128},
+    {0.078304613457687, 27.333707955481518, 135.475247829748128},
+    {0.090740740740741, 147.207528953818269, 135.743688985642649},
+    {0.090740740740741, 67.175739518129632, 155.790538127899197},
+    {0.090740740740741, 32.792471046181731, 44.256311014357351},
+    {0.090740740740741, 112.824260481870382, 335.790538127899197},
+    {0.084923207761833, 101.810709392034880, 235.428463450411130},
+    {0.084923207761833, 78.189290607965106, 55.428463450411122},
+    {0.093116673647177, 65.132900950498197, 260.165664821292125},
+    {0.093116673647177, 114.867099049501803, 80.165664821292154}};
+
+/* the J_λ_voronoi caller: all angles x all wavelengths in one batched execute */
+static int scenario_J(vrt_grid *g, int n)
 {
-    /* 3 x 3 x 4 simple-cubic lattice in the unit cube, 6 neighbours per site, x/y periodic,
+    enum { NA = 12, NLAM = 5 };
+    double k[3 * NA], w[NA];
+    int dirs[NA];
+    for (int a = 0; a < NA; a++) {
+        w[a] = UL7N12[a][0];
+        vrt_direction(UL7N12[a][1], UL7N12[a][2], k + 3 * a);     /* lambda_iteration.jl:87 */
+        dirs[a] = UL7N12[a][1] > 90 ? 1 : (UL7N12[a][1] < 90 ? -1 : 0);   /* :98,104 */
+    }
+    vrt_plan *plan = NULL;
+    if (vrt_plan_create_ex(g, NA, k, dirs, 3, &plan)) {
+        fprintf(stderr, "vrt_plan_create_ex: %s\n", vrt_last_error());
+        return 1;
+    }
+    int64_t nl = vrt_grid_num_layer_offsets(g, +1);
+    int64_t *layers = malloc(sizeof(int64_t) * (size_t)nl);
+    vrt_grid_get_layers(g, +1, layers);
+    const int64_t n1 = layers[1] - 1;
+    double *S = malloc(sizeof(double) * NLAM * (size_t)n), *J = malloc(sizeof(double) * NLAM * (size_t)n);
+    double *alpha = malloc(sizeof(double) * NLAM * (size_t)n * NA), *I0 = malloc(sizeof(double) * NLAM * (size_t)n1);
+    for (int i = 0; i < n; i++)
+        for (int l = 0; l < NLAM; l++) {
+            S[l + NLAM * i] = 1.0 + 0.1 * ((i * 7 + l * 3) % 11);          /* S_λ (nλ, n) */
+            for (int a = 0; a < NA; a++)                                      /* α_tot (nλ, n, n_angles), :93-96 */
+                alpha[l + NLAM * (i + (size_t)n * a)] = 0.5 + 0.05 * ((i + 2 * l + 3 * a) % 13);
+        }
+    for (int64_t p = 0; p < n1; p++)
+        for (int l = 0; l < NLAM; l++) I0[l + NLAM * p] = 2.0 + 0.25 * ((p + l) % 5);   /* B_λ(T) of perm_up[1:n1], :99-101 */
+    int rc = vrt_plan_execute(plan, NLAM, NLAM, S, alpha, VRT_ALPHA_ANGLE_SITE_LAM, I0, NULL, w, J, NULL);
+    if (rc) fprintf(stderr, "vrt_plan_execute: %s\n", vrt_last_error());
+    else
+        for (int i = 0; i < n; i++)
+            for (int l = 0; l < NLAM; l++) printf("%d %d %.17g\n", i + 1, l + 1, J[l + NLAM * i]);
+    free(S); free(J); free(alpha); free(I0); free(layers);
+    vrt_plan_destroy(plan);
+    return rc ? 1 : 0;
+}
+
+int main(int argc, char **argv)
+{
+    /* 4 x 5 x 6 simple-cubic lattice in the unit cube, 6 neighbours per site, x/y periodic,
      * walls -5 (bottom) / -6 (top): the reference's conventions (voronoi_utils.jl:97,141) */
-    enum { NX = 3, NY = 3, NZ = 4, N = NX * NY * NZ, D1 = 7 };
+    enum { NX = 4, NY = 5, NZ = 6, N = NX * NY * NZ, D1 = 7 };
     static double pos[3 * N];
     static int64_t nbr[N * D1];
     for (int i = 0; i < NX; i++)
@@ -40,6 +102,11 @@ int main(void)
     if (vrt_grid_create(N, pos, nbr, D1, bounds, 0, &g)) {
         fprintf(stderr, "vrt_grid_create: %s\n", vrt_last_error());
         return 1;
+    }
+    if (argc > 1 && atoi(argv[1]) == 2) {
+        int rc = scenario_J(g, N);
+        vrt_grid_destroy(g);
+        return rc;
     }
     int64_t nl = vrt_grid_num_layer_offsets(g, +1);
     int64_t *layers = malloc(sizeof(int64_t) * (size_t)nl);

@@ -45,6 +45,13 @@ typedef struct vrt_plan vrt_plan;   /* per-(grid, angle set) upwind tables + swe
 #define VRT_ALPHA_SITE 0        /* alpha[n]                 same for every wavelength and angle  */
 #define VRT_ALPHA_SITE_LAM 1    /* alpha[n][ld]             same for every angle (continuum)      */
 #define VRT_ALPHA_ANGLE_SITE_LAM 2 /* alpha[n_angles][n][ld] per angle (line: lambda_iteration.jl:89-96) */
+/* per angle, already in the library's NATIVE layout (device entry points only): for every angle a
+ * block of vrt_plan_native_alpha_count / n_angles doubles holding wavelength PAIRS side by side,
+ * element (l, pos) at ((l/2) * n + pos) * 2 + l%2 with pos = the site's position in the storage
+ * order of the angle's direction (vrt_grid_get_storage_order); an odd nlam is padded with one
+ * finite wavelength.  Written by vrt_plan_alpha_to_native_dev or vrt_line_opacity_dev; saves the
+ * 2 x 8 B per (site, angle, wavelength) of the layout change on every execute. */
+#define VRT_ALPHA_ANGLE_NATIVE 3
 
 const char *vrt_last_error(void);
 int vrt_version(void);
@@ -113,6 +120,17 @@ int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS
                          const double *dalpha, int alpha_mode, const double *dI0_up,
                          const double *dI0_down, const double *weights_host, double *dJ,
                          double *dI_out, void *stream);
+/* ---- native layout of per-angle alpha (VRT_ALPHA_ANGLE_NATIVE) ------------------------------
+ * storage order of a direction: out[pos] = 1-based site id at storage position pos (layers
+ * contiguous like perm_up / perm_down, sites of a layer along a Morton curve over (x, y)). */
+int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out);
+/* number of doubles of the native per-angle alpha buffer for nlam wavelengths */
+int64_t vrt_plan_native_alpha_count(const vrt_plan *p, int64_t nlam);
+/* converts the caller's (nlam, n, n_angles) alpha (VRT_ALPHA_ANGLE_SITE_LAM) once, e.g. per
+ * Λ-iteration when alpha changes, so that every execute of that iteration reads it in place */
+int vrt_plan_alpha_to_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha,
+                                 double *dalpha_native, void *stream);
+
 /* fp32 VALUE path (BASELINE config C5): S, alpha, I_0, J and the per-angle intensities are stored
  * as float, halving the bytes of this bandwidth-bound path; the geometry tables and all
  * arithmetic stay fp64.  Results agree with the fp64 solve to fp32 storage rounding (~1e-6

@@ -17,6 +17,21 @@ REF = "/root/reference/data/searchlight_data"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+RADIAL_EDGES = [0.0, 0.03, 0.06, 0.09, 0.12, 0.15, 0.18, 0.21]
+
+
+def radial_profile(a, c0, c1):
+    """Mean intensity in annuli around the beam centroid (periodic distances, box = 1)."""
+    n = a.shape[0]
+    g = (np.arange(n) + 0.5) / n
+    d0 = np.abs(g - c0) % 1.0
+    d0 = np.minimum(d0, 1.0 - d0)
+    d1 = np.abs(g - c1) % 1.0
+    d1 = np.minimum(d1, 1.0 - d1)
+    r = np.sqrt(d0[:, None] ** 2 + d1[None, :] ** 2)
+    return [float(a[(r >= lo) & (r < hi)].mean()) for lo, hi in zip(RADIAL_EDGES[:-1], RADIAL_EDGES[1:])]
+
+
 def stats(a):
     n = a.shape[0]
     ang = 2 * np.pi * (np.arange(n) + 0.5) / n
@@ -27,7 +42,8 @@ def stats(a):
     r0 = float(abs((w0 * np.exp(1j * ang)).sum()) / w0.sum())
     r1 = float(abs((w1 * np.exp(1j * ang)).sum()) / w1.sum())
     return {"centroid": [c0, c1], "resultant": [r0, r1], "mean": float(a.mean()), "max": float(a.max()),
-            "frac_above_0.05": float((a > 0.05).mean())}
+            "frac_above_0.05": float((a > 0.05).mean()),
+            "radial_edges": RADIAL_EDGES, "radial_profile": radial_profile(a, c0, c1)}
 
 
 out = {}

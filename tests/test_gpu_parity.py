@@ -507,20 +507,8 @@ def test_fp32_value_path_against_fp64_oracle(grids):
     plan.close()
 
 
-def test_plain_c_caller_matches_oracle(tmp_path):
-    """examples/c_caller.c -- a C host standing in for the Julia caller -- gives the oracle's answer."""
-    import os
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    libdir = os.path.join(root, "voronoirt_amd")
-    exe = tmp_path / "c_caller"
-    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"),
-                           os.path.join(root, "examples", "c_caller.c"), "-o", str(exe),
-                           "-L", libdir, "-lvrt_hip", f"-Wl,-rpath,{libdir}", "-lm"])
-    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr
-    got = np.array([float(ln.split()[1]) for ln in out.stdout.strip().splitlines()])
-    nx, ny, nz = 3, 3, 4
+def _c_caller_lattice():
+    nx, ny, nz = 4, 5, 6
     n = nx * ny * nz
     pos = np.zeros((n, 3))
     nbr = np.zeros((7, n), dtype=np.int64)
@@ -533,9 +521,56 @@ def test_plain_c_caller_matches_oracle(tmp_path):
                 nbr[1:, s] = [((i + 1) % nx * ny + j) * nz + k + 1, ((i - 1) % nx * ny + j) * nz + k + 1,
                               (i * ny + (j + 1) % ny) * nz + k + 1, (i * ny + (j - 1) % ny) * nz + k + 1,
                               s + 2 if k + 1 < nz else -6, s if k > 0 else -5]
-    so = orc.make_sites(pos, nbr, (0, 1, 0, 1, 0, 1))
+    return n, orc.make_sites(pos, nbr, (0, 1, 0, 1, 0, 1))
+
+
+def _build_c_caller(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "voronoirt_amd")
+    exe = tmp_path / "c_caller"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_caller.c"), "-o", str(exe),
+                           "-L", libdir, "-lvrt_hip", f"-Wl,-rpath,{libdir}", "-lm"])
+    return exe
+
+
+def test_plain_c_caller_matches_oracle(tmp_path):
+    """examples/c_caller.c -- a C host standing in for the Julia caller -- gives the oracle's answer."""
+    import subprocess
+    exe = _build_c_caller(tmp_path)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = np.array([float(ln.split()[1]) for ln in out.stdout.strip().splitlines()])
+    n, so = _c_caller_lattice()
     ref = orc.Delaunay_upII(orc.direction(150.0, 30.0), np.ones(n), np.full(so.layers_up[1] - 1, 3.0),
                             np.full(n, 2.0), so, 3)
+    assert _rel(got, ref) < RTOL
+
+
+def test_plain_c_caller_plays_J_lambda_voronoi(tmp_path):
+    """Scenario 2 of examples/c_caller.c is the caller julia/VoronoiRT_hip.jl's J_line is (the body
+    of J_λ_voronoi, lambda_iteration.jl:60-113, with the formal solves batched): 12 angles x 5
+    wavelengths, per-angle α_tot (nλ, n, n_angles), I_0 for the up rays, one vrt_plan_execute."""
+    import subprocess
+    exe = _build_c_caller(tmp_path)
+    out = subprocess.run([str(exe), "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    n, so = _c_caller_lattice()
+    nlam, na = 5, 12
+    got = np.zeros((n, nlam))
+    for ln in out.stdout.strip().splitlines():
+        i, l, v = ln.split()
+        got[int(i) - 1, int(l) - 1] = float(v)
+    ii, ll = np.meshgrid(np.arange(n), np.arange(nlam), indexing="ij")
+    S = 1.0 + 0.1 * ((ii * 7 + ll * 3) % 11)
+    alpha = np.stack([0.5 + 0.05 * ((ii + 2 * ll + 3 * a) % 13) for a in range(na)])
+    n1 = int(so.layers_up[1] - 1)
+    pp, l1 = np.meshgrid(np.arange(n1), np.arange(nlam), indexing="ij")
+    I0 = 2.0 + 0.25 * ((pp + l1) % 5)
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    ref = orc.J_voronoi(w, th, ph, S, alpha, so, I0_up=I0, nthreads=2)
     assert _rel(got, ref) < RTOL
 
 

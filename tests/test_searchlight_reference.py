@@ -33,6 +33,17 @@ def _stats(a):
     return (c0, c1), (r0, r1), a.mean()
 
 
+def _radial_profile(a, c0, c1, edges):
+    n = a.shape[0]
+    g = (np.arange(n) + 0.5) / n
+    d0 = np.abs(g - c0) % 1.0
+    d0 = np.minimum(d0, 1.0 - d0)
+    d1 = np.abs(g - c1) % 1.0
+    d1 = np.minimum(d1, 1.0 - d1)
+    r = np.sqrt(d0[:, None] ** 2 + d1[None, :] ** 2)
+    return np.array([a[(r >= lo) & (r < hi)].mean() for lo, hi in zip(edges[:-1], edges[1:])])
+
+
 def _circ_dist(a, b):
     d = abs(a - b) % 1.0
     return min(d, 1.0 - d)
@@ -81,6 +92,21 @@ def _check(img, k, ref):
     assert abs(img.max() - ref["max"]) < 0.12      # single-pixel peak: the noisiest statistic (0.73-0.81 seen)
     assert 0.65 < mean / ref["mean"] < 1.35
     assert img.min() >= 0.0 and img.max() <= 1.0 + 1e-12
+    # lit area and the radial beam profile around the centroid (mean intensity per annulus): the
+    # scheme's numerical diffusion, bin by bin, against what the reference itself produced
+    frac = float((img > 0.05).mean())
+    prof = _radial_profile(img, c0, c1, ref["radial_edges"])
+    print("frac_above_0.05", frac, ref["frac_above_0.05"], "radial", np.round(prof, 4).tolist(),
+          np.round(ref["radial_profile"], 4).tolist())
+    # measured on this realisation: lit fraction 0.088 / 0.095 vs the reference's 0.102 / 0.095; the
+    # (20, 15) profile agrees to 0.05 in every bin, the (160, 45) one to 0.02 in the core (r < 0.06)
+    # and the tail with the reference's shoulder (0.06 <= r < 0.12) 0.09-0.12 higher (its sites were
+    # unseeded, and the files come from an earlier revision of the reference)
+    refp = np.array(ref["radial_profile"])
+    assert abs(frac - ref["frac_above_0.05"]) < 0.02
+    assert abs(prof[0] - refp[0]) < 0.05 and abs(prof[1] - refp[1]) < 0.05
+    assert np.abs(prof - refp).max() < 0.15
+    assert (np.diff(prof) < 0).all() and (np.diff(refp) < 0).all()      # monotone falling beam
 
 
 @pytest.mark.parametrize("name,theta,phi,up", CASES)

@@ -22,7 +22,7 @@ p_int = ctypes.POINTER(ctypes.c_int)
 vp = ctypes.c_void_p
 
 VRT_OK, VRT_EINVAL, VRT_EGRID, VRT_ENODEVICE, VRT_ENOMEM, VRT_EIO = 0, -1, -2, -3, -4, -5
-ALPHA_SITE, ALPHA_SITE_LAM, ALPHA_ANGLE_SITE_LAM = 0, 1, 2
+ALPHA_SITE, ALPHA_SITE_LAM, ALPHA_ANGLE_SITE_LAM, ALPHA_ANGLE_NATIVE = 0, 1, 2, 3
 
 # name -> (restype, argtypes): every symbol include/voronoirt.h declares
 PROTOTYPES = {
@@ -54,6 +54,9 @@ PROTOTYPES = {
                                             vp, vp, vp]),
     "vrt_plan_execute_dev_f32": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, ctypes.c_int, vp, vp, p_dbl,
                                                 vp, vp, vp]),
+    "vrt_grid_get_storage_order": (ctypes.c_int, [vp, ctypes.c_int, p_i64]),
+    "vrt_plan_native_alpha_count": (c_i64, [vp, c_i64]),
+    "vrt_plan_alpha_to_native_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp]),
     "vrt_plan_last_sweep_timing": (ctypes.c_int, [vp, p_dbl, p_i64]),
     "vrt_plan_last_path": (ctypes.c_int, [vp]),
     "vrt_schedule_build": (ctypes.c_int, [vp, ctypes.c_int, p_i64, ctypes.c_int,

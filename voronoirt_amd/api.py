@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes
 import os
 import re
+import weakref
 
 import numpy as np
 
@@ -105,6 +106,7 @@ class VoronoiSites:
         self.perm_up = self._perm(+1)
         self.perm_down = self._perm(-1)
         self._plans = {}
+        self._live_plans = weakref.WeakSet()    # every FormalPlan built on this grid (closed with it)
 
     # -- introspection ------------------------------------------------------------------------
     def _layers(self, d):
@@ -116,6 +118,13 @@ class VoronoiSites:
     def _perm(self, d):
         out = np.zeros(self.n, dtype=np.int64)
         check(_lib.load().vrt_grid_get_perm(self._h, d, _i(out)))
+        return out
+
+    def storage_order(self, d: int) -> np.ndarray:
+        """1-based site id at every storage position of direction d (> 0 up, < 0 down): the site
+        order of the library's native layouts (VRT_ALPHA_ANGLE_NATIVE)."""
+        out = np.zeros(self.n, dtype=np.int64)
+        check(_lib.load().vrt_grid_get_storage_order(self._h, d, _i(out)))
         return out
 
     @property
@@ -131,7 +140,9 @@ class VoronoiSites:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            for p in self._plans.values():
+            # a plan holds a pointer to the grid: close every plan still alive before the grid goes,
+            # also those the caller created (a later plan.close() is then a no-op)
+            for p in list(self._live_plans):
                 p.close()
             self._plans = {}
             _lib.load().vrt_grid_destroy(self._h)
@@ -174,6 +185,7 @@ class FormalPlan:
             check(L.vrt_plan_create_ex(sites.handle, self.n_angles, _d(self.k),
                                        d.ctypes.data_as(_lib.p_int), self.n_sweeps, ctypes.byref(h)))
         self._h = h
+        sites._live_plans.add(self)
 
     @property
     def num_levels(self) -> int:
@@ -241,6 +253,15 @@ class FormalPlan:
         fn = _lib.load().vrt_plan_execute_dev_f32 if f32 else _lib.load().vrt_plan_execute_dev
         check(fn(self._h, nlam, ld, dS, dalpha, alpha_mode, dI0_up or None, dI0_down or None, _d(w),
                  dJ or None, dI_out or None, stream or None))
+
+    def native_alpha_count(self, nlam: int) -> int:
+        """Number of float64 values of the native per-angle alpha buffer (ALPHA_ANGLE_NATIVE)."""
+        return int(_lib.load().vrt_plan_native_alpha_count(self._h, nlam))
+
+    def alpha_to_native_dev(self, nlam: int, ld: int, dalpha: int, dalpha_native: int, stream: int = 0) -> None:
+        """Device (n_angles, n, ld) per-angle alpha -> the native layout, once per change of alpha."""
+        check(_lib.load().vrt_plan_alpha_to_native_dev(self._h, nlam, ld, dalpha, dalpha_native,
+                                                       stream or None))
 
     def last_sweep_timing(self):
         ms = ctypes.c_double()

@@ -255,16 +255,27 @@ static int ensure_level_schedule(vrt_plan *p)
     }
     p->level_off[(size_t)max_levels] = at;
     p->n_nodes = total;
-    int rc;
-    if ((rc = dev_alloc(&p->d_node_site, (size_t)total))) return rc;
-    if ((rc = dev_alloc(&p->d_node_meta, (size_t)total))) return rc;
-    if ((rc = dev_alloc(&p->d_node_u1, (size_t)total))) return rc;
-    if ((rc = dev_alloc(&p->d_node_u2, (size_t)total))) return rc;
-    if (total) {
-        VRT_HIP_TRY(hipMemcpy(p->d_node_u1, node_u1.data(), sizeof(int32_t) * total, hipMemcpyHostToDevice));
-        VRT_HIP_TRY(hipMemcpy(p->d_node_u2, node_u2.data(), sizeof(int32_t) * total, hipMemcpyHostToDevice));
-        VRT_HIP_TRY(hipMemcpy(p->d_node_site, node_site.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
-        VRT_HIP_TRY(hipMemcpy(p->d_node_meta, node_meta.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
+    int rc = VRT_OK;
+    if (!rc) rc = dev_alloc(&p->d_node_site, (size_t)total);
+    if (!rc) rc = dev_alloc(&p->d_node_meta, (size_t)total);
+    if (!rc) rc = dev_alloc(&p->d_node_u1, (size_t)total);
+    if (!rc) rc = dev_alloc(&p->d_node_u2, (size_t)total);
+    if (!rc && total) {
+        const size_t b = sizeof(uint32_t) * (size_t)total;
+        if (hipMemcpy(p->d_node_u1, node_u1.data(), b, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->d_node_u2, node_u2.data(), b, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->d_node_site, node_site.data(), b, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->d_node_meta, node_meta.data(), b, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(VRT_ENODEVICE, "uploading the level schedule failed");
+    }
+    if (rc) {                       // leave no half-built schedule behind
+        dev_free(p->d_node_site);
+        dev_free(p->d_node_meta);
+        dev_free(p->d_node_u1);
+        dev_free(p->d_node_u2);
+        p->level_off.clear();
+        p->n_nodes = 0;
+        return rc;
     }
     p->level_ready = true;
     return VRT_OK;
@@ -292,8 +303,10 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             free_plan(p);
             return fail(VRT_EINVAL, "direction " + std::to_string(a + 1) + " is not a unit vector");
         }
+        // θ>90 up, θ<90 down, θ=90 skipped (lambda_iteration.jl:98,104).  cos(90° π/180) is 6.1e-17,
+        // not 0, so a horizontal direction is recognised by |k_z| < 1e-12 (1e-12 rad from horizontal)
         int d = dirs ? (dirs[a] > 0 ? 1 : (dirs[a] < 0 ? -1 : 0))
-                     : (ka[0] < 0 ? 1 : (ka[0] > 0 ? -1 : 0));   // θ>90 up, θ<90 down, θ=90 skipped
+                     : (std::fabs(ka[0]) < 1e-12 ? 0 : (ka[0] < 0 ? 1 : -1));
         if (d == 0) continue;
         p->user_of_active.push_back((int)a);
         p->dir_of_active.push_back(d);
@@ -396,6 +409,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             visits += lsched[(size_t)a].n_visits;
         }
         if (max_layer > 8 * 1024) ok = false;     // 8 sites per thread of a 1024-thread workgroup
+        if (n >= ((int64_t)1 << 28)) ok = false;  // the tile kernels index 16-byte pair planes with 32-bit byte offsets
         p->tile_ok = ok;
         p->tile_max_layer_size = max_layer;
         p->tile_visits = visits;
@@ -478,7 +492,7 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
     vrt_grid *g = p->g;
     if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
     if (!dS || !dalpha) return fail(VRT_EINVAL, "S and alpha must not be NULL");
-    if (alpha_mode < 0 || alpha_mode > 2) return fail(VRT_EINVAL, "bad alpha_mode");
+    if (alpha_mode < 0 || alpha_mode > VRT_ALPHA_ANGLE_NATIVE) return fail(VRT_EINVAL, "bad alpha_mode");
     if (dJ && !weights) return fail(VRT_EINVAL, "weights must be given when J is requested");
     int rc = use_device(g->device);
     if (rc) return rc;
@@ -487,6 +501,8 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
     // coincide unless a θ = 90 direction was skipped, which per-angle alpha does not support.
     if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM && p->A != (int)p->n_angles_user)
         return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
+    if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && (f32 || !p->tile_ok))
+        return fail(VRT_EINVAL, "native-layout alpha needs the fp64 layer-step path (layers <= 8192 sites)");
     {
         // Three device paths produce the same results:
         //   "levels"  one launch per dependency level over all angles; any grid;
@@ -508,6 +524,7 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         if (force && std::strcmp(force, "levels") == 0) path = 1;
         if (force && std::strcmp(force, "tiles") == 0) path = 2;
         if (force && std::strcmp(force, "steps") == 0) path = 3;
+        if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE) path = 3;    // the layout IS the layer-step path's
         if (p->A == 0) path = 1;      // nothing to solve (every direction skipped): J = 0 via the level path
         if (path != 1 && !p->tile_ok)
             return fail(VRT_EINVAL, "VRT_PATH=tiles/steps but the grid does not fit the layer-tile kernels");
@@ -547,7 +564,7 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         const bool use_graph = genv && genv[0] == '1';
         SweepKey key;
         key.nlam = sa.nlam; key.ldS = sa.ldS; key.ldA = sa.ldA; key.ldI = sa.ldI;
-        key.S = sa.S; key.alpha = sa.alpha; key.I = sa.I; key.alpha_mode = sa.alpha_mode;
+        key.S = sa.S; key.alpha = sa.alpha; key.I = sa.I; key.alpha_mode = sa.alpha_mode; key.f32 = sa.f32;
         bool replayed = false;
         if (use_graph) {
             if (!(p->graph_exec && p->graph_key == key)) {
@@ -601,6 +618,7 @@ int vrt_device_count(void)
 int vrt_grid_create(int64_t n, const double *pos_zxy, const int64_t *nbr, int64_t D1,
                     const double bounds[6], int device, vrt_grid **out)
 {
+    DeviceScope scope;
     try {
         return grid_create_impl(n, pos_zxy, nbr, D1, bounds, device, out);
     } catch (const std::bad_alloc &) {
@@ -613,6 +631,7 @@ int vrt_grid_create(int64_t n, const double *pos_zxy, const int64_t *nbr, int64_
 int vrt_grid_create_from_file(const char *neighbours_file, int64_t n, const double *pos_zxy,
                               const double bounds[6], int device, vrt_grid **out)
 {
+    DeviceScope scope;
     try {
         if (!neighbours_file) return fail(VRT_EINVAL, "NULL file name");
         if (n < 1) return fail(VRT_EINVAL, "n must be positive");
@@ -630,6 +649,7 @@ int vrt_grid_create_from_file(const char *neighbours_file, int64_t n, const doub
 
 void vrt_grid_destroy(vrt_grid *g)
 {
+    DeviceScope scope;
     if (g && g->device >= 0) (void)hipSetDevice(g->device);
     free_grid(g);
 }
@@ -659,6 +679,7 @@ int vrt_grid_get_perm(const vrt_grid *g, int dir, int64_t *out)
 
 int vrt_grid_get_delaunay_lines(const vrt_grid *g, double *out)
 {
+    DeviceScope scope;
     if (!g || !out) return fail(VRT_EINVAL, "NULL argument");
     try {
         int rc = use_device(g->device);
@@ -699,6 +720,7 @@ void vrt_direction(double theta_deg, double phi_deg, double k[3])
 int vrt_plan_create_ex(vrt_grid *g, int64_t n_angles, const double *k, const int *dirs,
                        int n_sweeps, vrt_plan **out)
 {
+    DeviceScope scope;
     try {
         return plan_create_impl(g, n_angles, k, dirs, n_sweeps, out);
     } catch (const std::bad_alloc &) {
@@ -715,26 +737,34 @@ int vrt_plan_create(vrt_grid *g, int64_t n_angles, const double *k, int n_sweeps
 
 void vrt_plan_destroy(vrt_plan *p)
 {
+    DeviceScope scope;
     if (p && p->g) (void)hipSetDevice(p->g->device);
     free_plan(p);
 }
 
-int64_t vrt_plan_num_levels(const vrt_plan *p)
+int64_t vrt_plan_num_levels(const vrt_plan *cp)
 {
-    if (!p) return 0;
-    if (ensure_level_schedule(const_cast<vrt_plan *>(p))) return -1;
+    if (!cp) return 0;
+    vrt_plan *p = const_cast<vrt_plan *>(cp);      // the level schedule is built lazily, under the plan's mutex
+    DeviceScope scope;
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (use_device(p->g->device) || ensure_level_schedule(p)) return -1;
     return (int64_t)p->level_off.size() - 1;
 }
-int64_t vrt_plan_num_nodes(const vrt_plan *p)
+int64_t vrt_plan_num_nodes(const vrt_plan *cp)
 {
-    if (!p) return 0;
-    if (ensure_level_schedule(const_cast<vrt_plan *>(p))) return -1;
+    if (!cp) return 0;
+    vrt_plan *p = const_cast<vrt_plan *>(cp);
+    DeviceScope scope;
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (use_device(p->g->device) || ensure_level_schedule(p)) return -1;
     return p->n_nodes;
 }
 
 int vrt_plan_get_upwind(const vrt_plan *p, int64_t angle, int64_t *up, double *dots, double *w,
                         double *r)
 {
+    DeviceScope scope;
     if (!p) return fail(VRT_EINVAL, "NULL plan");
     if (angle < 0 || angle >= p->n_angles_user) return fail(VRT_EINVAL, "angle out of range");
     int a = -1;
@@ -869,11 +899,44 @@ int vrt_layer_sorted_slots(const vrt_grid *g, int dir, const uint32_t *vis, int6
     }
 }
 
+int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out)
+{
+    if (!g || !out) return fail(VRT_EINVAL, "NULL argument");
+    const Direction &d = direction_of(g, dir);
+    for (int64_t i = 0; i < g->n; i++) out[i] = (int64_t)d.store[(size_t)i] + 1;
+    return VRT_OK;
+}
+
+int64_t vrt_plan_native_alpha_count(const vrt_plan *p, int64_t nlam)
+{
+    if (!p || nlam < 1) return 0;
+    return (int64_t)p->A * ((nlam + 1) / 2 * 2) * p->g->n;
+}
+
+int vrt_plan_alpha_to_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha,
+                                 double *dalpha_native, void *stream)
+{
+    DeviceScope scope;
+    if (!p || !dalpha || !dalpha_native) return fail(VRT_EINVAL, "NULL argument");
+    if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
+    if (p->A != (int)p->n_angles_user)
+        return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        int rc = use_device(p->g->device);
+        if (rc) return rc;
+        return alpha_to_native(p, nlam, ld, dalpha, dalpha_native, (hipStream_t)stream);
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
 int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS,
                          const double *dalpha, int alpha_mode, const double *dI0_up,
                          const double *dI0_down, const double *weights_host, double *dJ,
                          double *dI_out, void *stream)
 {
+    DeviceScope scope;
     if (!p) return fail(VRT_EINVAL, "NULL plan");
     try {
         std::lock_guard<std::mutex> lock(p->mu);
@@ -891,6 +954,7 @@ int vrt_plan_execute_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float 
                              const float *dI0_down, const double *weights_host, float *dJ,
                              float *dI_out, void *stream)
 {
+    DeviceScope scope;
     if (!p) return fail(VRT_EINVAL, "NULL plan");
     try {
         std::lock_guard<std::mutex> lock(p->mu);
@@ -907,10 +971,11 @@ int vrt_plan_execute(vrt_plan *p, int64_t nlam, int64_t ld, const double *S, con
                      int alpha_mode, const double *I0_up, const double *I0_down,
                      const double *weights, double *J, double *I_out)
 {
+    DeviceScope scope;
     if (!p) return fail(VRT_EINVAL, "NULL plan");
     if (!S || !alpha) return fail(VRT_EINVAL, "S and alpha must not be NULL");
     if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
-    if (alpha_mode < 0 || alpha_mode > 2) return fail(VRT_EINVAL, "bad alpha_mode");
+    if (alpha_mode < 0 || alpha_mode > 2) return fail(VRT_EINVAL, "bad alpha_mode (host arrays: 0, 1 or 2)");
     try {
         std::lock_guard<std::mutex> lock(p->mu);
         vrt_grid *g = p->g;
@@ -981,6 +1046,7 @@ int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *d
                           const double *deps, const double *dS_old, double *dS_new, double *max_rel_change,
                           void *stream)
 {
+    DeviceScope scope;
     if (!g || !dJ || !dB || !deps || !dS_old || !dS_new || !max_rel_change)
         return fail(VRT_EINVAL, "NULL argument");
     if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
@@ -1004,6 +1070,7 @@ int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *d
 static int single_solve(vrt_grid *g, int dir, const double k[3], const double *S, const double *I0,
                         int64_t nI0, const double *alpha, int n_sweeps, double *I_out)
 {
+    DeviceScope scope;
     if (!g || !k || !S || !alpha || !I_out) return fail(VRT_EINVAL, "NULL argument");
     const Direction &d = direction_of(g, dir);
     if (nI0 != d.n1)   // Julia: DimensionMismatch at irregular_ray_tracing.jl:35 / :116
@@ -1011,30 +1078,43 @@ static int single_solve(vrt_grid *g, int dir, const double k[3], const double *S
                                     std::to_string(d.n1));
     if (nI0 > 0 && !I0) return fail(VRT_EINVAL, "I_0 is NULL");
     try {
-        // The cache lookup, a possible eviction and the solve itself run under the grid's mutex:
-        // concurrent callers (the reference calls these from Threads.@threads) are serialised per
-        // grid handle, which also keeps an evicted plan from being used by another thread.
-        std::lock_guard<std::mutex> lock(g->mu);
-        vrt_plan *plan = nullptr;
-        for (PlanCacheEntry *c : g->cache)
-            if (c->n_sweeps == n_sweeps * dir && c->k[0] == k[0] && c->k[1] == k[1] && c->k[2] == k[2])
-                plan = c->plan;
-        if (!plan) {
-            int dirs[1] = {dir};
-            int rc = plan_create_impl(g, 1, k, dirs, n_sweeps, &plan);
-            if (rc) return rc;
-            if (g->cache.size() >= 64) {   // drop the oldest entry
-                vrt_plan_destroy(g->cache.front()->plan);
-                delete g->cache.front();
-                g->cache.erase(g->cache.begin());
+        // Only the cache lookup / insertion / eviction runs under the grid's mutex; the solve itself
+        // takes the plan's own mutex (vrt_plan_execute), so concurrent callers with different
+        // directions (the reference calls these from Threads.@threads) overlap, and callers of the
+        // same direction queue on that plan's workspaces.  An entry in use is never evicted.
+        PlanCacheEntry *entry = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g->mu);
+            for (PlanCacheEntry *c : g->cache)
+                if (c->n_sweeps == n_sweeps * dir && c->k[0] == k[0] && c->k[1] == k[1] && c->k[2] == k[2])
+                    entry = c;
+            if (!entry) {
+                int dirs[1] = {dir};
+                vrt_plan *plan = nullptr;
+                int rc = plan_create_impl(g, 1, k, dirs, n_sweeps, &plan);
+                if (rc) return rc;
+                if (g->cache.size() >= 64)      // drop the oldest entry nobody is using
+                    for (size_t i = 0; i < g->cache.size(); i++)
+                        if (g->cache[i]->users == 0) {
+                            vrt_plan_destroy(g->cache[i]->plan);
+                            delete g->cache[i];
+                            g->cache.erase(g->cache.begin() + (long)i);
+                            break;
+                        }
+                entry = new PlanCacheEntry{{k[0], k[1], k[2]}, n_sweeps * dir, plan, 0};
+                g->cache.push_back(entry);
             }
-            PlanCacheEntry *c = new PlanCacheEntry{{k[0], k[1], k[2]}, n_sweeps * dir, plan};
-            g->cache.push_back(c);
+            entry->users++;
         }
         const double one = 1.0;
         // I_out doubles as J with weight 1: J = 0 + 1*I is exact
-        return vrt_plan_execute(plan, 1, 1, S, alpha, VRT_ALPHA_SITE, dir > 0 ? I0 : nullptr,
-                                dir > 0 ? nullptr : I0, &one, I_out, nullptr);
+        const int rc = vrt_plan_execute(entry->plan, 1, 1, S, alpha, VRT_ALPHA_SITE, dir > 0 ? I0 : nullptr,
+                                        dir > 0 ? nullptr : I0, &one, I_out, nullptr);
+        {
+            std::lock_guard<std::mutex> lock(g->mu);
+            entry->users--;
+        }
+        return rc;
     } catch (const std::bad_alloc &) {
         return fail(VRT_ENOMEM, "out of host memory");
     } catch (...) {

@@ -22,6 +22,20 @@ int fail(int code, const std::string &msg);
             return ::vrt::fail(VRT_ENODEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+// Restores the caller's current HIP device when an entry point returns (a multi-GPU host such as
+// torch keeps its own notion of the current device; the library must not change it behind its back).
+struct DeviceScope {
+    int prev = -1;
+    DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceScope()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
 constexpr int kMaxAngles = 64;          // active angles per plan (kernel-argument weight table)
 constexpr int64_t kMaxGuess = 70;       // read_cell's neighbour cap, voronoi_utils.jl:42
 constexpr int32_t kNoUpwind = -1;
@@ -51,10 +65,11 @@ struct SweepKey {
     int64_t nlam = -1, ldS = 0, ldA = 0, ldI = 0;
     const void *S = nullptr, *alpha = nullptr, *I = nullptr;
     int alpha_mode = -1;
+    bool f32 = false;
     bool operator==(const SweepKey &o) const
     {
         return nlam == o.nlam && ldS == o.ldS && ldA == o.ldA && ldI == o.ldI && S == o.S &&
-               alpha == o.alpha && I == o.I && alpha_mode == o.alpha_mode;
+               alpha == o.alpha && I == o.I && alpha_mode == o.alpha_mode && f32 == o.f32;
     }
 };
 
@@ -159,6 +174,7 @@ struct PlanCacheEntry {
     double k[3];
     int n_sweeps;
     vrt_plan *plan;
+    int users;          // single solves running on the plan right now (guarded by the grid's mutex)
 };
 
 // ---- host-side grid preparation (vrt_grid.cpp) ---------------------------------------------
@@ -213,6 +229,7 @@ int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, 
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
 int launch_sorted_tables(vrt_plan *p, int a);
 int launch_gpos(vrt_plan *p, int a);
+int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha, double *out, hipStream_t st);
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const double *dalpha,
                   int alpha_mode, const double *dI0_up, const double *dI0_down,
                   const double *weights_user, double *dJ, double *dI_out, hipStream_t st);

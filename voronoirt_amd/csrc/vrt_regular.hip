@@ -450,6 +450,7 @@ static void regular_free(vrt_regular *r)
 extern "C" int vrt_regular_create(int64_t nz, int64_t nx, int64_t ny, const double *z, const double *x,
                                   const double *y, int device, vrt_regular **out)
 {
+    DeviceScope scope;
     if (!z || !x || !y || !out) return fail(VRT_EINVAL, "NULL argument");
     if (nz < 2 || nx < 3 || ny < 3) return fail(VRT_EINVAL, "bad sizes");
     if (nx > 16384 || ny > 16384) return fail(VRT_EINVAL, "nx, ny must be at most 16384");
@@ -497,6 +498,7 @@ extern "C" int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const do
                                        int64_t alpha_stride, int64_t field_period, const double *dI0,
                                        int n_sweeps, double *dI_out, void *stream)
 {
+    DeviceScope scope;
     if (field_period < 0 || field_period > n_solve) return fail(VRT_EINVAL, "field_period must be in [0, n_solve]");
     if (!r || !k || !up || !dS || !dalpha || !dI0 || !dI_out) return fail(VRT_EINVAL, "NULL argument");
     if (n_solve < 1 || n_sweeps < 1) return fail(VRT_EINVAL, "bad sizes");
@@ -579,6 +581,7 @@ extern "C" int vrt_short_characteristics(int64_t nz, int64_t nx, int64_t ny, con
                                          int64_t S_stride, const double *alpha, int64_t alpha_stride,
                                          const double *I0, int n_sweeps, int device, double *I_out)
 {
+    DeviceScope scope;
     if (!z || !x || !y || !k || !up || !S || !alpha || !I0 || !I_out) return fail(VRT_EINVAL, "NULL argument");
     if (nz < 2 || nx < 3 || ny < 3 || n_solve < 1 || n_sweeps < 1) return fail(VRT_EINVAL, "bad sizes");
     const int64_t vol = nz * nx * ny, plane = nx * ny;

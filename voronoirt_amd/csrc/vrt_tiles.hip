@@ -27,6 +27,18 @@
 
 namespace vrt {
 
+// Timing diagnostics that switch pieces of the memory traffic off (and give WRONG results) exist
+// only in the -DVRT_DIAG build (voronoirt_amd/libvrt_hip_diag.so, used by tools/flags_sweep.sh):
+// in the product library every such branch folds away at compile time and no environment
+// variable can change a result.
+#ifdef VRT_DIAG
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
+
+constexpr uint32_t kNoSlot = 0xFFFFu;   // t_loc entry of an upwind outside the site's own layer (layers <= 8192 sites)
+
 // ---- table in sweep order -----------------------------------------------------------------------
 // t_u1/t_u2: sweep positions of the upwind sites; everything else copied from the site-order table.
 __global__ void __launch_bounds__(256)
@@ -54,8 +66,10 @@ k_permute_table(int64_t n, const int32_t *__restrict__ order, const int32_t *__r
         if (lay[mid] <= p) lo_i = mid; else hi_i = mid;
     }
     const int lo = lay[lo_i], hi = lay[lo_i + 1];
-    const uint32_t l1 = (ua >= lo && ua < hi) ? (uint32_t)(ua - lo) : 0u;
-    const uint32_t l2 = (ub >= lo && ub < hi) ? (uint32_t)(ub - lo) : 0u;
+    // kNoSlot: the kernels read a dedicated zero slot instead (coupling 0 times a finite 0, so an Inf
+    // or NaN elsewhere in the layer stays where the reference keeps it)
+    const uint32_t l1 = (ua >= lo && ua < hi) ? (uint32_t)(ua - lo) : kNoSlot;
+    const uint32_t l2 = (ub >= lo && ub < hi) ? (uint32_t)(ub - lo) : kNoSlot;
     t_loc[p] = l1 | (l2 << 16);
     t_w1[p] = w1[s];
     t_w2[p] = w2[s];
@@ -384,7 +398,7 @@ k_sweep_tiles(TileArgs ta)
     const int L = ta.nlayers[d];
 
     long long cyc1 = 0, cyc2 = 0, cyc3 = 0;
-    const bool timing = ta.dbg != nullptr;
+    const bool timing = kDiag && ta.dbg != nullptr;
     for (int layer = 2; layer <= L; layer++) {          // irregular_ray_tracing.jl:37
         long long t0 = timing ? clock64() : 0;
         const int lo = lay[layer - 1], hi = lay[layer];  // hi of the last layer = n-1: perm[n] is never visited
@@ -457,7 +471,8 @@ k_sweep_tiles(TileArgs ta)
                 const double gg2 = in2 ? ce * w2[j] : 0.0;
                 g1[kb + j] = gg1;
                 g2[kb + j] = gg2;
-                loc[kb + j] = (in1 ? (uint32_t)(u1 - lo) : 0u) | ((in2 ? (uint32_t)(u2 - lo) : 0u) << 16);
+                // an upwind outside the layer reads the zero slot tile[cnt] (coupling 0 x finite 0)
+                loc[kb + j] = (in1 ? (uint32_t)(u1 - lo) : (uint32_t)cnt) | ((in2 ? (uint32_t)(u2 - lo) : (uint32_t)cnt) << 16);
                 const int slot = tid + (kb + j) * T;
                 if (slot < cnt) {
                     tile[slot] = 0.0;                                        // I = zero(S), :23
@@ -466,6 +481,7 @@ k_sweep_tiles(TileArgs ta)
             }
             __builtin_amdgcn_sched_barrier(0);    // keep the batches apart: hoisting more loads spills
         }
+        if (tid == 0) tile[cnt] = 0.0;            // the zero slot
         __syncthreads();
         long long t1c = timing ? clock64() : 0;
         // ---- phase 2: the layer's Gauss-Seidel levels on the LDS tile ------------------------
@@ -517,6 +533,12 @@ k_sweep_tiles(TileArgs ta)
 // in-layer dependency structure (levels, tile slots) is the same for every wavelength of an
 // angle, so a level visit of the pair costs the same LDS instructions (b128) as one wavelength.
 // ---------------------------------------------------------------------------------------------
+struct DirWeights {
+    double w[kMaxAngles];
+    int32_t idx[kMaxAngles];
+    int count;
+};
+
 struct StepArgs {
     TileArgs ta;              // S, alpha, I in pair layout; ta.nlam = the caller's wavelength count
     int npair;                // ceil(nlam / 2)
@@ -599,7 +621,7 @@ k_step_coeffs(StepArgs sa)
     const bool early1 = u1 < lo, in1 = (gp >> 30) & 1u;      // in = upwind inside [lo, hi)
     const bool early2 = u2 < lo, in2 = gp >> 31;
     int i1 = min(u1, lo - 1), i2 = min(u2, lo - 1);
-    const int dbg = sa.debug_flags;
+    const int dbg = kDiag ? sa.debug_flags : 0;
     int v1 = u1, v2 = u2;
     if (dbg & 1) { v1 = p; v2 = p; }              // S/alpha gathers -> coalesced centre re-reads
     if (dbg & 2) { i1 = lo - 1; i2 = lo - 1; }    // I gathers -> one broadcast address
@@ -675,13 +697,14 @@ k_step_levels(StepArgs sa)
     double2 c[K], g1[K], g2[K];
     uint32_t loc[K], vis[K], self[K];   // self: storage slot of the sorted entry this thread owns
     // coefficients arrive in storage order (coalesced 16-byte loads) ...
-    const bool sorted = !(sa.debug_flags & 64);
+    const int dbgl = kDiag ? sa.debug_flags : 0;
+    const bool sorted = !(dbgl & 64);
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int i = tid + k * T;
         const bool ok = i < cnt;
         const int ii = ok ? i : cnt - 1;
-        if (sa.debug_flags & 8) {                  // no coefficient loads
+        if (dbgl & 8) {                  // no coefficient loads
             c[k] = make_double2(1.0 + ii, 2.0 + ii); g1[k] = make_double2(0.25, 0.25); g2[k] = make_double2(0.125, 0.125);
         } else {
             c[k] = sa.cg_c[o + ii];
@@ -720,13 +743,15 @@ k_step_levels(StepArgs sa)
 #pragma unroll
     for (int k = 0; k < K; k++)
         if (tid + k * T < cnt) tile2[tid + k * T] = make_double2(0.0, 0.0);   // I = zero(S), irregular_ray_tracing.jl:23
+    if (tid == 0) tile2[cnt] = make_double2(0.0, 0.0);                         // the zero slot
     __syncthreads();
-    const int nl = sa.debug_skip_levels ? 0 : ta.nlev[(size_t)a * (size_t)(ta.max_layers + 1) + sa.layer];
+    const int nl = (kDiag && sa.debug_skip_levels) ? 0 : ta.nlev[(size_t)a * (size_t)(ta.max_layers + 1) + sa.layer];
     for (int t = 1; t <= nl; t++) {
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if ((vis[k] & 0xFFu) == (uint32_t)t) {       // a site's visits come at increasing levels
-                const double2 x = tile2[loc[k] & 0xFFFFu], y = tile2[loc[k] >> 16];
+                const uint32_t lx = loc[k] & 0xFFFFu, ly = loc[k] >> 16;   // kNoSlot -> the zero slot
+                const double2 x = tile2[lx == kNoSlot ? (uint32_t)cnt : lx], y = tile2[ly == kNoSlot ? (uint32_t)cnt : ly];
                 double2 r;
                 r.x = c[k].x + g1[k].x * x.x + g2[k].x * y.x;
                 r.y = c[k].y + g1[k].y * x.y + g2[k].y * y.y;
@@ -739,18 +764,12 @@ k_step_levels(StepArgs sa)
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int slot = tid + k * T;
-        if (slot < cnt && (!(sa.debug_flags & 16) || tile2[slot].x == 1.2345e300)) I[lo + slot] = tile2[slot];
+        if (slot < cnt && (!(dbgl & 16) || tile2[slot].x == 1.2345e300)) I[lo + slot] = tile2[slot];
     }
     if (tid == 0 && sa.layer == ta.nlayers[d]) I[n - 1] = make_double2(0.0, 0.0);   // never-visited site perm[n]
 }
 
 // J_d[l][p] = Σ_{angles of direction d} w_a I_a[l][p], reference's angle order within the direction
-struct DirWeights {
-    double w[kMaxAngles];
-    int32_t idx[kMaxAngles];
-    int count;
-};
-
 __global__ void __launch_bounds__(256)
 k_reduce_dir(int64_t total, int64_t stride_angle, DirWeights dw, const double *__restrict__ I,
              double *__restrict__ Jd)
@@ -888,6 +907,24 @@ static int build_task_map(vrt_plan *p, int nlam, hipStream_t st)
     return VRT_OK;
 }
 
+// caller's per-angle alpha (n_angles, n, ld) -> the native layout of VRT_ALPHA_ANGLE_NATIVE
+int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha, double *out, hipStream_t st)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const int64_t nl_pad = (nlam + 1) / 2 * 2;
+    const size_t plane = (size_t)nl_pad * (size_t)n;
+    const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
+    for (int a = 0; a < p->A; a++) {
+        const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
+        hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2, dir.d_store,
+                           dalpha + (size_t)p->user_of_active[(size_t)a] * (size_t)n * (size_t)ld,
+                           out + (size_t)a * plane);
+    }
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 // internal streams + angle groups of the layer-step path
 static int ensure_step_streams(vrt_plan *p, int G)
 {
@@ -951,7 +988,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     ta.A = A;
     ta.alpha_mode = alpha_mode;
     ta.max_layers = p->tile_max_layers;
-    ta.tile_stride = (int)((std::max<int64_t>(p->tile_max_layer_size, 1) + 1) & ~(int64_t)1);
+    ta.tile_stride = (int)((std::max<int64_t>(p->tile_max_layer_size, 1) + 2) & ~(int64_t)1);   // + the zero slot
     if ((rc = build_task_map(p, (int)nlam, st))) return rc;
     ta.task_map = p->d_task_map;
     ta.angle_dir = p->d_angle_dir;
@@ -994,7 +1031,12 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
                                d == 0 ? dI0_up : dI0_down, p->d_I);
         }
     }
-    if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM) {
+    if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE) {
+        // already in storage-pair order per active angle (vrt_plan_alpha_to_native_dev or the
+        // opacity prologue wrote it): no transposed copy, the kernels read the caller's buffer
+        ta.alpha_mode = VRT_ALPHA_ANGLE_SITE_LAM;
+        ta.alpha_angle = dalpha;
+    } else if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM) {
         if ((rc = ensure_dev(p->ws_AA, p->ws_AA_cap, (size_t)A * plane))) return rc;
         for (int a = 0; a < A; a++) {
             const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
@@ -1005,7 +1047,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     }
     VRT_HIP_TRY(hipGetLastError());
 
-    const bool debug = std::getenv("VRT_TILE_DEBUG") != nullptr;
+    const bool debug = kDiag && std::getenv("VRT_TILE_DEBUG") != nullptr;
     long long *d_dbg = nullptr;
     ta.dbg = nullptr;
     int64_t launches = 1;
@@ -1025,17 +1067,17 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         sa.pairs_per_thread = std::getenv("VRT_STEP_PAIRS") ? std::max(1, std::atoi(std::getenv("VRT_STEP_PAIRS"))) : kStepPairs;
         sa.chunks = (int)((p->tile_max_layer_size + 255) / 256);
         sa.xcd_map = std::getenv("VRT_STEP_XCD") ? std::atoi(std::getenv("VRT_STEP_XCD")) : 2;
-        sa.debug_skip_levels = std::getenv("VRT_DEBUG_SKIP_LEVELS") != nullptr;
+        sa.debug_skip_levels = kDiag && std::getenv("VRT_DEBUG_SKIP_LEVELS") != nullptr;
         // 1: S/alpha gathers off, 2: I gathers off, 4: coefficient stores off, 8: coefficient loads off,
         // 16: I stores off, 32: no linear_weights arithmetic, 64: level kernel keeps the storage-order thread assignment
-        sa.debug_flags = std::getenv("VRT_DEBUG_FLAGS") ? std::atoi(std::getenv("VRT_DEBUG_FLAGS")) : 0;
+        sa.debug_flags = (kDiag && std::getenv("VRT_DEBUG_FLAGS")) ? std::atoi(std::getenv("VRT_DEBUG_FLAGS")) : 0;
         if ((sa.debug_flags & ~(64 | 128)) || sa.debug_skip_levels) {
             static bool warned = false;
             if (!warned) std::fprintf(stderr, "[vrt] VRT_DEBUG_FLAGS / VRT_DEBUG_SKIP_LEVELS set: timing diagnostics, the results are WRONG\n");
             warned = true;
         }
         const int Lmax = std::max(ta.nlayers[0] * (use_dir[0] ? 1 : 0), ta.nlayers[1] * (use_dir[1] ? 1 : 0));
-        const size_t lds_max = (size_t)std::max<int64_t>(p->tile_max_layer_size, 1) * sizeof(double2);
+        const size_t lds_max = (size_t)(std::max<int64_t>(p->tile_max_layer_size, 1) + 1) * sizeof(double2);   // + the zero slot
         const int force_K = std::getenv("VRT_STEP_K") ? std::atoi(std::getenv("VRT_STEP_K")) : 0;
         // The angles are dealt (heaviest first) to a few internal streams that advance through
         // the layers independently: the (angle, wavelength) problems of different streams share
@@ -1066,7 +1108,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
             }
             sa.chunks = (int)((cnt_l + 255) / 256);
             const int per_xcd = (sa.chunks + 7) / 8;     // largest chunk range of an XCD
-            const size_t lds = std::min(lds_max, (size_t)cnt_l * sizeof(double2));
+            const size_t lds = std::min(lds_max, (size_t)(cnt_l + 1) * sizeof(double2));
             // sites per thread of the level kernel: the fewest that cover the layer (14 VGPRs of
             // register-resident coefficients per site); VRT_STEP_K forces more (tests)
             const int step_K = std::max(1, std::min(8, std::max(force_K, (int)((cnt_l + 1023) / 1024))));
