@@ -187,6 +187,46 @@ int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *d
                           const double *deps, const double *dS_old, double *dS_new,
                           double *max_rel_change, void *stream);
 
+/* ---- fused per-angle opacity prologue -------------------------------------
+ * alpha_tot = alphaline_lambda + alpha_cont for EVERY angle of the plan from per-site line parameters,
+ * written directly in the native layout of VRT_ALPHA_ANGLE_NATIVE -- replaces the per-angle part of
+ * J_λ_voronoi between the angle loop header and the formal solve: damping_λ
+ * (src/lambda_iteration.jl:72-80, src/broadening.jl:87-89), compute_voigt_profile with the
+ * line-of-sight velocity of -k (src/line.jl:121-137, :198-208), αline_λ (src/line.jl:219-225) and
+ * α_tot = αline + α_cont (src/lambda_iteration.jl:93-96):
+ *   v_los = dot(velocity, -k);  a = γ λ²/(4π c0 ΔλD);  v = (λ - λ0 + λ0 v_los/c0)/ΔλD
+ *   alpha = line_strength * H(a, v)/(sqrt(π) ΔλD) + alpha_cont
+ * H = Re w4(v + i a), Humlíček's w4 as Transparency.jl's voigt_profile (absent from the reference
+ * checkout; tolerance-based parity).  Plain numbers in one unit system of the caller's choice:
+ *   lambda[nlam] (host), lambda0, c0;  device: velocity (3, n) rows z,x,y; doppler_width ΔλD[n];
+ *   gamma[n]; line_strength[n] = h c0/(4π λ0) (n_i B_ij - n_j B_ji); alpha_cont[n];
+ *   alpha_native: vrt_plan_native_alpha_count(p, nlam) doubles, out. */
+int vrt_line_opacity_dev(vrt_plan *p, int64_t nlam, const double *lambda, double lambda0, double c0,
+                         const double *d_velocity, const double *d_doppler_width, const double *d_gamma,
+                         const double *d_line_strength, const double *d_alpha_cont, double *d_alpha_native,
+                         void *stream);
+
+/* ---- rates + populations of the Λ-iteration epilogue on the device --------
+ * calculate_R (src/rates.jl:154-201: Rij / Rji λ-trapezoids :226-364, σij with the site's static
+ * Voigt profile :374-416, Gij :459-476) and get_revised_populations (src/populations.jl:191-221,
+ * the per-site 2 x 2 solve) for the reference's 2-level + continuum atom, from J in place:
+ *   R_ij = Σ_l pref_ij ((λ_l σ_l J_l + λ_l+1 σ_l+1 J_l+1)(λ_l+1 - λ_l))
+ *   R_ji = Σ_l pref_ji ((σ_l G_l λ_l (P_l + J_l) + σ_l+1 G_l+1 λ_l+1 (P_l+1 + J_l+1))(λ_l+1 - λ_l))
+ *   G_l = LTE[i]/LTE[j] exp(-hc_over_kB/(λ_l T)),  P_l = planck2[l] = 2 h c0²/λ_l⁵ in J's unit
+ * pref_ij / pref_ji = 2π/(h c0) times the unit factors the reference gets from Unitful (and its
+ * explicit /1000 in Rij, rates.jl:237,263).  blocks = [lo, hi) (0-based) of the bound-bound, level-1
+ * bound-free and level-2 bound-free wavelength blocks (line.λidx).  Host: lambda[nlam],
+ * planck2[nlam], sigma_bf1 / sigma_bf2 (σic per wavelength of the block).  Device: J (nlam, n) with
+ * leading dimension ld, doppler_width[n], gamma[n], temperature[n], lte_populations (n, 3),
+ * C (3, 3, n) collisional rates, atom_density[n]; out: R (3, 3, n), populations (n, 3). */
+int vrt_rates_populations_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *lambda,
+                              const int64_t blocks[6], const double *dJ, const double *planck2,
+                              double lambda0, double c0, const double *d_doppler_width, const double *d_gamma,
+                              double sigma_bb_const, const double *sigma_bf1, const double *sigma_bf2,
+                              const double *d_temperature, const double *d_lte_populations, double hc_over_kB,
+                              double pref_ij, double pref_ji, const double *d_C, const double *d_atom_density,
+                              double *d_R, double *d_populations, void *stream);
+
 /* ---- regular-grid short characteristics ---------------------------------
  * Drop-in bodies for short_characteristics_up / short_characteristics_down
  * (src/characteristics.jl:19-95, :110-180), batched over independent solves the way

@@ -33,7 +33,9 @@ _p_i32 = ctypes.POINTER(ctypes.c_int32)
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile) if the .so is missing or stale."""
     src = os.path.join(_HERE, "vrt_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    src2 = os.path.join(_HERE, "vrt_oracle_physics.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src),
+                                                                                   os.path.getmtime(src2)):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libvrt_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -80,6 +82,18 @@ def lib():
                                                 _p_dbl, _p_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _p_dbl,
                                                 ctypes.POINTER(ctypes.c_int)]
         L.orc_short_characteristics.restype = ctypes.c_int
+        L.orc_humlicek_w4.argtypes = [_c_dbl, _c_dbl, _p_dbl, _p_dbl]
+        L.orc_humlicek_w4.restype = None
+        L.orc_voigt_profile.argtypes = [_c_dbl, _c_dbl, _c_dbl]
+        L.orc_voigt_profile.restype = _c_dbl
+        L.orc_line_opacity.argtypes = [_p_dbl, _c_i64, _c_i64, _p_dbl, _c_dbl, _c_dbl, _p_dbl, _p_dbl, _p_dbl,
+                                       _p_dbl, _p_dbl, _p_dbl]
+        L.orc_line_opacity.restype = None
+        L.orc_calculate_R.argtypes = [_c_i64, _c_i64, _p_dbl, _p_i64, _p_dbl, _p_dbl, _c_dbl, _c_dbl, _p_dbl, _p_dbl,
+                                      _c_dbl, _p_dbl, _p_dbl, _p_dbl, _p_dbl, _c_dbl, _c_dbl, _c_dbl, _p_dbl]
+        L.orc_calculate_R.restype = None
+        L.orc_revised_populations.argtypes = [_c_i64, _p_dbl, _p_dbl, _p_dbl, _p_dbl]
+        L.orc_revised_populations.restype = None
         L.orc_max_threads.argtypes = []
         L.orc_max_threads.restype = ctypes.c_int
         _lib = L
@@ -312,3 +326,52 @@ def short_characteristics_up(k, S_0, I_0, alpha, z, x, y, n_sweeps=3, return_pla
 def short_characteristics_down(k, S_0, I_0, alpha, z, x, y, n_sweeps=3, return_planes=False):
     """src/characteristics.jl:110-180"""
     return _short_characteristics(False, k, S_0, I_0, alpha, z, x, y, n_sweeps, return_planes)
+
+
+# ---- physics either side of the formal solve (vrt_oracle_physics.c) --------------------------------
+def humlicek_w4(x: float, y: float) -> complex:
+    """Humlíček (1982) w4 approximation of the Faddeeva function w(x + i y), y >= 0."""
+    re, im = _c_dbl(), _c_dbl()
+    lib().orc_humlicek_w4(float(x), float(y), ctypes.byref(re), ctypes.byref(im))
+    return complex(re.value, im.value)
+
+
+def voigt_profile(a: float, v: float, dD: float) -> float:
+    """Transparency.jl's voigt_profile(a, v, ΔλD) = H(a, v) / (sqrt(π) ΔλD)  (src/line.jl:133)."""
+    return float(lib().orc_voigt_profile(float(a), float(v), float(dD)))
+
+
+def line_opacity(k, lam, lambda0, c0, velocity, doppler, gamma, line_strength, alpha_cont):
+    """α_tot (n, nlam) for one direction k -- lambda_iteration.jl:72-80, :89, :93-96."""
+    k, lam = _f64(k), _f64(lam)
+    velocity, doppler, gamma = _f64(velocity), _f64(doppler), _f64(gamma)
+    line_strength, alpha_cont = _f64(line_strength), _f64(alpha_cont)
+    n = doppler.size
+    out = np.zeros((n, lam.size))
+    lib().orc_line_opacity(_d(k), n, lam.size, _d(lam), float(lambda0), float(c0), _d(velocity), _d(doppler),
+                           _d(gamma), _d(line_strength), _d(alpha_cont), _d(out))
+    return out
+
+
+def calculate_R(lam, blocks, J, planck2, lambda0, c0, doppler, gamma, sigma_bb_const, sigma_bf1, sigma_bf2,
+                temperature, lte, hc_over_kB, pref_ij, pref_ji):
+    """calculate_R (src/rates.jl:154-201); J (n, nlam), lte (3, n) C-order == Julia (n, 3); returns
+    R as (n, 3, 3) C-order with R[i, c, r] == Julia R[r+1, c+1, i+1]."""
+    lam, J, planck2 = _f64(lam), _f64(J), _f64(planck2)
+    blocks = _i64(blocks)
+    n = J.shape[0]
+    R = np.zeros((n, 3, 3))
+    lib().orc_calculate_R(n, lam.size, _d(lam), _i(blocks), _d(J), _d(planck2), float(lambda0), float(c0),
+                          _d(_f64(doppler)), _d(_f64(gamma)), float(sigma_bb_const), _d(_f64(sigma_bf1)),
+                          _d(_f64(sigma_bf2)), _d(_f64(temperature)), _d(_f64(lte)), float(hc_over_kB),
+                          float(pref_ij), float(pref_ji), _d(R))
+    return R
+
+
+def revised_populations(R, C, atom_density):
+    """get_revised_populations (src/populations.jl:191-221); returns (3, n) C-order == Julia (n, 3)."""
+    R, C, atom_density = _f64(R), _f64(C), _f64(atom_density)
+    n = atom_density.size
+    out = np.zeros((3, n))
+    lib().orc_revised_populations(n, _d(R), _d(C), _d(atom_density), _d(out))
+    return out

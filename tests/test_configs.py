@@ -239,3 +239,40 @@ def test_C5_4M_sites_fp32_storage():
     assert ((J3 - 2.0 * J1).abs().max() / J3.abs().max()).item() < 1e-5
     plan.close()
     hs.close()
+
+
+# ---- N > 1 code path of bench.py, rehearsed on one GPU ------------------------------------------------
+@pytest.mark.parametrize("shard", ["lambda-strong", "angle"])
+def test_bench_two_ranks_reproduce_the_one_rank_J(tmp_path, shard):
+    """`python bench.py --gpus 2` launches its own two ranks (torch.distributed.run, before any GPU
+    call), shards the FIXED tiny problem by wavelength blocks (all-gather of J) or by angles
+    (all-reduce of J) and must reproduce the single-rank J.  VRT_BENCH_REHEARSE=1: both ranks share
+    GPU 0 and the collectives run over gloo (RCCL refuses two ranks on one device)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VRT_BENCH_REHEARSE="1")
+    env.pop("VRT_PATH", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    outs = {}
+    for gpus in (1, 2):
+        dump = tmp_path / f"J_{gpus}.npy"
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--workload", "tiny",
+               "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-critical-path",
+               "--shard", shard, "--dump-J", str(dump)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        outs[gpus] = (json.loads(line), np.load(dump))
+    (j1, J1), (j2, J2) = outs[1], outs[2]
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    assert j2["config"]["shard"] == shard and J1.shape == J2.shape
+    # same cell-update count for the fixed job at either rank count
+    assert abs(j2["value"] * j2["ms_per_step"] - j1["value"] * j1["ms_per_step"]) < 1e-6 * j1["value"] * j1["ms_per_step"]
+    if shard == "lambda-strong":
+        assert np.array_equal(J1, J2)            # every wavelength is solved by exactly one rank
+    else:
+        assert np.abs(J1 - J2).max() <= 1e-13 * np.abs(J1).max()   # the all-reduce changes the summation order

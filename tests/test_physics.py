@@ -1,0 +1,214 @@
+"""The two steps either side of the formal solve that the library also runs on the device
+(SURVEY.md 8f rows 2 and 4): the per-angle opacity prologue and the rates / populations epilogue.
+
+Parity status: UNPINNED upstream -- the reference's arithmetic for them goes through Transparency.jl
+(absent, version unpinned) and Unitful conversions, and it holds no test for them.  Pinned here:
+  * the Voigt profile (Humlíček's w4, the algorithm Transparency.jl documents) against
+    scipy.special.wofz on a committed fixture, at w4's own accuracy (1e-4 relative),
+  * the oracle's restatement of the reference's formulas against an independent numpy transcription,
+  * the HIP kernels against the oracle at 1e-12 (-m gpu)."""
+import os
+
+import numpy as np
+import pytest
+
+import voronoirt_amd as vrt
+from oracle import oracle as orc
+from voronoirt_amd import _lib, api, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+C0 = 2.99792458e8
+H_PLANCK = 6.62607015e-34
+K_B = 1.380649e-23
+
+
+def test_voigt_w4_against_wofz_fixture():
+    fx = np.load(os.path.join(GOLDEN, "voigt_wofz.npz"))
+    got = np.array([orc.humlicek_w4(v, a).real for a, v in zip(fx["a"], fx["v"])])
+    rel = np.abs(got - fx["H"]) / fx["H"]
+    assert rel.max() < 1e-4, rel.max()             # Humlíček 1982: relative accuracy 1e-4
+    # normalisation of the profile: ∫ H(a, v) dv = sqrt(π)
+    v = np.linspace(-400, 400, 400001)
+    Hv = np.array([orc.humlicek_w4(x, 0.1).real for x in v[::40]])
+    assert abs(np.trapezoid(Hv, v[::40]) / np.sqrt(np.pi) - 1) < 2e-3
+    assert orc.voigt_profile(0.3, 1.2, 2.5e-12) == orc.humlicek_w4(1.2, 0.3).real / (np.sqrt(np.pi) * 2.5e-12)
+
+
+def _line_case(n, seed, nbb=51, nbf=20):
+    """A Ly-α-like 2-level + continuum atom (src/line.jl:232-247) on n sites, SI numbers."""
+    rng = np.random.default_rng(seed)
+    lambda0 = 121.567e-9
+    # bound-bound sampling like sample_λ_line (log-spaced wings), bound-free blocks linear
+    q = np.concatenate([-np.geomspace(600, 0.05, nbb // 2), [0.0], np.geomspace(0.05, 600, nbb // 2)])
+    lam_bb = lambda0 * (1 + q * 2.5e3 / C0)
+    lam_bf1 = np.linspace(22.8e-9, 91.17e-9, nbf)
+    lam_bf2 = np.linspace(91.2e-9, 364.7e-9, nbf)
+    lam = np.concatenate([lam_bb, lam_bf1, lam_bf2])
+    blocks = np.array([0, nbb, nbb, nbb + nbf, nbb + nbf, nbb + 2 * nbf], dtype=np.int64)
+    T = rng.uniform(4e3, 2e4, n)
+    m_H = 1.6735575e-27
+    doppler = lambda0 / C0 * np.sqrt(2 * K_B * T / m_H)
+    gamma = 4.702e8 + 10 ** rng.uniform(6, 10, n)
+    velocity = rng.normal(0, 8e3, (n, 3))
+    n_i = 10 ** rng.uniform(14, 19, n)
+    n_j = n_i * 10 ** rng.uniform(-9, -5, n)
+    Bij = 4.5e20
+    strength = H_PLANCK * C0 / (4 * np.pi * lambda0) * (n_i * Bij - n_j * Bij * 0.25)
+    alpha_cont = 10 ** rng.uniform(-9, -5, n)
+    return dict(lambda0=lambda0, lam=lam, blocks=blocks, T=T, doppler=doppler, gamma=gamma, velocity=velocity,
+                strength=strength, alpha_cont=alpha_cont, n_i=n_i, n_j=n_j, Bij=Bij, rng=rng)
+
+
+def test_oracle_line_opacity_against_numpy_transcription():
+    c = _line_case(300, 1)
+    k = orc.direction(112.8, 335.8)
+    got = orc.line_opacity(k, c["lam"][:51], c["lambda0"], C0, c["velocity"], c["doppler"], c["gamma"],
+                           c["strength"], c["alpha_cont"])
+    from scipy.special import wofz
+    v_los = c["velocity"] @ (-k)
+    lam = c["lam"][:51][None, :]
+    a = c["gamma"][:, None] * lam ** 2 / (4 * np.pi * C0 * c["doppler"][:, None])
+    v = (lam - c["lambda0"] + c["lambda0"] * v_los[:, None] / C0) / c["doppler"][:, None]
+    ref = c["strength"][:, None] * wofz(v + 1j * a).real / (np.sqrt(np.pi) * c["doppler"][:, None]) + c["alpha_cont"][:, None]
+    assert np.abs(got / ref - 1).max() < 1e-4        # w4 vs the exact Faddeeva function
+
+
+def _rates_case(n, seed):
+    c = _line_case(n, seed)
+    rng = c["rng"]
+    nlam = c["lam"].size
+    J = 10 ** rng.uniform(-12, -3, (n, nlam))
+    planck2 = 2 * H_PLANCK * C0 ** 2 / c["lam"] ** 5
+    lte = np.stack([c["n_i"], c["n_j"] * 3.0, c["n_i"] * 10 ** rng.uniform(-6, 0, n)])       # (3, n) == Julia (n, 3)
+    sig1 = 7.9e-22 * (c["lam"][51:71] / c["lam"][70]) ** 3
+    sig2 = 1.4e-21 * (c["lam"][71:91] / c["lam"][90]) ** 3
+    C = 10 ** rng.uniform(-2, 4, (n, 3, 3))
+    for d in range(3):
+        C[:, d, d] = 0.0
+    atom = lte.sum(axis=0) * rng.uniform(0.9, 1.1, n)
+    return c, dict(J=J, planck2=planck2, lte=lte, sig1=sig1, sig2=sig2, C=C, atom=atom,
+                   sigma_bb_const=H_PLANCK * C0 / (4 * np.pi * c["lambda0"]) * c["Bij"],
+                   hc_over_kB=H_PLANCK * C0 / K_B, pref_ij=2 * np.pi / (H_PLANCK * C0) / 1000.0,
+                   pref_ji=2 * np.pi / (H_PLANCK * C0))
+
+
+def test_oracle_rates_and_populations_against_numpy_transcription():
+    c, r = _rates_case(200, 2)
+    lam = c["lam"]
+    R = orc.calculate_R(lam, c["blocks"], r["J"], r["planck2"], c["lambda0"], C0, c["doppler"], c["gamma"],
+                        r["sigma_bb_const"], r["sig1"], r["sig2"], c["T"], r["lte"], r["hc_over_kB"],
+                        r["pref_ij"], r["pref_ji"])
+    # independent transcription of Rij / Rji (rates.jl:226-364) with numpy's own trapezoid
+    def trap(y, x):
+        return ((y[:, 1:] + y[:, :-1]) * np.diff(x)[None, :]).sum(axis=1)
+    for lev, (lo, hi), sig in ((1, (51, 71), r["sig1"]), (2, (71, 91), r["sig2"])):
+        l = lam[lo:hi]
+        G = (r["lte"][lev - 1] / r["lte"][2])[:, None] * np.exp(-r["hc_over_kB"] / (l[None, :] * c["T"][:, None]))
+        rij = r["pref_ij"] * trap(l[None, :] * sig[None, :] * r["J"][:, lo:hi], l)
+        rji = r["pref_ji"] * trap(sig[None, :] * G * l[None, :] * (r["planck2"][None, lo:hi] + r["J"][:, lo:hi]), l)
+        assert np.abs(R[:, 2, lev - 1] / rij - 1).max() < 1e-12      # Julia R[lev, 3, i]
+        assert np.abs(R[:, lev - 1, 2] / rji - 1).max() < 1e-12      # Julia R[3, lev, i]
+    l = lam[:51]
+    a = c["gamma"][:, None] * l[None, :] ** 2 / (4 * np.pi * C0 * c["doppler"][:, None])
+    v = (l[None, :] - c["lambda0"]) / c["doppler"][:, None]
+    H = np.array([[orc.humlicek_w4(v[i, j], a[i, j]).real for j in range(51)] for i in range(v.shape[0])])
+    sig = r["sigma_bb_const"] * H / (np.sqrt(np.pi) * c["doppler"][:, None])
+    G = (r["lte"][0] / r["lte"][1])[:, None] * np.exp(-r["hc_over_kB"] / (l[None, :] * c["T"][:, None]))
+    assert np.abs(R[:, 1, 0] / (r["pref_ij"] * trap(l[None, :] * sig * r["J"][:, :51], l)) - 1).max() < 1e-12
+    assert np.abs(R[:, 0, 1] / (r["pref_ji"] * trap(sig * G * l[None, :] * (r["planck2"][None, :51] + r["J"][:, :51]), l)) - 1).max() < 1e-12
+    assert (R[:, 0, 0] == 0).all() and (R[:, 1, 1] == 0).all() and (R[:, 2, 2] == 0).all()
+    # get_revised_populations (populations.jl:191-221): A x = b per site, with numpy's solver
+    pops = orc.revised_populations(R, r["C"], r["atom"])
+    P = R + r["C"]                                 # P[i, c, r] == Julia P[r+1, c+1, i+1]
+    Pj = lambda rr, cc: P[:, cc - 1, rr - 1]
+    A = np.zeros((R.shape[0], 2, 2))
+    A[:, 0, 0] = Pj(1, 2) + Pj(2, 1) + Pj(2, 3)
+    A[:, 0, 1] = Pj(1, 2) - Pj(3, 2)
+    A[:, 1, 1] = Pj(1, 3) + Pj(3, 1) + Pj(3, 2)
+    A[:, 1, 0] = Pj(1, 3) - Pj(2, 3)
+    b = np.stack([r["atom"] * Pj(1, 2), r["atom"] * Pj(1, 3)], axis=1)
+    x = np.linalg.solve(A, b[:, :, None])[:, :, 0]
+    assert np.abs(pops[1] / x[:, 0] - 1).max() < 1e-9 and np.abs(pops[2] / x[:, 1] - 1).max() < 1e-9
+    assert np.allclose(pops.sum(axis=0), r["atom"], rtol=1e-13)
+
+
+@pytest.mark.gpu
+def test_gpu_line_opacity_native_layout_and_sweep(voro_small):
+    """vrt_line_opacity_dev writes α_tot of every angle in the native layout; the same α through the
+    caller's layout gives the same J bit for bit, and both match the oracle's α / J."""
+    import torch
+    pos, nbr, bounds = voro_small
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    n = hs.n
+    c = _line_case(n, 3)
+    nlam = 51
+    lam = c["lam"][:nlam]
+    # scale the opacities to the box so that Δτ spans the branches
+    scale = 3e4 / c["strength"].max() * c["doppler"].mean()
+    strength, alpha_cont = c["strength"] * scale, c["alpha_cont"] * 1e5
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
+    dev = torch.device("cuda", 0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_vel, d_dop, d_gam, d_str, d_ac = t(c["velocity"]), t(c["doppler"]), t(c["gamma"]), t(strength), t(alpha_cont)
+    native = torch.full((plan.native_alpha_count(nlam),), float("nan"), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.line_opacity_dev(lam, c["lambda0"], C0, d_vel.data_ptr(), d_dop.data_ptr(), d_gam.data_ptr(),
+                          d_str.data_ptr(), d_ac.data_ptr(), native.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    alpha_ref = np.stack([orc.line_opacity(orc.direction(th[a], ph[a]), lam, c["lambda0"], C0, c["velocity"],
+                                           c["doppler"], c["gamma"], strength, alpha_cont) for a in range(nq)])
+    npad = nlam + 1
+    nat = native.cpu().numpy().reshape(nq, npad // 2, n, 2)
+    assert np.isfinite(nat).all()
+    for a in range(nq):
+        order = hs.storage_order(1 if th[a] > 90 else -1) - 1
+        got = nat[a].transpose(1, 0, 2).reshape(n, npad)[:, :nlam]       # [pos][l]
+        assert np.abs(got / alpha_ref[a][order] - 1).max() < 1e-12, a
+    rng = np.random.default_rng(4)
+    S = 1 + rng.random((n, nlam))
+    I0 = rng.random((so.layers_up[1] - 1, nlam))
+    Sd, I0d = t(S), t(I0)
+    J = torch.empty((n, nlam), dtype=torch.float64, device=dev)
+    plan.execute_dev(nlam, nlam, Sd.data_ptr(), native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE, w, dJ=J.data_ptr(),
+                     dI0_up=I0d.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert plan.last_path == "steps"
+    ref = orc.J_voronoi(w, th, ph, S, alpha_ref, so, I0_up=I0, nthreads=4)
+    assert np.abs(J.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-10
+    plan.close()
+    hs.close()
+
+
+@pytest.mark.gpu
+def test_gpu_rates_and_populations_against_oracle(bcc_small):
+    import torch
+    pos, nbr, bounds = bcc_small
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    n = hs.n
+    c, r = _rates_case(n, 5)
+    dev = torch.device("cuda", 0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    ld = c["lam"].size + 3
+    Jd = torch.full((n, ld), float("nan"), dtype=torch.float64, device=dev)
+    Jd[:, : c["lam"].size] = t(r["J"])
+    d_dop, d_gam, d_T, d_lte, d_C, d_atom = t(c["doppler"]), t(c["gamma"]), t(c["T"]), t(r["lte"]), t(r["C"]), t(r["atom"])
+    d_R = torch.empty((n, 3, 3), dtype=torch.float64, device=dev)
+    d_pop = torch.empty((3, n), dtype=torch.float64, device=dev)
+    api.rates_populations_dev(hs, c["lam"], c["blocks"], ld, Jd.data_ptr(), r["planck2"], c["lambda0"], C0,
+                              d_dop.data_ptr(), d_gam.data_ptr(), r["sigma_bb_const"], r["sig1"], r["sig2"],
+                              d_T.data_ptr(), d_lte.data_ptr(), r["hc_over_kB"], r["pref_ij"], r["pref_ji"],
+                              d_C.data_ptr(), d_atom.data_ptr(), d_R.data_ptr(), d_pop.data_ptr(),
+                              stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    R_ref = orc.calculate_R(c["lam"], c["blocks"], r["J"], r["planck2"], c["lambda0"], C0, c["doppler"], c["gamma"],
+                            r["sigma_bb_const"], r["sig1"], r["sig2"], c["T"], r["lte"], r["hc_over_kB"],
+                            r["pref_ij"], r["pref_ji"])
+    R = d_R.cpu().numpy()
+    m = R_ref != 0
+    assert np.array_equal(R == 0, ~m)
+    assert np.abs(R[m] / R_ref[m] - 1).max() < 1e-12
+    pops_ref = orc.revised_populations(R, r["C"], r["atom"])          # same R in: isolates the 2 x 2 solve
+    assert np.array_equal(d_pop.cpu().numpy(), pops_ref)
+    hs.close()

@@ -57,6 +57,10 @@ PROTOTYPES = {
     "vrt_grid_get_storage_order": (ctypes.c_int, [vp, ctypes.c_int, p_i64]),
     "vrt_plan_native_alpha_count": (c_i64, [vp, c_i64]),
     "vrt_plan_alpha_to_native_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp]),
+    "vrt_line_opacity_dev": (ctypes.c_int, [vp, c_i64, p_dbl, c_dbl, c_dbl, vp, vp, vp, vp, vp, vp, vp]),
+    "vrt_rates_populations_dev": (ctypes.c_int, [vp, c_i64, c_i64, p_dbl, p_i64, vp, p_dbl, c_dbl, c_dbl, vp, vp,
+                                                 c_dbl, p_dbl, p_dbl, vp, vp, c_dbl, c_dbl, c_dbl, vp, vp, vp,
+                                                 vp, vp]),
     "vrt_plan_last_sweep_timing": (ctypes.c_int, [vp, p_dbl, p_i64]),
     "vrt_plan_last_path": (ctypes.c_int, [vp]),
     "vrt_schedule_build": (ctypes.c_int, [vp, ctypes.c_int, p_i64, ctypes.c_int,

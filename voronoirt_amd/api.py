@@ -263,6 +263,15 @@ class FormalPlan:
         check(_lib.load().vrt_plan_alpha_to_native_dev(self._h, nlam, ld, dalpha, dalpha_native,
                                                        stream or None))
 
+    def line_opacity_dev(self, lam, lambda0: float, c0: float, d_velocity: int, d_doppler: int, d_gamma: int,
+                         d_line_strength: int, d_alpha_cont: int, d_alpha_native: int, stream: int = 0) -> None:
+        """Fused opacity prologue (`vrt_line_opacity_dev`): α_tot of every angle of this plan from
+        per-site line parameters (device pointers), written in the native layout."""
+        lam = _f64(lam)
+        check(_lib.load().vrt_line_opacity_dev(self._h, lam.size, _d(lam), float(lambda0), float(c0), d_velocity,
+                                               d_doppler, d_gamma, d_line_strength, d_alpha_cont, d_alpha_native,
+                                               stream or None))
+
     def last_sweep_timing(self):
         ms = ctypes.c_double()
         launches = ctypes.c_int64()
@@ -471,3 +480,19 @@ def lambda_update_dev(sites: VoronoiSites, nlam: int, ld: int, dJ: int, dB: int,
     check(_lib.load().vrt_lambda_update_dev(sites.handle, nlam, ld, dJ, dB, deps, dS_old, dS_new,
                                             ctypes.byref(out), stream or None))
     return out.value
+
+
+def rates_populations_dev(sites: VoronoiSites, lam, blocks, ld: int, dJ: int, planck2, lambda0: float, c0: float,
+                          d_doppler: int, d_gamma: int, sigma_bb_const: float, sigma_bf1, sigma_bf2,
+                          d_temperature: int, d_lte: int, hc_over_kB: float, pref_ij: float, pref_ji: float,
+                          d_C: int, d_atom_density: int, d_R: int, d_populations: int, stream: int = 0) -> None:
+    """Device-resident rates + populations epilogue (`vrt_rates_populations_dev`): calculate_R
+    (src/rates.jl:154-201) and get_revised_populations (src/populations.jl:191-221) from J in place."""
+    lam, planck2 = _f64(lam), _f64(planck2)
+    blocks = np.ascontiguousarray(blocks, dtype=np.int64)
+    s1, s2 = _f64(sigma_bf1), _f64(sigma_bf2)
+    check(_lib.load().vrt_rates_populations_dev(sites.handle, lam.size, ld, _d(lam), _i(blocks), dJ, _d(planck2),
+                                                float(lambda0), float(c0), d_doppler, d_gamma, float(sigma_bb_const),
+                                                _d(s1), _d(s2), d_temperature, d_lte, float(hc_over_kB),
+                                                float(pref_ij), float(pref_ji), d_C, d_atom_density, d_R,
+                                                d_populations, stream or None))

@@ -74,6 +74,7 @@ static void free_grid(vrt_grid *g)
     dev_free(g->up.d_lay);
     dev_free(g->down.d_lay);
     dev_free(g->d_scalars);
+    dev_free(g->d_small);
     dev_free(g->up.d_store);
     dev_free(g->down.d_store);
     dev_free(g->up.d_srank);
@@ -1065,6 +1066,87 @@ int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *d
     std::memcpy(&d, &h[0], sizeof(double));
     *max_rel_change = h[1] ? std::nan("") : d;
     return VRT_OK;
+}
+
+// wavelength-sized host arrays -> the grid's device scratch (caller holds g->mu)
+static int upload_small(vrt_grid *g, const std::vector<double> &h, hipStream_t st)
+{
+    if (!g->d_small || g->small_cap < h.size()) {
+        dev_free(g->d_small);
+        g->small_cap = 0;
+        int rc = dev_alloc(&g->d_small, std::max<size_t>(h.size(), 256));
+        if (rc) return rc;
+        g->small_cap = std::max<size_t>(h.size(), 256);
+    }
+    // synchronous w.r.t. the host vector: the copy is enqueued on st and the vector dies at return
+    VRT_HIP_TRY(hipMemcpyAsync(g->d_small, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st));
+    VRT_HIP_TRY(hipStreamSynchronize(st));
+    return VRT_OK;
+}
+
+int vrt_line_opacity_dev(vrt_plan *p, int64_t nlam, const double *lambda, double lambda0, double c0,
+                         const double *d_velocity, const double *d_doppler_width, const double *d_gamma,
+                         const double *d_line_strength, const double *d_alpha_cont, double *d_alpha_native,
+                         void *stream)
+{
+    DeviceScope scope;
+    if (!p || !lambda || !d_velocity || !d_doppler_width || !d_gamma || !d_line_strength || !d_alpha_cont ||
+        !d_alpha_native)
+        return fail(VRT_EINVAL, "NULL argument");
+    if (nlam < 1) return fail(VRT_EINVAL, "nlam must be >= 1");
+    if (!(lambda0 > 0) || !(c0 > 0)) return fail(VRT_EINVAL, "lambda0 and c0 must be positive");
+    try {
+        vrt_grid *g = p->g;
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        if (!p->tile_ok) return fail(VRT_EINVAL, "the native alpha layout needs the layer-step path (layers <= 8192 sites)");
+        std::lock_guard<std::mutex> lock(g->mu);
+        std::vector<double> h(lambda, lambda + nlam);
+        if ((rc = upload_small(g, h, (hipStream_t)stream))) return rc;
+        return launch_line_opacity(p, nlam, g->d_small, lambda0, c0, d_velocity, d_doppler_width, d_gamma,
+                                   d_line_strength, d_alpha_cont, d_alpha_native, (hipStream_t)stream);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_rates_populations_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *lambda,
+                              const int64_t blocks[6], const double *dJ, const double *planck2,
+                              double lambda0, double c0, const double *d_doppler_width, const double *d_gamma,
+                              double sigma_bb_const, const double *sigma_bf1, const double *sigma_bf2,
+                              const double *d_temperature, const double *d_lte_populations, double hc_over_kB,
+                              double pref_ij, double pref_ji, const double *d_C, const double *d_atom_density,
+                              double *d_R, double *d_populations, void *stream)
+{
+    DeviceScope scope;
+    if (!g || !lambda || !blocks || !dJ || !planck2 || !d_doppler_width || !d_gamma || !sigma_bf1 || !sigma_bf2 ||
+        !d_temperature || !d_lte_populations || !d_C || !d_atom_density || !d_R || !d_populations)
+        return fail(VRT_EINVAL, "NULL argument");
+    if (nlam < 2 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 2 and ld >= nlam");
+    for (int b = 0; b < 3; b++)
+        if (blocks[2 * b] < 0 || blocks[2 * b + 1] > nlam || blocks[2 * b + 1] - blocks[2 * b] < 2)
+            return fail(VRT_EINVAL, "each wavelength block needs at least two wavelengths inside [0, nlam)");
+    try {
+        int rc = use_device(g->device);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lock(g->mu);
+        std::vector<double> h;
+        h.insert(h.end(), lambda, lambda + nlam);
+        h.insert(h.end(), planck2, planck2 + nlam);
+        h.insert(h.end(), sigma_bf1, sigma_bf1 + (blocks[3] - blocks[2]));
+        h.insert(h.end(), sigma_bf2, sigma_bf2 + (blocks[5] - blocks[4]));
+        if ((rc = upload_small(g, h, (hipStream_t)stream))) return rc;
+        return launch_rates_populations(g, nlam, ld, blocks, g->d_small, dJ, lambda0, c0, d_doppler_width,
+                                        d_gamma, sigma_bb_const, d_temperature, d_lte_populations, hc_over_kB,
+                                        pref_ij, pref_ji, d_C, d_atom_density, d_R, d_populations,
+                                        (hipStream_t)stream);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
 }
 
 static int single_solve(vrt_grid *g, int dir, const double k[3], const double *S, const double *I0,

@@ -91,6 +91,8 @@ struct vrt_grid {
     double *d_lz = nullptr, *d_lx = nullptr, *d_ly = nullptr;   // Delaunay lines, CSR-packed SoA
     hipStream_t stream = nullptr;
     unsigned long long *d_scalars = nullptr;   // scratch of the Λ-iteration epilogue's reduction
+    double *d_small = nullptr;                 // wavelength-sized host arrays of the physics kernels (λ, 2hc²/λ⁵, σ_bf)
+    size_t small_cap = 0;
     // cache of single-angle plans for vrt_delaunay_up/down
     std::mutex mu;
     std::vector<vrt::PlanCacheEntry *> cache;
@@ -224,6 +226,17 @@ int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, void *dI_out, int64_t ld
 int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, const double *dB,
                          const double *deps, const double *dS_old, double *dS_new,
                          unsigned long long *d_result, hipStream_t st);
+
+// ---- physics either side of the formal solve (vrt_physics.hip) -------------------------------------
+int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, double lambda0, double c0,
+                        const double *d_velocity, const double *d_doppler, const double *d_gamma,
+                        const double *d_strength, const double *d_alpha_cont, double *d_out, hipStream_t st);
+int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_t blocks[6],
+                             const double *d_small, const double *dJ, double lambda0, double c0,
+                             const double *d_doppler, const double *d_gamma, double sigma_bb_const,
+                             const double *d_temperature, const double *d_lte, double hc_over_kB,
+                             double pref_ij, double pref_ji, const double *d_C, const double *d_atom_density,
+                             double *d_R, double *d_populations, hipStream_t st);
 
 // ---- layer-tile path (vrt_tiles.hip) ----------------------------------------------------------
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);

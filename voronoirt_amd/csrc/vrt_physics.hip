@@ -1,0 +1,274 @@
+// The two steps either side of the formal solve in a Λ-iteration, on the device (SURVEY.md 8f rows 2
+// and 4), so that a whole iteration J -> S_new, R, populations -> α -> J ... stays in HBM:
+//
+//   k_line_opacity        per-angle α_tot = αline_λ + α_cont from per-site line parameters
+//                         (src/lambda_iteration.jl:72-80, :89, :93-96; src/line.jl:121-137, :198-208,
+//                         :219-225), written DIRECTLY in the sweep's native storage-pair layout
+//                         (VRT_ALPHA_ANGLE_NATIVE): the (nλ, n, n_angles) array and its layout change
+//                         never exist
+//   k_rates_populations   radiative rates R (calculate_R, src/rates.jl:154-201 with Rij / Rji
+//                         :226-364, σij :374-416, Gij :459-476) and the statistical-equilibrium
+//                         populations (get_revised_populations, src/populations.jl:191-221) from J in
+//                         place: per site a map over the wavelengths, nothing but R (9 n) and the
+//                         populations (3 n) leaves the kernel
+//
+// The Voigt profile is Transparency.jl's `voigt_profile` (absent from the reference checkout,
+// version unpinned): its documented algorithm, Humlíček's w4 (JQSRT 27, 437, 1982), is restated
+// here operation for operation as in oracle/vrt_oracle_physics.c; parity for these two kernels is
+// tolerance-based (1e-12 against that restatement; w4 itself is a 1e-4 approximation of the
+// Faddeeva function).  All quantities are plain numbers in one unit system chosen by the caller;
+// physical constants and unit factors come in as arguments.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <string>
+
+#include "vrt_internal.h"
+
+namespace vrt {
+
+struct cplx { double re, im; };
+__device__ __forceinline__ cplx c_mul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx c_add(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx c_sub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx c_real(double x) { return {x, 0.0}; }
+__device__ __forceinline__ cplx c_scale(cplx a, double s) { return {a.re * s, a.im * s}; }
+__device__ __forceinline__ cplx c_div(cplx a, cplx b)
+{
+    const double d = b.re * b.re + b.im * b.im;
+    return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+
+// Re w4(x + i y), y >= 0: Humlíček's four regions
+__device__ double humlicek_w4_re(double x, double y)
+{
+    const cplx t = {y, -x};
+    const double s = fabs(x) + y;
+    if (s >= 15.0) return c_div(c_scale(t, 0.5641896), c_add(c_real(0.5), c_mul(t, t))).re;
+    if (s >= 5.5) {
+        const cplx u = c_mul(t, t);
+        return c_div(c_mul(t, c_add(c_real(1.410474), c_scale(u, 0.5641896))),
+                     c_add(c_real(0.75), c_mul(u, c_add(c_real(3.0), u)))).re;
+    }
+    if (y >= 0.195 * fabs(x) - 0.176) {
+        cplx num = c_add(c_real(3.778987), c_scale(t, 0.5642236));
+        num = c_add(c_real(11.96482), c_mul(t, num));
+        num = c_add(c_real(20.20933), c_mul(t, num));
+        num = c_add(c_real(16.4955), c_mul(t, num));
+        cplx den = c_add(c_real(6.699398), t);
+        den = c_add(c_real(21.69274), c_mul(t, den));
+        den = c_add(c_real(39.27121), c_mul(t, den));
+        den = c_add(c_real(38.82363), c_mul(t, den));
+        den = c_add(c_real(16.4955), c_mul(t, den));
+        return c_div(num, den).re;
+    }
+    const cplx u = c_mul(t, t);
+    cplx num = c_sub(c_real(1.320522), c_scale(u, 0.56419));
+    num = c_sub(c_real(35.76683), c_mul(u, num));
+    num = c_sub(c_real(219.0313), c_mul(u, num));
+    num = c_sub(c_real(1540.787), c_mul(u, num));
+    num = c_sub(c_real(3321.9905), c_mul(u, num));
+    num = c_sub(c_real(36183.31), c_mul(u, num));
+    cplx den = c_sub(c_real(1.841439), u);
+    den = c_sub(c_real(61.57037), c_mul(u, den));
+    den = c_sub(c_real(364.2191), c_mul(u, den));
+    den = c_sub(c_real(2186.181), c_mul(u, den));
+    den = c_sub(c_real(9022.228), c_mul(u, den));
+    den = c_sub(c_real(24322.84), c_mul(u, den));
+    den = c_sub(c_real(32066.6), c_mul(u, den));
+    const double e = exp(u.re);
+    const cplx ex = {e * cos(u.im), e * sin(u.im)};
+    return c_sub(ex, c_div(c_mul(t, num), den)).re;
+}
+
+constexpr double kPi = 3.14159265358979323846;
+
+__device__ __forceinline__ double voigt_profile(double a, double v, double dD)
+{
+    return humlicek_w4_re(v, a) / (sqrt(kPi) * dD);
+}
+
+// ---- opacity prologue -------------------------------------------------------------------------------
+// one thread per storage position of the angle's direction; it walks the wavelength pairs, so the
+// site's seven line parameters are read once and every pair plane is written coalesced (16 B/lane)
+__global__ void __launch_bounds__(256)
+k_line_opacity(int64_t n, int nlam, int npair, const int32_t *__restrict__ store, double k0, double k1, double k2,
+               const double *__restrict__ lambda, double lambda0, double c0, const double *__restrict__ velocity,
+               const double *__restrict__ doppler, const double *__restrict__ gamma,
+               const double *__restrict__ strength, const double *__restrict__ alpha_cont,
+               double2 *__restrict__ out /* [npair][n] */)
+{
+    const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= n) return;
+    const int32_t site = store[pos];
+    // v_los = dot(velocity, -k)   (line.jl:126, :205)
+    const double v_los = velocity[3 * (size_t)site] * (-k0) + velocity[3 * (size_t)site + 1] * (-k1) +
+                         velocity[3 * (size_t)site + 2] * (-k2);
+    const double dD = doppler[site], gm = gamma[site], st = strength[site], ac = alpha_cont[site];
+    for (int q = 0; q < npair; q++) {
+        double v2[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int l = 2 * q + h;
+            if (l < nlam) {
+                const double lam = lambda[l];
+                const double a = gm * (lam * lam) / (4.0 * kPi * c0 * dD);            // broadening.jl:87-89
+                const double v = (lam - lambda0 + lambda0 * v_los / c0) / dD;          // line.jl:132
+                v2[h] = st * voigt_profile(a, v, dD) + ac;                             // line.jl:133, :219-225; lambda_iteration.jl:93-96
+            } else
+                v2[h] = ac;                                                            // padding wavelength: finite
+        }
+        out[(size_t)q * (size_t)n + (size_t)pos] = make_double2(v2[0], v2[1]);
+    }
+}
+
+int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, double lambda0, double c0,
+                        const double *d_velocity, const double *d_doppler, const double *d_gamma,
+                        const double *d_strength, const double *d_alpha_cont, double *d_out, hipStream_t st)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const int npair = (int)((nlam + 1) / 2);
+    const size_t plane = (size_t)npair * 2 * (size_t)n;
+    for (int a = 0; a < p->A; a++) {
+        const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
+        const double *k = p->k.data() + 3 * (size_t)a;
+        hipLaunchKernelGGL(k_line_opacity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (int)nlam, npair,
+                           dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
+                           d_strength, d_alpha_cont, reinterpret_cast<double2 *>(d_out + (size_t)a * plane));
+    }
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+// ---- rates + populations epilogue ------------------------------------------------------------------
+struct RatesArgs {
+    int64_t n, nlam, ld;
+    int64_t blocks[6];                  // [lo, hi) of the bb, bf-level-1, bf-level-2 wavelength blocks
+    const double *lambda, *planck2;     // [nlam] device
+    const double *sigma_bf1, *sigma_bf2;   // device, one entry per wavelength of the block
+    const double *J;                    // (nlam, n), leading dimension ld
+    double lambda0, c0, sigma_bb_const, hc_over_kB, pref_ij, pref_ji;
+    const double *doppler, *gamma, *temperature, *lte, *C, *atom_density;
+    double *R, *populations;
+};
+
+__device__ __forceinline__ void solve2(const double A[4], const double b[2], double x[2])
+{
+    double a00 = A[0], a10 = A[1], a01 = A[2], a11 = A[3], b0 = b[0], b1 = b[1];
+    if (fabs(a10) > fabs(a00)) {                    // partial pivoting
+        double t;
+        t = a00; a00 = a10; a10 = t;
+        t = a01; a01 = a11; a11 = t;
+        t = b0; b0 = b1; b1 = t;
+    }
+    const double m = a10 / a00;
+    const double u11 = a11 - m * a01;
+    const double y1 = b1 - m * b0;
+    x[1] = y1 / u11;
+    x[0] = (b0 - a01 * x[1]) / a00;
+}
+
+__global__ void __launch_bounds__(256)
+k_rates_populations(RatesArgs ra)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = ra.n;
+    if (i >= n) return;
+    const double *__restrict__ Ji = ra.J + (size_t)i * (size_t)ra.ld;
+    const double T = ra.temperature[i];
+    double R[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) R[q] = 0.0;
+    // ionisation / recombination: levels 1, 2 <-> continuum (rates.jl:170-178)
+    for (int level = 1; level <= 2; level++) {
+        const int64_t lo = ra.blocks[2 * level], hi = ra.blocks[2 * level + 1];
+        const double *__restrict__ sig = level == 1 ? ra.sigma_bf1 : ra.sigma_bf2;
+        const double n_ratio = ra.lte[i + n * (level - 1)] / ra.lte[i + n * 2];
+        double rij = 0.0, rji = 0.0, s_prev = 0.0, G_prev = 0.0, J_prev = 0.0;
+        for (int64_t l = lo; l < hi; l++) {
+            const double lam = ra.lambda[l], s = sig[l - lo], Jl = Ji[l];
+            const double G = n_ratio * exp(-ra.hc_over_kB / (lam * T));                 // Gij, rates.jl:473
+            if (l > lo) {
+                const double lp = ra.lambda[l - 1], dl = lam - lp;
+                rij += ra.pref_ij * ((lp * s_prev * J_prev + lam * s * Jl) * dl);      // :262-263
+                rji += ra.pref_ji * ((s_prev * G_prev * lp * (ra.planck2[l - 1] + J_prev) +
+                                      s * G * lam * (ra.planck2[l] + Jl)) * dl);        // :357-358
+            }
+            s_prev = s; G_prev = G; J_prev = Jl;
+        }
+        R[(level - 1) + 3 * 2] = rij;
+        R[2 + 3 * (level - 1)] = rji;
+    }
+    // bound-bound 1 <-> 2 (rates.jl:183-191): σij carries the static Voigt profile of the site
+    {
+        const int64_t lo = ra.blocks[0], hi = ra.blocks[1];
+        const double n_ratio = ra.lte[i] / ra.lte[i + n];
+        const double dD = ra.doppler[i], gm = ra.gamma[i];
+        double rij = 0.0, rji = 0.0, s_prev = 0.0, G_prev = 0.0, J_prev = 0.0;
+        for (int64_t l = lo; l < hi; l++) {
+            const double lam = ra.lambda[l], Jl = Ji[l];
+            const double a = gm * (lam * lam) / (4.0 * kPi * ra.c0 * dD);
+            const double v = (lam - ra.lambda0) / dD;                                    // rates.jl:408
+            const double s = ra.sigma_bb_const * (humlicek_w4_re(v, a) / (sqrt(kPi) * dD));
+            const double G = n_ratio * exp(-ra.hc_over_kB / (lam * T));
+            if (l > lo) {
+                const double lp = ra.lambda[l - 1], dl = lam - lp;
+                rij += ra.pref_ij * ((lp * s_prev * J_prev + lam * s * Jl) * dl);      // :236-237
+                rji += ra.pref_ji * ((s_prev * G_prev * lp * (ra.planck2[l - 1] + J_prev) +
+                                      s * G * lam * (ra.planck2[l] + Jl)) * dl);        // :312-313
+            }
+            s_prev = s; G_prev = G; J_prev = Jl;
+        }
+        R[0 + 3 * 1] = rij;
+        R[1 + 3 * 0] = rji;
+    }
+    double P[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        ra.R[9 * (size_t)i + q] = R[q];
+        P[q] = R[q] + ra.C[9 * (size_t)i + q];                                           // populations.jl:195
+    }
+    // statistical equilibrium, n_levels = 2 (populations.jl:205-219)
+#define PP(r, c) P[((r) - 1) + 3 * ((c) - 1)]
+    const double N = ra.atom_density[i];
+    double A[4], b[2], x[2];
+    A[0] = PP(1, 2) + PP(2, 1) + PP(2, 3);
+    A[2] = PP(1, 2) - PP(3, 2);
+    A[3] = PP(1, 3) + PP(3, 1) + PP(3, 2);
+    A[1] = PP(1, 3) - PP(2, 3);
+    b[0] = N * PP(1, 2);
+    b[1] = N * PP(1, 3);
+#undef PP
+    solve2(A, b, x);
+    ra.populations[i + n] = x[0];
+    ra.populations[i + 2 * n] = x[1];
+    ra.populations[i] = N - (x[0] + x[1]);
+}
+
+int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_t blocks[6],
+                             const double *d_small /* lambda | planck2 | sigma_bf1 | sigma_bf2 */,
+                             const double *dJ, double lambda0, double c0, const double *d_doppler,
+                             const double *d_gamma, double sigma_bb_const, const double *d_temperature,
+                             const double *d_lte, double hc_over_kB, double pref_ij, double pref_ji,
+                             const double *d_C, const double *d_atom_density, double *d_R,
+                             double *d_populations, hipStream_t st)
+{
+    RatesArgs ra;
+    ra.n = g->n; ra.nlam = nlam; ra.ld = ld;
+    for (int q = 0; q < 6; q++) ra.blocks[q] = blocks[q];
+    ra.lambda = d_small;
+    ra.planck2 = d_small + nlam;
+    ra.sigma_bf1 = d_small + 2 * nlam;
+    ra.sigma_bf2 = ra.sigma_bf1 + (blocks[3] - blocks[2]);
+    ra.J = dJ;
+    ra.lambda0 = lambda0; ra.c0 = c0; ra.sigma_bb_const = sigma_bb_const; ra.hc_over_kB = hc_over_kB;
+    ra.pref_ij = pref_ij; ra.pref_ji = pref_ji;
+    ra.doppler = d_doppler; ra.gamma = d_gamma; ra.temperature = d_temperature; ra.lte = d_lte;
+    ra.C = d_C; ra.atom_density = d_atom_density; ra.R = d_R; ra.populations = d_populations;
+    hipLaunchKernelGGL(k_rates_populations, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, st, ra);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+}  // namespace vrt
