@@ -134,7 +134,8 @@ int vrt_plan_alpha_to_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const do
 /* fp32 VALUE path (BASELINE config C5): S, alpha, I_0, J and the per-angle intensities are stored
  * as float, halving the bytes of this bandwidth-bound path; the geometry tables and all
  * arithmetic stay fp64.  Results agree with the fp64 solve to fp32 storage rounding (~1e-6
- * relative).  Runs on the level kernels. */
+ * relative).  Runs on the layer-step kernels (coefficients handed over and level tiles held as
+ * float) when no layer exceeds 18 432 sites, on the level kernels otherwise. */
 int vrt_plan_execute_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dS,
                              const float *dalpha, int alpha_mode, const float *dI0_up,
                              const float *dI0_down, const double *weights_host, float *dJ,
@@ -144,7 +145,8 @@ int vrt_plan_execute_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float 
 int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches);
 /* which device path the last execute took: 1 = "levels" (one launch per dependency level),
  * 2 = "tiles" (one persistent launch), 3 = "steps" (two launches per BFS layer); 0 = none yet.
- * The environment variable VRT_PATH=levels|tiles|steps overrides the default choice. */
+ * The three paths give the same results; the environment variable VRT_PATH=levels|tiles|steps
+ * overrides the default choice (performance experiments, the parity tests' cross-checks). */
 int vrt_plan_last_path(const vrt_plan *p);
 
 /* ---- schedule introspection (host only, works on a device < 0 grid handle) -----------------

@@ -416,35 +416,94 @@ def test_full_size_sample_against_oracle(full_grid):
         assert _rel(got, ref) < RTOL
 
 
-def test_large_layers_fall_back_to_level_kernels():
-    """Layers above 8192 sites do not fit the LDS layer-tile kernels: the library must choose the
-    general level path by itself, refuse VRT_PATH=tiles/steps, and still match the oracle."""
-    import os
-    pos, nbr, bounds = synth.bcc_grid(66, 3, seed=5)          # 2 * 66^2 = 8712 sites per layer
+def _large_layer_case(a, nlam, seed):
+    pos, nbr, bounds = synth.bcc_grid(a, 3, seed=seed)          # 2 a^2 sites per layer
     hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
     so = orc.make_sites(pos, nbr, bounds)
-    assert int(np.diff(so.layers_up).max()) > 8192
     n = so.n
     rng = np.random.default_rng(8)
-    nlam = 12
     S = 1 + rng.random((n, nlam))
     al = 1e-6 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+    I0 = rng.random((so.layers_up[1] - 1, nlam))
+    return hs, so, S, al, I0
+
+
+def test_layers_of_8712_sites_run_on_the_single_wavelength_step_kernels(monkeypatch):
+    """Layers above 8192 sites exceed the wavelength-PAIR level kernel (16-byte tile slots, 15
+    registers of coefficients per site); up to 12 288 sites they run on the single-wavelength one
+    (fp64, tile in sorted order).  Same results as the level path, to the last bit of the 1e-10 bar."""
+    monkeypatch.delenv("VRT_PATH", raising=False)
+    hs, so, S, al, I0 = _large_layer_case(66, 12, 5)           # 8712 sites per layer
+    assert int(np.diff(so.layers_up).max()) == 8712
     w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
     plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
-    I0 = rng.random((so.layers_up[1] - 1, nlam))
-    old = os.environ.pop("VRT_PATH", None)
-    try:
-        J, _ = plan.execute(S, al, weights=w, I0_up=I0)
-        assert plan.last_path == "levels"                     # 144 problems would otherwise pick "tiles"
-        ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
-        assert _rel(J, ref) < RTOL
-        os.environ["VRT_PATH"] = "steps"
-        with pytest.raises(vrt.VrtError):
-            plan.execute(S, al, weights=w, I0_up=I0)
-    finally:
-        os.environ.pop("VRT_PATH", None)
-        if old is not None:
-            os.environ["VRT_PATH"] = old
+    J, _ = plan.execute(S, al, weights=w, I0_up=I0)
+    assert plan.last_path == "steps"                          # 144 problems <= 256, but layers > 4096: not tiles
+    ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
+    assert _rel(J, ref) < RTOL
+    monkeypatch.setenv("VRT_PATH", "tiles")                   # the persistent tile kernel cannot hold them
+    with pytest.raises(vrt.VrtError):
+        plan.execute(S, al, weights=w, I0_up=I0)
+    monkeypatch.setenv("VRT_PATH", "levels")
+    J2, _ = plan.execute(S, al, weights=w, I0_up=I0)
+    assert _rel(J2, ref) < RTOL
+    plan.close()
+    hs.close()
+
+
+def test_layers_of_17298_sites_fp32_on_steps_fp64_on_levels(monkeypatch):
+    """17 298-site layers (C5's are 17 672): fp32 storage fits the single-wavelength step kernel
+    (float tile and coefficients, 18 sites per thread); fp64 does not (12 288) and must fall back to
+    the level path by itself, refusing VRT_PATH=steps."""
+    import torch
+    monkeypatch.delenv("VRT_PATH", raising=False)
+    hs, so, S, al, I0 = _large_layer_case(93, 6, 6)            # 2 * 93^2 = 17 298 sites per layer
+    assert int(np.diff(so.layers_up).max()) == 17298
+    n, nlam = so.n, S.shape[1]
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    ref = orc.J_voronoi(w, th, ph, S.astype(np.float32).astype(np.float64), al.astype(np.float32).astype(np.float64),
+                        so, I0_up=I0.astype(np.float32).astype(np.float64), nthreads=8)
+    dev = torch.device("cuda", 0)
+    Sd, Ad, I0d = (torch.from_numpy(x.astype(np.float32)).to(dev).contiguous() for x in (S, al, I0))
+    Jd = torch.zeros((n, nlam), dtype=torch.float32, device=dev)
+    plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=Jd.data_ptr(),
+                     dI0_up=I0d.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, f32=True)
+    torch.cuda.synchronize()
+    assert plan.last_path == "steps"
+    assert _rel(Jd.cpu().numpy().astype(np.float64), ref) < 5e-6
+    J, _ = plan.execute(S, al, weights=w, I0_up=I0)           # fp64: too large for the step kernels
+    assert plan.last_path == "levels"
+    assert _rel(J, orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)) < RTOL
+    monkeypatch.setenv("VRT_PATH", "steps")
+    with pytest.raises(vrt.VrtError):
+        plan.execute(S, al, weights=w, I0_up=I0)
+    plan.close()
+    hs.close()
+
+
+def test_layers_of_20000_sites_fall_back_to_the_level_kernels(monkeypatch):
+    """Beyond 18 432 sites per layer nothing holds a layer in one workgroup: both storage types run on
+    the general level path."""
+    import torch
+    monkeypatch.delenv("VRT_PATH", raising=False)
+    hs, so, S, al, I0 = _large_layer_case(100, 4, 7)           # 20 000 sites per layer
+    assert int(np.diff(so.layers_up).max()) == 20000
+    n, nlam = so.n, S.shape[1]
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    J, _ = plan.execute(S, al, weights=w, I0_up=I0)
+    assert plan.last_path == "levels"
+    ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
+    assert _rel(J, ref) < RTOL
+    dev = torch.device("cuda", 0)
+    Sd, Ad, I0d = (torch.from_numpy(x.astype(np.float32)).to(dev).contiguous() for x in (S, al, I0))
+    Jd = torch.zeros((n, nlam), dtype=torch.float32, device=dev)
+    plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=Jd.data_ptr(),
+                     dI0_up=I0d.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, f32=True)
+    torch.cuda.synchronize()
+    assert plan.last_path == "levels"
+    assert _rel(Jd.cpu().numpy().astype(np.float64), ref) < 5e-6
     plan.close()
     hs.close()
 
@@ -472,11 +531,16 @@ def test_default_path_choice(grids):
             os.environ["VRT_PATH"] = old
 
 
-def test_fp32_value_path_against_fp64_oracle(grids):
+@pytest.mark.parametrize("f32_path", ["steps", "levels"])
+def test_fp32_value_path_against_fp64_oracle(grids, f32_path, monkeypatch):
     """BASELINE config C5's path: S, α, I_0, J stored as float32, arithmetic in fp64.  Checked
     against the fp64 oracle fed with the same float32-rounded inputs; the remaining difference is
     the float32 rounding of the stored intensities (tolerance 5e-6 relative, fp64 path: 1e-10)."""
     import torch
+    if f32_path == "levels":
+        monkeypatch.setenv("VRT_PATH", "levels")
+    else:
+        monkeypatch.delenv("VRT_PATH", raising=False)
     hs, so = grids["voronoi"]
     n = so.n
     nlam = 7
@@ -494,7 +558,7 @@ def test_fp32_value_path_against_fp64_oracle(grids):
                      dI0_up=I0d.data_ptr(), dI_out=Id.data_ptr(),
                      stream=torch.cuda.current_stream().cuda_stream, f32=True)
     torch.cuda.synchronize()
-    assert plan.last_path == "levels"
+    assert plan.last_path == f32_path     # fp32 storage runs on the layer-step kernels by default
     ref = orc.J_voronoi(w, th, ph, S.astype(np.float64), al.astype(np.float64), so,
                         I0_up=I0.astype(np.float64), nthreads=4)
     J = Jd.cpu().numpy().astype(np.float64)
@@ -756,11 +820,53 @@ def test_every_level_kernel_instantiation_of_the_step_path(grids, K, monkeypatch
     plan.close()
 
 
+@pytest.mark.parametrize("K", [2, 4, 6, 8, 10, 12, 14, 16, 18])
+@pytest.mark.parametrize("f32", [False, True])
+def test_every_single_wavelength_level_kernel_instantiation(grids, K, f32, monkeypatch):
+    """k_step_levels1 (one wavelength per workgroup, tile in sorted order) is instantiated for even
+    sites-per-thread counts up to 12 (fp64 storage) / 18 (fp32 storage).  VRT_STEP_SINGLE=1 selects it
+    on a small grid, VRT_STEP_K forces the instantiation; fp64 results equal the pair kernel's bit
+    for bit (same arithmetic per wavelength)."""
+    import torch
+    if K > 12 and not f32:
+        pytest.skip("fp64 storage: at most 12 sites per thread")
+    monkeypatch.setenv("VRT_PATH", "steps")
+    monkeypatch.setenv("VRT_STEP_K", str(K))
+    hs, so = grids["voronoi"]
+    n = so.n
+    rng = np.random.default_rng(200 + K)
+    nlam = 5
+    S = 1 + rng.random((n, nlam))
+    al = 1e-6 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+    I0 = rng.random((so.layers_up[1] - 1, nlam))
+    w, th, ph, nq = vrt.read_quadrature("ul2n3.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    if not f32:
+        J_pair, _ = plan.execute(S, al, weights=w, I0_up=I0)
+        monkeypatch.setenv("VRT_STEP_SINGLE", "1")
+        J, _ = plan.execute(S, al, weights=w, I0_up=I0)
+        assert plan.last_path == "steps"
+        assert np.array_equal(J, J_pair)
+        assert _rel(J, orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=4)) < RTOL
+    else:
+        dev = torch.device("cuda", 0)
+        S32, al32, I032 = (x.astype(np.float32) for x in (S, al, I0))
+        Sd, Ad, I0d = (torch.from_numpy(x).to(dev).contiguous() for x in (S32, al32, I032))
+        Jd = torch.zeros((n, nlam), dtype=torch.float32, device=dev)
+        plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=Jd.data_ptr(),
+                         dI0_up=I0d.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, f32=True)
+        torch.cuda.synchronize()
+        assert plan.last_path == "steps"
+        ref = orc.J_voronoi(w, th, ph, S32.astype(np.float64), al32.astype(np.float64), so,
+                            I0_up=I032.astype(np.float64), nthreads=4)
+        assert _rel(Jd.cpu().numpy().astype(np.float64), ref) < 5e-6
+    plan.close()
+
+
 def test_step_path_thread_assignment_does_not_change_results(grids, monkeypatch):
-    """The level kernel deals a layer's sites to its threads sorted by visit pattern (wave-uniform
-    levels); the storage-order assignment (diagnostic flag 64) and every internal stream count
-    must give bit-identical J: the Gauss-Seidel order lives in the visit levels, not in who holds
-    which site."""
+    """Every internal stream count and block-to-XCD mapping of the layer-step path must give
+    bit-identical J: the Gauss-Seidel order lives in the visit levels, not in which workgroup runs
+    where or when."""
     monkeypatch.setenv("VRT_PATH", "steps")
     hs, so = grids["bcc"]
     n = so.n
@@ -771,7 +877,7 @@ def test_step_path_thread_assignment_does_not_change_results(grids, monkeypatch)
     w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
     ks = vrt.quadrature_directions(th, ph)
     out = []
-    for env in ({}, {"VRT_DEBUG_FLAGS": "64"}, {"VRT_STEP_STREAMS": "1"}, {"VRT_STEP_STREAMS": "3", "VRT_STEP_XCD": "0"}):
+    for env in ({}, {"VRT_STEP_STREAMS": "1"}, {"VRT_STEP_STREAMS": "3", "VRT_STEP_XCD": "0"}, {"VRT_STEP_XCD": "1"}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         plan = vrt.FormalPlan(hs, ks, 3)
@@ -783,3 +889,27 @@ def test_step_path_thread_assignment_does_not_change_results(grids, monkeypatch)
     assert _rel(out[0], orc.J_voronoi(w, th, ph, S, al, so, nthreads=4)) < RTOL
     for J in out[1:]:
         assert np.array_equal(J, out[0])
+
+
+def test_diagnostic_environment_variables_cannot_change_results(grids, monkeypatch):
+    """The timing diagnostics that switch memory traffic off live behind -DVRT_DIAG in a separate
+    library (voronoirt_amd/libvrt_hip_diag.so, tools/flags_sweep.sh); the product library ignores
+    their environment variables."""
+    monkeypatch.setenv("VRT_PATH", "steps")
+    assert _lib.LIB_PATH.endswith("libvrt_hip.so")
+    hs, so = grids["bcc"]
+    n = so.n
+    rng = np.random.default_rng(6)
+    nlam = 6
+    S = 1 + rng.random((n, nlam))
+    al = 1e-6 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    J0, _ = plan.execute(S, al, weights=w)
+    monkeypatch.setenv("VRT_DEBUG_FLAGS", "31")
+    monkeypatch.setenv("VRT_DEBUG_SKIP_LEVELS", "1")
+    monkeypatch.setenv("VRT_TILE_DEBUG", "1")
+    J1, _ = plan.execute(S, al, weights=w)
+    assert np.array_equal(J0, J1)
+    assert _rel(J0, orc.J_voronoi(w, th, ph, S, al, so, nthreads=4)) < RTOL
+    plan.close()

@@ -41,7 +41,7 @@ stream = torch.cuda.current_stream().cuda_stream
 for path in (None, "levels", "steps", "tiles"):
     if path:
         os.environ["VRT_PATH"] = path
-    if path in ("steps", "tiles") and max(lu.max(), ld_.max()) > 8192:
+    if (path == "tiles" and max(lu.max(), ld_.max()) > 8192) or (path == "steps" and max(lu.max(), ld_.max()) > 12288):
         continue
     for _ in range(2):
         plan.execute_dev(nlam, nlam, S.data_ptr(), al.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=J.data_ptr(), dI0_up=I0.data_ptr(), stream=stream)

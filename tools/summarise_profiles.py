@@ -2,24 +2,36 @@
 """Copies the judged summaries of a tools/make_profiles.sh run from gpurun_out/ into profiles/<round>/
 (kernel-trace stats csv, bench JSON lines, and the per-kernel PMC sums inside c4_summary.json).
 
-    python tools/summarise_profiles.py <tag> <round-dir>     e.g.  r1b r1
+    python tools/summarise_profiles.py <tag> <round-dir>     e.g.  r2 r2
+
+c4_summary.json carries the digest of the kernel sources the profile was taken with
+(bench.source_digest): bench.py quotes `roofline.traffic` from it only while the library is that
+exact one.
 """
-import collections, csv, glob, json, os, shutil, sys
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
 
 tag, rnd = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import bench  # noqa: E402  (source_digest, ONE_TIME_KERNELS)
+
 go, out = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles", rnd)
 os.makedirs(out, exist_ok=True)
 
 stats_csv = glob.glob(os.path.join(go, f"prof_{tag}_default", "**", "*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(stats_csv, os.path.join(out, "c4_steps_default_kernel_stats.csv"))
-bench_log = open(os.path.join(go, f"prof_{tag}_default", "bench.log")).read().splitlines()
-steps_total = 7    # tools/make_profiles.sh: 2 warm-up + 5 timed steps under the profiler
+steps_total = 4    # tools/prof_kernels.sh: 1 warm-up + 3 timed steps under the profiler
 ks = {}
 for r in csv.DictReader(open(stats_csv)):
     if r["Name"].startswith(("vrt::", "void vrt::")):
         name = r["Name"].split("(")[0]
-        once = any(k in name for k in ("k_upwind_table", "k_permute_table", "k_delaunay_lines", "k_sorted_tables", "k_gpos"))
+        once = any(k in name for k in bench.ONE_TIME_KERNELS)
         ks[name] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                     "ms_per_step": float(r["TotalDurationNs"]) / 1e6 / (1 if once else steps_total)}
 pmc = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -28,18 +40,35 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
         for r in csv.DictReader(open(f)):
             if r["Kernel_Name"].startswith(("vrt::", "void vrt::")):
                 pmc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]] += float(r["Counter_Value"])
-summary_path = os.path.join(out, "c4_summary.json")
-summary = json.load(open(summary_path)) if os.path.exists(summary_path) else {"kernel_stats": {}, "pmc_one_step": {}}
-summary["kernel_stats"]["steps_default"] = ks
-summary["pmc_one_step"]["steps_default"] = {k: dict(v) for k, v in pmc.items()}
-summary["note_steps_default"] = (
-    "steps_default re-profiled with tools/make_profiles.sh after the wavelength-pair layout, the sorted "
-    "thread assignment of k_step_levels and the compact coupling list (kernel_stats: 2 warm-up + 5 timed "
-    "steps, two internal streams, so launches of the two angle groups overlap and the summed durations "
-    "exceed the sweep window; pmc: ONE step, separate passes per counter, FETCH_SIZE/WRITE_SIZE in KiB).  "
-    "The levels and tiles sections are the earlier profiles of those (unchanged) kernels.")
-json.dump(summary, open(summary_path, "w"), indent=1)
-for src, dst in ((f"{tag}_bench_default.json", "bench_default.json"), (f"{tag}_bench_c3.json", "bench_c3_default.json")):
-    line = [l for l in open(os.path.join(go, src)).read().splitlines() if l.startswith("{")][-1]
-    open(os.path.join(out, dst), "w").write(line + "\n")
+bench_line = [ln for ln in open(os.path.join(go, f"{tag}_bench_default.json")).read().splitlines() if ln.startswith("{")][-1]
+b = json.loads(bench_line)
+per_step = {k: v for k, v in pmc.items() if not any(o in k for o in bench.ONE_TIME_KERNELS)}
+total = sum((2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0 for c in per_step.values())
+summary = {
+    "note": "rocprofv3 on MI355X, `python bench.py` default command (C4: 995566 sites x 12 angles x 51 wavelengths, "
+            "fp64, per-angle alpha in the native layout).  kernel_stats: --kernel-trace --stats over 1 warm-up + 3 "
+            "timed steps (tools/prof_kernels.sh); one-time kernels (tables, layout change of alpha) are plan "
+            "creation / set-up, not part of a step.  pmc_one_step: separate --pmc passes of ONE step "
+            "(tools/prof_pmc.sh), sums over all dispatches of a kernel, FETCH_SIZE / WRITE_SIZE in KiB; per "
+            "MI355X_MICROARCH.md FETCH_SIZE tallies 128-B requests at 64 B on gfx950, so bytes = 2 x FETCH_SIZE + "
+            "WRITE_SIZE.  The sweep runs on two internal streams, so launches of the two directions overlap and "
+            "their summed durations exceed the wall time of the sweep.",
+    "source_digest": bench.source_digest(),
+    "alpha_layout": b["config"].get("alpha_layout"),
+    "path": b["roofline"]["path"],
+    "bench": {"ms_per_step": b["ms_per_step"], "step_event_ms": b["roofline"]["step_event_ms"],
+              "sweep_ms": b["roofline"]["sweep_only"]["ms"], "frac": b["roofline"]["frac"]},
+    "traffic_bytes_per_step": total,
+    "algorithmic_bytes_per_step": b["roofline"]["algorithmic_bytes_per_step"],
+    "kernel_stats": ks,
+    "pmc_one_step": {k: dict(v) for k, v in pmc.items()},
+}
+json.dump(summary, open(os.path.join(out, "c4_summary.json"), "w"), indent=1)
+for src, dst in ((f"{tag}_bench_default.json", "bench_default.json"), (f"{tag}_bench_c3.json", "bench_c3_default.json"),
+                 (f"{tag}_bench_c5_f32.json", "bench_c5_f32.json")):
+    path = os.path.join(go, src)
+    if os.path.exists(path):
+        line = [ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1]
+        open(os.path.join(out, dst), "w").write(line + "\n")
 print(json.dumps(ks, indent=1)[:1500])
+print("traffic per step %.1f GB, algorithmic %.1f GB" % (total / 1e9, b["roofline"]["algorithmic_bytes_per_step"] / 1e9))

@@ -32,10 +32,21 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP/C++ source of the product into voronoirt_amd/libvrt_hip.so."""
+def build_library(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """Compile every HIP/C++ source of the product into voronoirt_amd/libvrt_hip.so.
+
+    diag=True builds voronoirt_amd/libvrt_hip_diag.so with -DVRT_DIAG instead: the timing diagnostics
+    that switch pieces of the memory traffic off (VRT_DEBUG_FLAGS, VRT_DEBUG_SKIP_LEVELS,
+    VRT_TILE_DEBUG; wrong results) exist only there.  tools/flags_sweep.sh selects it with
+    VRT_LIB_PATH; nothing else loads it."""
+    if diag:
+        return _build(os.path.join(HERE, "libvrt_hip_diag.so"), ["-DVRT_DIAG"], verbose)
     if not force and not is_stale():
         return LIB
+    return _build(LIB, [], verbose)
+
+
+def _build(out: str, extra, verbose: bool) -> str:
     cmd = [
         _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
         # build-wide floating-point contract: no FMA contraction on host or device, so neighbour
@@ -43,13 +54,13 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         "-ffp-contract=off", "-fno-fast-math",
         "-Wall", "-Wno-unused-result",
         "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-        "-o", LIB,
-    ] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
+        "-o", out,
+    ] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

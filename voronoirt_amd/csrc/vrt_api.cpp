@@ -175,6 +175,8 @@ static void free_plan(vrt_plan *p)
     dev_free(p->t_vis_s);
     dev_free(p->t_loc_s);
     dev_free(p->t_gpos);
+    dev_free(p->t_rank_s);
+    dev_free(p->t_loc_ss);
     dev_free(p->d_nlev); dev_free(p->d_angle_dir); dev_free(p->d_task_map);
     for (int d = 0; d < 2; d++) { dev_free(p->ws_S[d]); dev_free(p->ws_A[d]); dev_free(p->ws_J[d]); }
     dev_free(p->ws_AA);
@@ -409,7 +411,9 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             max_layer = std::max(max_layer, lsched[(size_t)a].max_layer_size);
             visits += lsched[(size_t)a].n_visits;
         }
-        if (max_layer > 8 * 1024) ok = false;     // 8 sites per thread of a 1024-thread workgroup
+        // the layer-step level kernels hold a whole layer per workgroup: 8192 sites as fp64 wavelength
+        // pairs, 12 288 as fp64 single wavelengths, 18 432 as fp32 ones (vrt_tiles.hip)
+        if (max_layer > steps_max_layer(/*f32=*/true)) ok = false;
         if (n >= ((int64_t)1 << 28)) ok = false;  // the tile kernels index 16-byte pair planes with 32-bit byte offsets
         p->tile_ok = ok;
         p->tile_max_layer_size = max_layer;
@@ -428,6 +432,8 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             VRT_TRY_FREE(dev_alloc(&p->t_vis_s, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_loc_s, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_gpos, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_rank_s, tab));
+            VRT_TRY_FREE(dev_alloc(&p->t_loc_ss, tab));
             uint32_t *d_vis_site = nullptr;
             VRT_TRY_FREE(dev_alloc(&d_vis_site, (size_t)n));
             const int maxL = (int)std::max(g->up.reduced.size(), g->down.reduced.size()) - 1;
@@ -487,9 +493,8 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
                               const void *dI0_down_, const double *weights, void *dJ_,
                               void *dI_out_, hipStream_t st, bool f32 = false)
 {
-    const double *dS = (const double *)dS_, *dalpha = (const double *)dalpha_;
-    const double *dI0_up = (const double *)dI0_up_, *dI0_down = (const double *)dI0_down_;
-    double *dJ = (double *)dJ_, *dI_out = (double *)dI_out_;
+    const void *dS = dS_, *dalpha = dalpha_;
+    void *dJ = dJ_, *dI_out = dI_out_;
     vrt_grid *g = p->g;
     if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
     if (!dS || !dalpha) return fail(VRT_EINVAL, "S and alpha must not be NULL");
@@ -502,39 +507,39 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
     // coincide unless a θ = 90 direction was skipped, which per-angle alpha does not support.
     if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM && p->A != (int)p->n_angles_user)
         return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
-    if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && (f32 || !p->tile_ok))
-        return fail(VRT_EINVAL, "native-layout alpha needs the fp64 layer-step path (layers <= 8192 sites)");
+    const bool steps_ok = p->tile_ok && p->tile_max_layer_size <= steps_max_layer(f32);
+    if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && (f32 || !steps_ok))
+        return fail(VRT_EINVAL, "native-layout alpha needs the fp64 layer-step path (layers <= 12288 sites)");
     {
         // Three device paths produce the same results:
         //   "levels"  one launch per dependency level over all angles; any grid;
         //   "steps"   two launches per BFS layer: chip-wide coefficient kernel + one workgroup per
         //             (angle, wavelength) running the layer's Gauss-Seidel levels on an LDS tile;
         //   "tiles"   ONE launch: each (angle, wavelength) workgroup walks all layers itself.
-        // steps/tiles need layers of at most 8192 sites and <= 255 levels per layer.  Default when
-        // that holds: tiles while the (angle, wavelength) problems fit one round of workgroups
-        // (<= 256) AND the layers are small (<= 4096 sites: the one launch has no per-layer launch
-        // cost -- C2, 2738-site layers: 1.2 ms vs 1.8 ms on steps, which is host-launch-bound
-        // there); steps otherwise (its chip-wide coefficient kernel wins once a layer holds more
-        // than a few sites per thread -- 1M sites x 12 angles x 1 λ: 5.1 vs 7.8 ms; C4: 11.8 vs
-        // 20.5 ms); levels when the grid does not fit and for the fp32 value path.
+        // tiles needs layers of at most 8192 sites, steps of at most 12 288 (fp64) / 18 432 (fp32
+        // storage) and both <= 255 levels per layer.  Default when that holds: tiles while the
+        // (angle, wavelength) problems fit one round of workgroups (<= 256) AND the layers are small
+        // (<= 4096 sites: the one launch has no per-layer launch cost -- C2, 2738-site layers: 1.2 ms
+        // vs 1.8 ms on steps, which is host-launch-bound there); steps otherwise (its chip-wide
+        // coefficient kernel wins once a layer holds more than a few sites per thread -- 1M sites x
+        // 12 angles x 1 λ: 5.1 vs 7.8 ms; C4: 11.8 vs 20.5 ms); levels when the grid does not fit.
         // VRT_PATH selects one explicitly.
         const char *force = std::getenv("VRT_PATH");
+        const bool tiles_ok = steps_ok && !f32 && p->tile_max_layer_size <= 8192;
         int path = 1;
-        if (p->tile_ok && !f32)
-            path = ((int64_t)p->A * nlam <= 256 && p->tile_max_layer_size <= 4096) ? 2 : 3;
+        if (steps_ok)
+            path = (tiles_ok && (int64_t)p->A * nlam <= 256 && p->tile_max_layer_size <= 4096) ? 2 : 3;
         if (force && std::strcmp(force, "levels") == 0) path = 1;
         if (force && std::strcmp(force, "tiles") == 0) path = 2;
         if (force && std::strcmp(force, "steps") == 0) path = 3;
         if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE) path = 3;    // the layout IS the layer-step path's
         if (p->A == 0) path = 1;      // nothing to solve (every direction skipped): J = 0 via the level path
-        if (path != 1 && !p->tile_ok)
-            return fail(VRT_EINVAL, "VRT_PATH=tiles/steps but the grid does not fit the layer-tile kernels");
-        if (path != 1 && f32)
-            return fail(VRT_EINVAL, "the fp32 value path runs on the level kernels only (VRT_PATH=levels)");
+        if ((path == 3 && !steps_ok) || (path == 2 && !tiles_ok))
+            return fail(VRT_EINVAL, "VRT_PATH=tiles/steps but the grid (or the fp32 storage type) does not fit those kernels");
         if (path != 1) {
             p->last_path = path;
-            return execute_tiles(p, nlam, ld, dS, dalpha, alpha_mode, dI0_up, dI0_down, weights, dJ,
-                                 dI_out, st);
+            return execute_tiles(p, nlam, ld, dS_, dalpha_, alpha_mode, dI0_up_, dI0_down_, weights, dJ_,
+                                 dI_out_, st, f32);
         }
         p->last_path = 1;
     }
@@ -1099,7 +1104,8 @@ int vrt_line_opacity_dev(vrt_plan *p, int64_t nlam, const double *lambda, double
         vrt_grid *g = p->g;
         int rc = use_device(g->device);
         if (rc) return rc;
-        if (!p->tile_ok) return fail(VRT_EINVAL, "the native alpha layout needs the layer-step path (layers <= 8192 sites)");
+        if (!p->tile_ok || p->tile_max_layer_size > steps_max_layer(false))
+            return fail(VRT_EINVAL, "the native alpha layout needs the fp64 layer-step path (layers <= 12288 sites)");
         std::lock_guard<std::mutex> lock(g->mu);
         std::vector<double> h(lambda, lambda + nlam);
         if ((rc = upload_small(g, h, (hipStream_t)stream))) return rc;

@@ -142,6 +142,8 @@ struct vrt_plan {
     int32_t *t_self = nullptr;           // [A][n] sorted index (absolute) -> storage position
     uint32_t *t_vis_s = nullptr, *t_loc_s = nullptr;   // t_vis / t_loc in sorted order
     uint32_t *t_gpos = nullptr;          // [A][n] compact in-layer coupling list (k_gpos)
+    int32_t *t_rank_s = nullptr;         // [A][n] storage position -> sorted index (inverse of t_self)
+    uint32_t *t_loc_ss = nullptr;        // [A][n] upwind tile slots of the sorted entries, in SORTED terms
     int32_t *d_nlev = nullptr, *d_angle_dir = nullptr;
     std::vector<int64_t> angle_visits;   // surviving visits per active angle (task cost)
     std::vector<int32_t> h_task_map;     // block -> angle | wavelength << 8
@@ -243,8 +245,9 @@ int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
 int launch_sorted_tables(vrt_plan *p, int a);
 int launch_gpos(vrt_plan *p, int a);
 int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha, double *out, hipStream_t st);
-int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const double *dalpha,
-                  int alpha_mode, const double *dI0_up, const double *dI0_down,
-                  const double *weights_user, double *dJ, double *dI_out, hipStream_t st);
+int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, const void *dalpha,
+                  int alpha_mode, const void *dI0_up, const void *dI0_down,
+                  const double *weights_user, void *dJ, void *dI_out, hipStream_t st, bool f32);
+int64_t steps_max_layer(bool f32);   // largest layer the layer-step level kernels hold
 
 }  // namespace vrt

@@ -96,13 +96,37 @@ int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site)
 // visit levels and tile slots in the sorted thread order of k_step_levels (build_sorted_slots)
 __global__ void __launch_bounds__(256)
 k_sorted_tables(int64_t n, const int32_t *__restrict__ self, const uint32_t *__restrict__ t_vis,
-                const uint32_t *__restrict__ t_loc, uint32_t *__restrict__ vis_s, uint32_t *__restrict__ loc_s)
+                const uint32_t *__restrict__ t_loc, uint32_t *__restrict__ vis_s, uint32_t *__restrict__ loc_s,
+                int32_t *__restrict__ rank_s)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t p = self[i];
     vis_s[i] = t_vis[p];
     loc_s[i] = t_loc[p];
+    rank_s[p] = (int32_t)i;              // storage position -> sorted index (absolute)
+}
+
+// the single-wavelength level kernel keeps its LDS tile in SORTED order (a thread's write address is
+// then its own index, no per-site register): the two upwind tile slots of sorted entry i, also in
+// sorted terms
+__global__ void __launch_bounds__(256)
+k_sorted_loc(int64_t n, const int32_t *__restrict__ lay, int nlayers, const uint32_t *__restrict__ loc_s,
+             const int32_t *__restrict__ rank_s, uint32_t *__restrict__ loc_ss)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int lo_i = 0, hi_i = nlayers;                  // layer of sorted index i (sorting stays inside layers)
+    while (hi_i - lo_i > 1) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (lay[mid] <= i) lo_i = mid; else hi_i = mid;
+    }
+    const int lo = lay[lo_i];
+    const uint32_t l = loc_s[i];
+    const uint32_t l1 = l & 0xFFFFu, l2 = l >> 16;
+    const uint32_t s1 = l1 == kNoSlot ? kNoSlot : (uint32_t)(rank_s[lo + (int)l1] - lo);
+    const uint32_t s2 = l2 == kNoSlot ? kNoSlot : (uint32_t)(rank_s[lo + (int)l2] - lo);
+    loc_ss[i] = s1 | (s2 << 16);
 }
 
 int launch_sorted_tables(vrt_plan *p, int a)
@@ -110,8 +134,12 @@ int launch_sorted_tables(vrt_plan *p, int a)
     vrt_grid *g = p->g;
     const int64_t n = g->n;
     const size_t o = (size_t)a * (size_t)n;
-    hipLaunchKernelGGL(k_sorted_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g->stream, n,
-                       p->t_self + o, p->t_vis + o, p->t_loc + o, p->t_vis_s + o, p->t_loc_s + o);
+    const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(k_sorted_tables, grid, dim3(256), 0, g->stream, n, p->t_self + o, p->t_vis + o,
+                       p->t_loc + o, p->t_vis_s + o, p->t_loc_s + o, p->t_rank_s + o);
+    hipLaunchKernelGGL(k_sorted_loc, grid, dim3(256), 0, g->stream, n, dir.d_lay, (int)dir.reduced.size() - 1,
+                       p->t_loc_s + o, p->t_rank_s + o, p->t_loc_ss + o);
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
@@ -121,7 +149,7 @@ int launch_sorted_tables(vrt_plan *p, int a)
 // kernels exchange the couplings as a dense list per (angle, wavelength pair, layer):
 //   t_gpos[a][p] = position of the site's first in-layer coupling in that list (exclusive prefix
 //                  count over the layer's storage order) | in1 << 30 | in2 << 31
-// one workgroup per (layer, angle); a thread scans 8 consecutive slots (layers <= 8192 sites).
+// one workgroup per (layer, angle); a thread scans ceil(cnt / 1024) consecutive slots.
 __global__ void __launch_bounds__(1024)
 k_gpos(int64_t n, const int32_t *__restrict__ lay, int nlayers, const int32_t *__restrict__ t_u1,
        const int32_t *__restrict__ t_u2, uint32_t *__restrict__ gpos)
@@ -131,17 +159,13 @@ k_gpos(int64_t n, const int32_t *__restrict__ lay, int nlayers, const int32_t *_
     if (layer > nlayers) return;
     const int lo = lay[layer - 1], hi = lay[layer], cnt = hi - lo;
     const int tid = threadIdx.x;
-    uint32_t fl[8];
+    const int per = (cnt + 1023) / 1024;
     int sum = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int s = tid * 8 + j;
-        fl[j] = 0;
+    for (int j = 0; j < per; j++) {
+        const int s = tid * per + j;
         if (s < cnt) {
             const int u1 = t_u1[lo + s], u2 = t_u2[lo + s];
-            const uint32_t in1 = (u1 >= lo) & (u1 < hi), in2 = (u2 >= lo) & (u2 < hi);
-            fl[j] = in1 | (in2 << 1);
-            sum += (int)(in1 + in2);
+            sum += (int)((u1 >= lo) & (u1 < hi)) + (int)((u2 >= lo) & (u2 < hi));
         }
     }
     part[tid] = sum;
@@ -153,12 +177,13 @@ k_gpos(int64_t n, const int32_t *__restrict__ lay, int nlayers, const int32_t *_
         __syncthreads();
     }
     int pos = part[tid] - sum;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int s = tid * 8 + j;
+    for (int j = 0; j < per; j++) {
+        const int s = tid * per + j;
         if (s < cnt) {
-            gpos[lo + s] = (uint32_t)pos | (fl[j] << 30);
-            pos += (int)((fl[j] & 1u) + (fl[j] >> 1));
+            const int u1 = t_u1[lo + s], u2 = t_u2[lo + s];
+            const uint32_t in1 = (u1 >= lo) & (u1 < hi), in2 = (u2 >= lo) & (u2 < hi);
+            gpos[lo + s] = (uint32_t)pos | (in1 << 30) | (in2 << 31);
+            pos += (int)(in1 + in2);
         }
     }
 }
@@ -190,23 +215,35 @@ __device__ __forceinline__ size_t sw_index(int l, int64_t p, int64_t n, int lb)
                    : (((size_t)(l >> 1) * (size_t)n + (size_t)p) << 1) + (size_t)(l & 1);
 }
 
+// storage types: T = double, or float for the fp32 VALUE path (BASELINE config C5: S, α, I, J held as
+// float, all arithmetic fp64); a wavelength pair is one 16-byte (double2) or 8-byte (float2) access
+template <typename T> struct Pair;
+template <> struct Pair<double> { typedef double2 type; };
+template <> struct Pair<float> { typedef float2 type; };
+__device__ __forceinline__ double2 to_d2(double2 v) { return v; }
+__device__ __forceinline__ double2 to_d2(float2 v) { return make_double2((double)v.x, (double)v.y); }
+template <typename T> __device__ __forceinline__ typename Pair<T>::type from_d2(double2 v);
+template <> __device__ __forceinline__ double2 from_d2<double>(double2 v) { return v; }
+template <> __device__ __forceinline__ float2 from_d2<float>(double2 v) { return make_float2((float)v.x, (float)v.y); }
+
 // out[l][p] = in[order[p]][l]   (caller's (nλ, n) site-major rows -> wavelength-major sweep order)
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_to_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__restrict__ order,
-                 const double *__restrict__ in, double *__restrict__ out)
+                 const T *__restrict__ in, T *__restrict__ out)
 {
-    __shared__ double tile[64][65];
+    __shared__ T tile[64][65];
     __shared__ int32_t rows[64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
     const int l0 = blockIdx.y * 64;
     if (threadIdx.x < 64) rows[threadIdx.x] = p0 + threadIdx.x < n ? order[p0 + threadIdx.x] : -1;
     __syncthreads();
-    double v[16];
+    T v[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {          // 16 independent row reads in flight per thread
         const int32_t site = rows[ty + 4 * j];
-        v[j] = (site >= 0 && l0 + tx < nlam) ? in[(size_t)site * ld + l0 + tx] : 0.0;
+        v[j] = (site >= 0 && l0 + tx < nlam) ? in[(size_t)site * ld + l0 + tx] : (T)0;
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) tile[ty + 4 * j][tx] = v[j];
@@ -222,53 +259,55 @@ k_to_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__restr
         for (int j = 0; j < 8; j++) {
             const int c = 2 * (ty + 4 * j), l = l0 + c;
             if (l < nlam && p0 + tx < n) {
-                double2 v;
-                v.x = tile[tx][c];
-                v.y = l + 1 < nlam ? tile[tx][c + 1] : 0.0;
-                reinterpret_cast<double2 *>(out)[(size_t)(l >> 1) * (size_t)n + (size_t)(p0 + tx)] = v;
+                typename Pair<T>::type v2;
+                v2.x = tile[tx][c];
+                v2.y = l + 1 < nlam ? tile[tx][c + 1] : (T)0;
+                reinterpret_cast<typename Pair<T>::type *>(out)[(size_t)(l >> 1) * (size_t)n + (size_t)(p0 + tx)] = v2;
             }
         }
     }
 }
 
 // out[p] = in[order[p]]   (per-site vector, e.g. wavelength-independent α)
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_gather_vec(int64_t n, const int32_t *__restrict__ order, const double *__restrict__ in,
-             double *__restrict__ out)
+k_gather_vec(int64_t n, const int32_t *__restrict__ order, const T *__restrict__ in,
+             T *__restrict__ out)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) out[p] = in[order[p]];
 }
 
 // I[a][l][p] = I0[p][l] for p < n1 (boundary layer, already in sweep order), blockIdx.z = angle slot
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_boundary_sweep_order(int64_t n, int nlam, int lb, int64_t n1, const int32_t *__restrict__ angles,
                        const int32_t *__restrict__ order, const int32_t *__restrict__ srank,
-                       const double *__restrict__ I0, double *__restrict__ I)
+                       const T *__restrict__ I0, T *__restrict__ I)
 {
-    __shared__ double tile[64][65];
+    __shared__ T tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
     const int l0 = blockIdx.y * 64;
     const int a = angles[blockIdx.z];
     for (int r = ty; r < 64; r += 4) {
         const int64_t p = p0 + r;
-        if (p < n1 && l0 + tx < nlam) tile[r][tx] = I0 ? I0[(size_t)p * nlam + l0 + tx] : 0.0;
+        if (p < n1 && l0 + tx < nlam) tile[r][tx] = I0 ? I0[(size_t)p * nlam + l0 + tx] : (T)0;
     }
     __syncthreads();
     const int nl_pad = (nlam + lb - 1) / lb * lb;
-    double *Ia = I + (size_t)a * (size_t)nl_pad * (size_t)n;
+    T *Ia = I + (size_t)a * (size_t)nl_pad * (size_t)n;
     for (int c = ty; c < 64; c += 4) {
         const int l = l0 + c;
         // I_0 is ordered like perm[1:n1] (irregular_ray_tracing.jl:33); storage is Morton order
         if (l < nlam && p0 + tx < n1) {
             const int32_t pos = srank[order[p0 + tx]];
             Ia[sw_index(l, pos, n, lb)] = tile[tx][c];
-            if (l == nlam - 1 && nl_pad > nlam) Ia[sw_index(nlam, pos, n, lb)] = 0.0;   // padding wavelength
+            if (l == nlam - 1 && nl_pad > nlam) Ia[sw_index(nlam, pos, n, lb)] = (T)0;   // padding wavelength
         }
         // the never-visited site perm[n] (storage position n-1) keeps I = 0 (voronoi_utils.jl:266)
         // -- also on a single-layer grid, where no layer kernel ever runs
-        if (blockIdx.x == 0 && tx == 0 && l < nl_pad) Ia[sw_index(l, n - 1, n, lb)] = 0.0;
+        if (blockIdx.x == 0 && tx == 0 && l < nl_pad) Ia[sw_index(l, n - 1, n, lb)] = (T)0;
     }
 }
 
@@ -551,6 +590,8 @@ struct StepArgs {
     int pairs_per_thread;     // wavelength pairs one k_step_coeffs thread loops over
     int chunks;               // 256-slot chunks per layer (k_step_coeffs grid.x / 1)
     int xcd_map;              // 0: plain grid; 1, 2: contiguous chunk ranges per XCD (2: angle fastest)
+    const int32_t *t_rank_s;  // single-wavelength level kernel: storage position -> sorted index
+    const uint32_t *t_loc_ss; //   and the upwind tile slots in sorted terms
     int debug_skip_levels;    // diagnostics only (VRT_DEBUG_SKIP_LEVELS=1): wrong results
     int debug_flags;          // diagnostics only (VRT_DEBUG_FLAGS bit mask): wrong results, see execute_tiles
 };
@@ -558,6 +599,10 @@ struct StepArgs {
 __device__ __forceinline__ double2 ld2(const double2 *base, unsigned idx)
 {
     return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + ((size_t)idx << 4));
+}
+__device__ __forceinline__ double2 ld2(const float2 *base, unsigned idx)     // fp32 storage, fp64 arithmetic
+{
+    return to_d2(*reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + ((size_t)idx << 3)));
 }
 
 // one upwind's share of the visit: t = ((e I_u + a S_u) + b S_c) w  (I_u dropped unless the upwind
@@ -581,9 +626,15 @@ __device__ __forceinline__ void upwind_term(double r, double w, double a_c, doub
 // grid: x = slot chunk, y = angle * ceil(npair / kStepPairs) + pair group
 constexpr int kStepPairs = 4;   // default pairs per thread (VRT_STEP_PAIRS overrides)
 
+// T: storage type of S, α, I.  SPLIT = false: the coefficients go to the pair level kernel as double2
+// (c) + a compact double2 list (g); SPLIT = true: to the single-wavelength level kernel as one
+// plane of T per wavelength (c[l][slot], compact g[l][..]) -- fp32 on the fp32 value path, which
+// halves the hand-off bytes.
+template <typename T, bool SPLIT>
 __global__ void __launch_bounds__(256)
 k_step_coeffs(StepArgs sa)
 {
+    typedef typename Pair<T>::type T2;
     const TileArgs &ta = sa.ta;
     const int ppt = sa.pairs_per_thread;
     const int ngrp = (sa.npair + ppt - 1) / ppt;
@@ -629,17 +680,17 @@ k_step_coeffs(StepArgs sa)
     struct PairIn { double2 a_c, a_1, a_2, S_c, S_1, S_2, I_1, I_2; };
     auto load_pair = [&](int q) {
         PairIn in;
-        const double2 *__restrict__ S = reinterpret_cast<const double2 *>(ta.S[d]) + (size_t)q * (size_t)n;
-        const double2 *__restrict__ I = reinterpret_cast<const double2 *>(ta.I) + ((size_t)a * sa.npair + q) * (size_t)n;
+        const T2 *__restrict__ S = reinterpret_cast<const T2 *>(ta.S[d]) + (size_t)q * (size_t)n;
+        const T2 *__restrict__ I = reinterpret_cast<const T2 *>(ta.I) + ((size_t)a * sa.npair + q) * (size_t)n;
         if (ta.alpha_mode == VRT_ALPHA_SITE) {                      // one opacity per site for every λ
-            const double *__restrict__ Al = ta.alpha[d];
+            const T *__restrict__ Al = reinterpret_cast<const T *>(ta.alpha[d]);
             const double c0 = Al[p], c1 = Al[v1], c2 = Al[v2];
             in.a_c = make_double2(c0, c0); in.a_1 = make_double2(c1, c1); in.a_2 = make_double2(c2, c2);
         } else {
-            const double2 *__restrict__ Al =
+            const T2 *__restrict__ Al =
                 ta.alpha_mode == VRT_ALPHA_SITE_LAM
-                    ? reinterpret_cast<const double2 *>(ta.alpha[d]) + (size_t)q * (size_t)n
-                    : reinterpret_cast<const double2 *>(ta.alpha_angle) + ((size_t)a * sa.npair + q) * (size_t)n;
+                    ? reinterpret_cast<const T2 *>(ta.alpha[d]) + (size_t)q * (size_t)n
+                    : reinterpret_cast<const T2 *>(ta.alpha_angle) + ((size_t)a * sa.npair + q) * (size_t)n;
             in.a_c = ld2(Al, p); in.a_1 = ld2(Al, v1); in.a_2 = ld2(Al, v2);
         }
         in.S_c = ld2(S, p); in.S_1 = ld2(S, v1); in.S_2 = ld2(S, v2);
@@ -662,7 +713,15 @@ k_step_coeffs(StepArgs sa)
         upwind_term(r1, w1, cur.a_c.y, cur.a_1.y, cur.S_c.y, cur.S_1.y, cur.I_1.y, early1, in1, t1, g1.y, cheap);
         upwind_term(r2, w2, cur.a_c.y, cur.a_2.y, cur.S_c.y, cur.S_2.y, cur.I_2.y, early2, in2, t2, g2.y, cheap);
         c.y = t1 + t2;
-        if (!((dbg & 4) && c.x != 1.2345e300)) {                    // (dbg & 4: no coefficient stores)
+        if (SPLIT) {                                                // one plane of T per wavelength
+            T *cc = reinterpret_cast<T *>(sa.cg_c), *gg = reinterpret_cast<T *>(sa.cg_g);
+            const size_t o0 = ((size_t)a * (2 * sa.npair) + 2 * q) * (size_t)sa.cg_stride, o1 = o0 + (size_t)sa.cg_stride;
+            cc[o0 + slot] = (T)c.x;
+            cc[o1 + slot] = (T)c.y;
+            T *g0 = gg + 2 * o0 + (gp & 0xFFFFu), *gy = gg + 2 * o1 + (gp & 0xFFFFu);
+            if (in1) { g0[0] = (T)g1.x; gy[0] = (T)g1.y; }
+            if (in2) { g0[in1 ? 1 : 0] = (T)g2.x; gy[in1 ? 1 : 0] = (T)g2.y; }
+        } else if (!((dbg & 4) && c.x != 1.2345e300)) {             // (dbg & 4: no coefficient stores)
             const size_t o = ((size_t)a * sa.npair + q) * (size_t)sa.cg_stride + (size_t)slot;
             sa.cg_c[o] = c;
             double2 *gl = sa.cg_g + 2 * (o - (size_t)slot) + (gp & 0xFFFFu);
@@ -769,26 +828,124 @@ k_step_levels(StepArgs sa)
     if (tid == 0 && sa.layer == ta.nlayers[d]) I[n - 1] = make_double2(0.0, 0.0);   // never-visited site perm[n]
 }
 
+// Single-wavelength level kernel for layers the pair kernel cannot hold (its tile is 16 B per site
+// and its register-resident coefficients 15 VGPRs per site, i.e. 8192 sites): one workgroup per
+// (angle, wavelength), tile of T (8 B or 4 B per site) kept in SORTED order so a thread's write
+// slot is its own index (no per-site register for it), coefficients c, g1, g2 held as T (6 or 3
+// VGPRs per site) + packed upwind slots + packed visit levels: up to 12 sites per thread in fp64
+// (12 288-site layers), 18 in fp32 (18 432).  The visit arithmetic is done in fp64.
+template <typename T, int K>
+__global__ void __launch_bounds__(1024)
+k_step_levels1(StepArgs sa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+    T *tile1 = reinterpret_cast<T *>(tile_raw);
+    const TileArgs &ta = sa.ta;
+    const int TT = 1024, tid = threadIdx.x;
+    const int a = sa.angle_list[blockIdx.x / ta.nlam], l = blockIdx.x % ta.nlam;
+    const int d = ta.angle_dir[a];
+    if (sa.layer > ta.nlayers[d]) return;
+    const int lo = ta.lay[d][sa.layer - 1], hi = ta.lay[d][sa.layer];
+    const int cnt = hi - lo;
+    const int64_t n = ta.n;
+    const size_t tab = (size_t)a * (size_t)n;
+    const uint32_t *__restrict__ tvis = ta.t_vis_s + tab;
+    const uint32_t *__restrict__ tloc = sa.t_loc_ss + tab;
+    const int32_t *__restrict__ tself = ta.t_self + tab;
+    const int32_t *__restrict__ trank = sa.t_rank_s + tab;
+    // element (l, pos) of the pair planes: ((l / 2) n + pos) 2 + l % 2
+    T *I = reinterpret_cast<T *>(ta.I) + (((size_t)a * sa.npair + (size_t)(l >> 1)) * (size_t)n << 1) + (size_t)(l & 1);
+    const size_t o = ((size_t)a * (2 * sa.npair) + l) * (size_t)sa.cg_stride;
+    const T *__restrict__ cc = reinterpret_cast<const T *>(sa.cg_c) + o;
+    const T *__restrict__ gg = reinterpret_cast<const T *>(sa.cg_g) + 2 * o;
+    T c[K], g1[K], g2[K];
+    uint32_t loc[K], vis[K];
+    {
+        uint32_t self[K];            // live during the permutation only
+        // coefficients arrive in storage order (coalesced) ...
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int i = tid + k * TT;
+            const bool ok = i < cnt;
+            const int ii = ok ? i : cnt - 1;
+            c[k] = cc[ii];
+            const uint32_t gp = ta.t_gpos[tab + lo + ii];
+            const T *gl = gg + (gp & 0xFFFFu);
+            const bool in1 = (gp >> 30) & 1u, in2 = gp >> 31;
+            g1[k] = in1 ? gl[0] : (T)0;
+            g2[k] = in2 ? gl[in1 ? 1 : 0] : (T)0;
+            self[k] = (uint32_t)(tself[lo + ii] - lo);
+            loc[k] = tloc[lo + ii];
+            vis[k] = ok ? tvis[lo + ii] : 0u;
+        }
+        // ... and are dealt to the threads in visit-pattern order through the still unused tile
+#pragma unroll
+        for (int arr = 0; arr < 3; arr++) {
+            T *v = arr == 0 ? c : arr == 1 ? g1 : g2;
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (tid + k * TT < cnt) tile1[tid + k * TT] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < K; k++) v[k] = tile1[self[k]];
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        if (tid + k * TT < cnt) tile1[tid + k * TT] = (T)0;      // I = zero(S), irregular_ray_tracing.jl:23
+    if (tid == 0) tile1[cnt] = (T)0;                             // the zero slot
+    __syncthreads();
+    const int nl = ta.nlev[(size_t)a * (size_t)(ta.max_layers + 1) + sa.layer];
+    for (int t = 1; t <= nl; t++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if ((vis[k] & 0xFFu) == (uint32_t)t) {       // a site's visits come at increasing levels
+                uint32_t lk = loc[k];
+                asm volatile("" : "+v"(lk));      // keep the two slots packed in ONE register (no hoisted addresses)
+                const uint32_t lx = lk & 0xFFFFu, ly = lk >> 16;           // kNoSlot -> the zero slot
+                const double x = (double)tile1[lx == kNoSlot ? (uint32_t)cnt : lx];
+                const double y = (double)tile1[ly == kNoSlot ? (uint32_t)cnt : ly];
+                T ck = c[k], g1k = g1[k], g2k = g2[k];
+                if (sizeof(T) == 4)      // keep the state in fp32 registers: without this the compiler hoists
+                    asm volatile("" : "+v"(ck), "+v"(g1k), "+v"(g2k));   // the conversions and holds doubles
+                tile1[tid + k * TT] = (T)((double)ck + (double)g1k * x + (double)g2k * y);
+                vis[k] >>= 8;
+            }
+        }
+        __syncthreads();
+    }
+    // the tile is in sorted order: storage slot i holds tile1[rank_s[i]] (LDS gather, coalesced store)
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int slot = tid + k * TT;
+        if (slot < cnt) I[(size_t)(lo + slot) << 1] = tile1[trank[lo + slot] - lo];
+    }
+    if (tid == 0 && sa.layer == ta.nlayers[d]) I[(size_t)(n - 1) << 1] = (T)0;   // never-visited site perm[n]
+}
+
 // J_d[l][p] = Σ_{angles of direction d} w_a I_a[l][p], reference's angle order within the direction
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_reduce_dir(int64_t total, int64_t stride_angle, DirWeights dw, const double *__restrict__ I,
-             double *__restrict__ Jd)
+k_reduce_dir(int64_t total, int64_t stride_angle, DirWeights dw, const T *__restrict__ I,
+             T *__restrict__ Jd)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     double acc = 0.0;
-    for (int j = 0; j < dw.count; j++) acc += dw.w[j] * I[(size_t)dw.idx[j] * stride_angle + t];
-    Jd[t] = acc;
+    for (int j = 0; j < dw.count; j++) acc += dw.w[j] * (double)I[(size_t)dw.idx[j] * stride_angle + t];
+    Jd[t] = (T)acc;
 }
 
 // J[site][l] = J_up[l][rank_up[site]] + J_down[l][rank_down[site]], walking sites in up order so
 // the J_up reads are coalesced and the J_down reads are piecewise contiguous on stratified grids.
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_combine_J(int64_t n, int nlam, int64_t ldJ, int lb, const int32_t *__restrict__ order_up,
-            const int32_t *__restrict__ rank_down, const double *__restrict__ Ju,
-            const double *__restrict__ Jdn, double *__restrict__ J)
+            const int32_t *__restrict__ rank_down, const T *__restrict__ Ju,
+            const T *__restrict__ Jdn, T *__restrict__ J)
 {
-    __shared__ double tile[64][65];
+    __shared__ T tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
     const int l0 = blockIdx.y * 64;
@@ -802,9 +959,9 @@ k_combine_J(int64_t n, int nlam, int64_t ldJ, int lb, const int32_t *__restrict_
         const int l = l0 + c;
         if (l < nlam && p < n) {
             double v = 0.0;
-            if (Ju) v = Ju[sw_index(l, p, n, lb)];
-            if (Jdn) v = v + Jdn[sw_index(l, pd, n, lb)];
-            tile[tx][c] = v;
+            if (Ju) v = (double)Ju[sw_index(l, p, n, lb)];
+            if (Jdn) v = v + (double)Jdn[sw_index(l, pd, n, lb)];
+            tile[tx][c] = (T)v;
         }
     }
     __syncthreads();
@@ -815,17 +972,18 @@ k_combine_J(int64_t n, int nlam, int64_t ldJ, int lb, const int32_t *__restrict_
 }
 
 // out[order[p]][l] = in[l][p]  (sweep order, wavelength-major -> caller's site-major rows)
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_from_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__restrict__ order,
-                   const double *__restrict__ in, double *__restrict__ out)
+                   const T *__restrict__ in, T *__restrict__ out)
 {
-    __shared__ double tile[64][65];
+    __shared__ T tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t p0 = (int64_t)blockIdx.x * 64;
     const int l0 = blockIdx.y * 64;
     for (int c = ty; c < 64; c += 4) {
         const int l = l0 + c;
-        if (l < nlam && p0 + tx < n) tile[tx][c] = in ? in[sw_index(l, p0 + tx, n, lb)] : 0.0;
+        if (l < nlam && p0 + tx < n) tile[tx][c] = in ? in[sw_index(l, p0 + tx, n, lb)] : (T)0;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
@@ -917,7 +1075,7 @@ int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha,
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
     for (int a = 0; a < p->A; a++) {
         const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-        hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2, dir.d_store,
+        hipLaunchKernelGGL(k_to_sweep_order<double>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2, dir.d_store,
                            dalpha + (size_t)p->user_of_active[(size_t)a] * (size_t)n * (size_t)ld,
                            out + (size_t)a * plane);
     }
@@ -963,24 +1121,65 @@ static int ensure_step_streams(vrt_plan *p, int G)
     return VRT_OK;
 }
 
-int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const double *dalpha,
-                  int alpha_mode, const double *dI0_up, const double *dI0_down,
-                  const double *weights_user, double *dJ, double *dI_out, hipStream_t st)
+// sites per thread the single-wavelength level kernel is instantiated for (even counts)
+constexpr int kSingleMaxK64 = 12, kSingleMaxK32 = 18;
+
+template <typename T, int K>
+static void launch_levels1(dim3 grid, size_t lds, hipStream_t sg, const StepArgs &sa)
 {
+    hipLaunchKernelGGL((k_step_levels1<T, K>), grid, dim3(1024), lds, sg, sa);
+}
+
+template <typename T>
+static void launch_levels1_K(int K, dim3 grid, size_t lds, hipStream_t sg, const StepArgs &sa)
+{
+    switch ((K + 1) / 2 * 2) {
+    case 2: launch_levels1<T, 2>(grid, lds, sg, sa); break;
+    case 4: launch_levels1<T, 4>(grid, lds, sg, sa); break;
+    case 6: launch_levels1<T, 6>(grid, lds, sg, sa); break;
+    case 8: launch_levels1<T, 8>(grid, lds, sg, sa); break;
+    case 10: launch_levels1<T, 10>(grid, lds, sg, sa); break;
+    case 12: launch_levels1<T, 12>(grid, lds, sg, sa); break;
+    default:
+        if (sizeof(T) == 4) {
+            switch ((K + 1) / 2 * 2) {
+            case 14: launch_levels1<float, 14>(grid, lds, sg, sa); break;
+            case 16: launch_levels1<float, 16>(grid, lds, sg, sa); break;
+            default: launch_levels1<float, 18>(grid, lds, sg, sa); break;
+            }
+        }
+        break;
+    }
+}
+
+// T = storage type of the caller's arrays and of every workspace plane
+template <typename T>
+static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, const T *dalpha,
+                           int alpha_mode, const T *dI0_up, const T *dI0_down,
+                           const double *weights_user, T *dJ, T *dI_out, hipStream_t st)
+{
+    constexpr bool kF32 = sizeof(T) == 4;
     vrt_grid *g = p->g;
     const int64_t n = g->n;
     const int A = p->A;
     const bool steps = p->last_path == 3;
+    // the pair level kernel (fp64 storage, layers <= 8192 sites) or the single-wavelength one
+    // (VRT_STEP_SINGLE=1 selects the single-wavelength kernel on any grid: same results, for the tests)
+    const bool single = steps && (kF32 || p->tile_max_layer_size > 8192 ||
+                                  (std::getenv("VRT_STEP_SINGLE") && std::atoi(std::getenv("VRT_STEP_SINGLE")) == 1));
     // storage layout: wavelength pairs side by side on the layer-step path, plain planes on the
     // persistent tile path (sw_index); planes are padded to a whole number of blocks
     const int lb = steps ? 2 : 1;
     const int64_t nl_pad = (nlam + lb - 1) / lb * lb;
     const size_t plane = (size_t)nl_pad * (size_t)n;
+    // workspaces are kept as double buffers; a plane of T needs this many doubles
+    auto dcount = [](size_t elems) { return (elems * sizeof(T) + 7) / 8; };
     int rc;
-    if ((rc = ensure_dev(p->d_I, p->I_cap, (size_t)std::max(1, A) * plane))) return rc;
+    if ((rc = ensure_dev(p->d_I, p->I_cap, dcount((size_t)std::max(1, A) * plane)))) return rc;
+    T *wI = reinterpret_cast<T *>(p->d_I);
     const bool use_dir[2] = {p->n_up > 0, p->n_down > 0};
     for (int d = 0; d < 2; d++)
-        if (use_dir[d] && (rc = ensure_dev(p->ws_S[d], p->ws_S_cap[d], plane))) return rc;
+        if (use_dir[d] && (rc = ensure_dev(p->ws_S[d], p->ws_S_cap[d], dcount(plane)))) return rc;
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
     TileArgs ta;
     ta.n = n;
@@ -989,7 +1188,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     ta.alpha_mode = alpha_mode;
     ta.max_layers = p->tile_max_layers;
     ta.tile_stride = (int)((std::max<int64_t>(p->tile_max_layer_size, 1) + 2) & ~(int64_t)1);   // + the zero slot
-    if ((rc = build_task_map(p, (int)nlam, st))) return rc;
+    if (!steps && (rc = build_task_map(p, (int)nlam, st))) return rc;
     ta.task_map = p->d_task_map;
     ta.angle_dir = p->d_angle_dir;
     ta.nlev = p->d_nlev;
@@ -1002,6 +1201,7 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     ta.t_gpos = p->t_gpos;
     ta.alpha_angle = nullptr;
     ta.I = p->d_I;
+    ta.dbg = nullptr;
     for (int d = 0; d < 2; d++) {
         const Direction &dir = d == 0 ? g->up : g->down;
         ta.lay[d] = dir.d_lay;
@@ -1009,39 +1209,40 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         ta.S[d] = nullptr;
         ta.alpha[d] = nullptr;
         if (!use_dir[d]) continue;
-        hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store, dS,
-                           p->ws_S[d]);
+        hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store, dS,
+                           reinterpret_cast<T *>(p->ws_S[d]));
         ta.S[d] = p->ws_S[d];
         if (alpha_mode == VRT_ALPHA_SITE) {
-            if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], (size_t)n))) return rc;
-            hipLaunchKernelGGL(k_gather_vec, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
-                               dir.d_store, dalpha, p->ws_A[d]);
+            if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], dcount((size_t)n)))) return rc;
+            hipLaunchKernelGGL(k_gather_vec<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
+                               dir.d_store, dalpha, reinterpret_cast<T *>(p->ws_A[d]));
             ta.alpha[d] = p->ws_A[d];
         } else if (alpha_mode == VRT_ALPHA_SITE_LAM) {
-            if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], plane))) return rc;
-            hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
-                               dalpha, p->ws_A[d]);
+            if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], dcount(plane)))) return rc;
+            hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
+                               dalpha, reinterpret_cast<T *>(p->ws_A[d]));
             ta.alpha[d] = p->ws_A[d];
         }
         const int cnt = d == 0 ? p->n_up : p->n_down;
         if (dir.n1 > 0) {
             const dim3 bgrid((unsigned)((dir.n1 + 63) / 64), (unsigned)((nlam + 63) / 64), (unsigned)cnt);
-            hipLaunchKernelGGL(k_boundary_sweep_order, bgrid, dim3(256), 0, st, n, (int)nlam, lb, dir.n1,
+            hipLaunchKernelGGL(k_boundary_sweep_order<T>, bgrid, dim3(256), 0, st, n, (int)nlam, lb, dir.n1,
                                d == 0 ? p->d_angles_up : p->d_angles_down, dir.d_order, dir.d_srank,
-                               d == 0 ? dI0_up : dI0_down, p->d_I);
+                               d == 0 ? dI0_up : dI0_down, wI);
         }
     }
     if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE) {
         // already in storage-pair order per active angle (vrt_plan_alpha_to_native_dev or the
         // opacity prologue wrote it): no transposed copy, the kernels read the caller's buffer
         ta.alpha_mode = VRT_ALPHA_ANGLE_SITE_LAM;
-        ta.alpha_angle = dalpha;
+        ta.alpha_angle = reinterpret_cast<const double *>(dalpha);
     } else if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM) {
-        if ((rc = ensure_dev(p->ws_AA, p->ws_AA_cap, (size_t)A * plane))) return rc;
+        if ((rc = ensure_dev(p->ws_AA, p->ws_AA_cap, dcount((size_t)A * plane)))) return rc;
         for (int a = 0; a < A; a++) {
             const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-            hipLaunchKernelGGL(k_to_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
-                               dalpha + (size_t)a * (size_t)n * (size_t)ld, p->ws_AA + (size_t)a * plane);
+            hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
+                               dalpha + (size_t)a * (size_t)n * (size_t)ld,
+                               reinterpret_cast<T *>(p->ws_AA) + (size_t)a * plane);
         }
         ta.alpha_angle = p->ws_AA;
     }
@@ -1049,13 +1250,15 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
 
     const bool debug = kDiag && std::getenv("VRT_TILE_DEBUG") != nullptr;
     long long *d_dbg = nullptr;
-    ta.dbg = nullptr;
     int64_t launches = 1;
     if (steps && A > 0) {
         // ---- layer-step variant: 2 launches per BFS layer -------------------------------------
         const int stride = (int)((std::max<int64_t>(p->tile_max_layer_size, 1) + 63) & ~(int64_t)63);
         const int npair = (int)(nl_pad / 2);
-        const size_t cgn = (size_t)A * (size_t)nl_pad * (size_t)stride;   // doubles: npair double2 planes
+        // hand-off buffers: pair kernel -> double2 per (angle, pair, slot); single-wavelength
+        // kernel -> one plane of T per (angle, wavelength)
+        const size_t cgn = single ? dcount((size_t)A * (size_t)nl_pad * (size_t)stride)
+                                  : (size_t)A * (size_t)nl_pad * (size_t)stride;
         if ((rc = ensure_dev(p->ws_cg[0], p->ws_cg_cap[0], cgn))) return rc;
         if ((rc = ensure_dev(p->ws_cg[1], p->ws_cg_cap[1], 2 * cgn))) return rc;
         StepArgs sa;
@@ -1064,6 +1267,8 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         sa.npair = npair;
         sa.cg_c = reinterpret_cast<double2 *>(p->ws_cg[0]);
         sa.cg_g = reinterpret_cast<double2 *>(p->ws_cg[1]);
+        sa.t_rank_s = p->t_rank_s;
+        sa.t_loc_ss = p->t_loc_ss;
         sa.pairs_per_thread = std::getenv("VRT_STEP_PAIRS") ? std::max(1, std::atoi(std::getenv("VRT_STEP_PAIRS"))) : kStepPairs;
         sa.chunks = (int)((p->tile_max_layer_size + 255) / 256);
         sa.xcd_map = std::getenv("VRT_STEP_XCD") ? std::atoi(std::getenv("VRT_STEP_XCD")) : 2;
@@ -1077,7 +1282,6 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
             warned = true;
         }
         const int Lmax = std::max(ta.nlayers[0] * (use_dir[0] ? 1 : 0), ta.nlayers[1] * (use_dir[1] ? 1 : 0));
-        const size_t lds_max = (size_t)(std::max<int64_t>(p->tile_max_layer_size, 1) + 1) * sizeof(double2);   // + the zero slot
         const int force_K = std::getenv("VRT_STEP_K") ? std::atoi(std::getenv("VRT_STEP_K")) : 0;
         // The angles are dealt (heaviest first) to a few internal streams that advance through
         // the layers independently: the (angle, wavelength) problems of different streams share
@@ -1108,10 +1312,10 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
             }
             sa.chunks = (int)((cnt_l + 255) / 256);
             const int per_xcd = (sa.chunks + 7) / 8;     // largest chunk range of an XCD
-            const size_t lds = std::min(lds_max, (size_t)(cnt_l + 1) * sizeof(double2));
-            // sites per thread of the level kernel: the fewest that cover the layer (14 VGPRs of
-            // register-resident coefficients per site); VRT_STEP_K forces more (tests)
-            const int step_K = std::max(1, std::min(8, std::max(force_K, (int)((cnt_l + 1023) / 1024))));
+            // sites per thread of the level kernel: the fewest that cover the layer (register-
+            // resident coefficients); VRT_STEP_K forces more (tests)
+            const int need_K = (int)((cnt_l + 1023) / 1024);
+            const int step_K = std::max(1, std::min(8, std::max(force_K, need_K)));
             for (int gi = 0; gi < G; gi++) {
                 hipStream_t sg = G == 1 ? st : p->step_stream[gi];
                 const int n_list = p->step_group_off[gi + 1] - p->step_group_off[gi];
@@ -1119,17 +1323,28 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
                 sa.angle_list = p->d_step_angles + p->step_group_off[gi];
                 sa.n_list = n_list;
                 const dim3 g1(sa.xcd_map ? (unsigned)(8 * per_xcd * n_list * ngrp) : (unsigned)(sa.chunks * n_list * ngrp));
-                const dim3 g2((unsigned)((size_t)n_list * (size_t)npair));
-                hipLaunchKernelGGL(k_step_coeffs, g1, dim3(256), 0, sg, sa);
-                switch (step_K) {
-                case 1: hipLaunchKernelGGL(k_step_levels<1>, g2, dim3(1024), lds, sg, sa); break;
-                case 2: hipLaunchKernelGGL(k_step_levels<2>, g2, dim3(1024), lds, sg, sa); break;
-                case 3: hipLaunchKernelGGL(k_step_levels<3>, g2, dim3(1024), lds, sg, sa); break;
-                case 4: hipLaunchKernelGGL(k_step_levels<4>, g2, dim3(1024), lds, sg, sa); break;
-                case 5: hipLaunchKernelGGL(k_step_levels<5>, g2, dim3(1024), lds, sg, sa); break;
-                case 6: hipLaunchKernelGGL(k_step_levels<6>, g2, dim3(1024), lds, sg, sa); break;
-                case 7: hipLaunchKernelGGL(k_step_levels<7>, g2, dim3(1024), lds, sg, sa); break;
-                default: hipLaunchKernelGGL(k_step_levels<8>, g2, dim3(1024), lds, sg, sa); break;
+                if (single) {
+                    hipLaunchKernelGGL((k_step_coeffs<T, true>), g1, dim3(256), 0, sg, sa);
+                    const int K1 = std::max(need_K, std::min(force_K, kF32 ? kSingleMaxK32 : kSingleMaxK64));
+                    launch_levels1_K<T>(std::max(K1, 1), dim3((unsigned)((size_t)n_list * (size_t)nlam)),
+                                        (size_t)(cnt_l + 1) * sizeof(T), sg, sa);
+                    launches += 2;
+                    continue;
+                }
+                if constexpr (!kF32) {
+                    const size_t lds = (size_t)(cnt_l + 1) * sizeof(double2);   // + the zero slot
+                    const dim3 g2((unsigned)((size_t)n_list * (size_t)npair));
+                    hipLaunchKernelGGL((k_step_coeffs<double, false>), g1, dim3(256), 0, sg, sa);
+                    switch (step_K) {
+                    case 1: hipLaunchKernelGGL(k_step_levels<1>, g2, dim3(1024), lds, sg, sa); break;
+                    case 2: hipLaunchKernelGGL(k_step_levels<2>, g2, dim3(1024), lds, sg, sa); break;
+                    case 3: hipLaunchKernelGGL(k_step_levels<3>, g2, dim3(1024), lds, sg, sa); break;
+                    case 4: hipLaunchKernelGGL(k_step_levels<4>, g2, dim3(1024), lds, sg, sa); break;
+                    case 5: hipLaunchKernelGGL(k_step_levels<5>, g2, dim3(1024), lds, sg, sa); break;
+                    case 6: hipLaunchKernelGGL(k_step_levels<6>, g2, dim3(1024), lds, sg, sa); break;
+                    case 7: hipLaunchKernelGGL(k_step_levels<7>, g2, dim3(1024), lds, sg, sa); break;
+                    default: hipLaunchKernelGGL(k_step_levels<8>, g2, dim3(1024), lds, sg, sa); break;
+                    }
                 }
                 launches += 2;
             }
@@ -1142,27 +1357,30 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         VRT_HIP_TRY(hipGetLastError());
         VRT_HIP_TRY(hipEventRecord(p->ev1, st));
     } else {
-    if (debug && hipMalloc((void **)&d_dbg, sizeof(long long) * 4 * (size_t)A * (size_t)nlam) == hipSuccess) ta.dbg = d_dbg;
-    VRT_HIP_TRY(hipEventRecord(p->ev0, st));
-    if (A > 0) {
-        const size_t lds = 2 * (size_t)ta.tile_stride * sizeof(double);
-        const dim3 grid((unsigned)((size_t)A * (size_t)nlam));
-        // layers of up to 3072 sites: 768 threads x 4 sites in ONE phase-1 batch (the 168 VGPRs of
-        // 3 waves per SIMD hold its 48 loads); larger layers: 1024 threads, batches of two
-        const bool wide = p->tile_max_layer_size <= 3072 && !(std::getenv("VRT_TILE_WIDE") && std::atoi(std::getenv("VRT_TILE_WIDE")) == 0);
-        if (wide && p->tile_max_layer_size <= 1536)
-            hipLaunchKernelGGL((k_sweep_tiles<2, 2, 768>), grid, dim3(768), lds, st, ta);
-        else if (wide)
-            hipLaunchKernelGGL((k_sweep_tiles<4, 4, 768>), grid, dim3(768), lds, st, ta);
-        else
-        switch (p->tile_K) {
-        case 2: hipLaunchKernelGGL((k_sweep_tiles<2, 2, 1024>), grid, dim3(1024), lds, st, ta); break;
-        case 4: hipLaunchKernelGGL((k_sweep_tiles<4, 2, 1024>), grid, dim3(1024), lds, st, ta); break;
-        default: hipLaunchKernelGGL((k_sweep_tiles<8, 2, 1024>), grid, dim3(1024), lds, st, ta); break;
-        }
-        VRT_HIP_TRY(hipGetLastError());
-    }
-    VRT_HIP_TRY(hipEventRecord(p->ev1, st));
+        if constexpr (!kF32) {
+            if (debug && hipMalloc((void **)&d_dbg, sizeof(long long) * 4 * (size_t)A * (size_t)nlam) == hipSuccess) ta.dbg = d_dbg;
+            VRT_HIP_TRY(hipEventRecord(p->ev0, st));
+            if (A > 0) {
+                const size_t lds = 2 * (size_t)ta.tile_stride * sizeof(double);
+                const dim3 grid((unsigned)((size_t)A * (size_t)nlam));
+                // layers of up to 3072 sites: 768 threads x 4 sites in ONE phase-1 batch (the 168 VGPRs of
+                // 3 waves per SIMD hold its 48 loads); larger layers: 1024 threads, batches of two
+                const bool wide = p->tile_max_layer_size <= 3072 && !(std::getenv("VRT_TILE_WIDE") && std::atoi(std::getenv("VRT_TILE_WIDE")) == 0);
+                if (wide && p->tile_max_layer_size <= 1536)
+                    hipLaunchKernelGGL((k_sweep_tiles<2, 2, 768>), grid, dim3(768), lds, st, ta);
+                else if (wide)
+                    hipLaunchKernelGGL((k_sweep_tiles<4, 4, 768>), grid, dim3(768), lds, st, ta);
+                else
+                    switch (p->tile_K) {
+                    case 2: hipLaunchKernelGGL((k_sweep_tiles<2, 2, 1024>), grid, dim3(1024), lds, st, ta); break;
+                    case 4: hipLaunchKernelGGL((k_sweep_tiles<4, 2, 1024>), grid, dim3(1024), lds, st, ta); break;
+                    default: hipLaunchKernelGGL((k_sweep_tiles<8, 2, 1024>), grid, dim3(1024), lds, st, ta); break;
+                    }
+                VRT_HIP_TRY(hipGetLastError());
+            }
+            VRT_HIP_TRY(hipEventRecord(p->ev1, st));
+        } else
+            return fail(VRT_EINVAL, "the persistent tile kernel stores fp64 only");
     }
     p->ev_valid = true;
     p->last_launches = launches;
@@ -1179,10 +1397,10 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
     }
 
     if (dJ) {
-        double *Jd[2] = {nullptr, nullptr};
+        T *Jd[2] = {nullptr, nullptr};
         for (int d = 0; d < 2; d++) {
             if (!use_dir[d]) continue;
-            if ((rc = ensure_dev(p->ws_J[d], p->ws_J_cap[d], plane))) return rc;
+            if ((rc = ensure_dev(p->ws_J[d], p->ws_J_cap[d], dcount(plane)))) return rc;
             DirWeights dw;
             dw.count = 0;
             for (int a = 0; a < A; a++)
@@ -1191,11 +1409,11 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
                     dw.idx[dw.count] = a;
                     dw.count++;
                 }
-            hipLaunchKernelGGL(k_reduce_dir, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st,
-                               (int64_t)plane, (int64_t)plane, dw, p->d_I, p->ws_J[d]);
-            Jd[d] = p->ws_J[d];
+            Jd[d] = reinterpret_cast<T *>(p->ws_J[d]);
+            hipLaunchKernelGGL(k_reduce_dir<T>, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st,
+                               (int64_t)plane, (int64_t)plane, dw, wI, Jd[d]);
         }
-        hipLaunchKernelGGL(k_combine_J, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, g->up.d_store,
+        hipLaunchKernelGGL(k_combine_J<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, g->up.d_store,
                            g->down.d_srank, Jd[0], Jd[1], dJ);
         VRT_HIP_TRY(hipGetLastError());
     }
@@ -1205,13 +1423,29 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS, const
         for (int64_t u = 0; u < p->n_angles_user; u++) {
             const int a = active_of_user[(size_t)u];
             const Direction &dir = (a >= 0 && p->dir_of_active[(size_t)a] < 0) ? g->down : g->up;
-            hipLaunchKernelGGL(k_from_sweep_order, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
-                               a >= 0 ? p->d_I + (size_t)a * plane : nullptr,
+            hipLaunchKernelGGL(k_from_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
+                               a >= 0 ? wI + (size_t)a * plane : (const T *)nullptr,
                                dI_out + (size_t)u * (size_t)n * (size_t)ld);
         }
         VRT_HIP_TRY(hipGetLastError());
     }
     return VRT_OK;
 }
+
+int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, const void *dalpha,
+                  int alpha_mode, const void *dI0_up, const void *dI0_down,
+                  const double *weights_user, void *dJ, void *dI_out, hipStream_t st, bool f32)
+{
+    if (f32)
+        return execute_tiles_t<float>(p, nlam, ld, (const float *)dS, (const float *)dalpha, alpha_mode,
+                                      (const float *)dI0_up, (const float *)dI0_down, weights_user, (float *)dJ,
+                                      (float *)dI_out, st);
+    return execute_tiles_t<double>(p, nlam, ld, (const double *)dS, (const double *)dalpha, alpha_mode,
+                                   (const double *)dI0_up, (const double *)dI0_down, weights_user, (double *)dJ,
+                                   (double *)dI_out, st);
+}
+
+// limits of the layer-step level kernels (sites per layer)
+int64_t steps_max_layer(bool f32) { return f32 ? (int64_t)kSingleMaxK32 * 1024 : (int64_t)kSingleMaxK64 * 1024; }
 
 }  // namespace vrt
