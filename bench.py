@@ -371,7 +371,8 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     if rank == 0 and world == 1 and cpu_baseline:      # reported at N = 1 only
         from oracle import oracle as orc
         cores = len(os.sched_getaffinity(0))
-        lam_s = args.cpu_lam if args.cpu_lam > 0 else min(nlam, cores)
+        # bounded sample (about 10-30 s of CPU work): <= 3e8 cell-updates for the threaded run
+        lam_s = args.cpu_lam if args.cpu_lam > 0 else max(1, min(nlam, cores, int(3.0e8 // (n * A))))
         t0 = time.time()
         so = orc.make_sites(pos, nbr, bounds)
         t_osites = time.time() - t0
@@ -386,11 +387,16 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
                               nthreads=cores)
         t_cpu = time.time() - t0
         cpu_updates = n * A * lam_s
-        # T = 1: one wavelength, all angles, one thread (T = 1 and T = all cores)
-        al1 = np.ascontiguousarray(al_h[:, :, :1] if per_angle else al_h[:, :1])
+        # T = 1: one wavelength, one thread (T = 1 and T = all cores); all angles, or
+        # one up + one down ray when that alone would take more than ~30 s
+        sel = np.arange(A)
+        if n * A > 3.0e7:
+            th_m = theta[my_angles]
+            sel = np.array([int(np.argmax(th_m > 90)), int(np.argmax(th_m < 90))])
+        al1 = np.ascontiguousarray(al_h[sel][:, :, :1] if per_angle else al_h[:, :1])
         t0 = time.time()
-        orc.J_voronoi(w_mine, theta[my_angles], phi[my_angles], np.ascontiguousarray(S_h[:, :1]), al1, so,
-                      I0_up=np.ascontiguousarray(I0_h[:, :1]), nthreads=1)
+        orc.J_voronoi(w_mine[sel], theta[my_angles][sel], phi[my_angles][sel], np.ascontiguousarray(S_h[:, :1]), al1,
+                      so, I0_up=np.ascontiguousarray(I0_h[:, :1]), nthreads=1)
         t_cpu1 = time.time() - t0
         J_gpu = J[:, :lam_s].cpu().numpy().astype(np.float64)
         parity = float(np.abs(J_gpu - J_ref).max() / np.abs(J_ref).max())
@@ -401,8 +407,8 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
                       f"restatement threaded over wavelengths like Threads.@threads; its grid "
                       f"prep (read_cell equivalent) took {t_osites:.1f} s and is not counted",
             "seconds": t_cpu,
-            "single_thread": {"value": n * A / t_cpu1, "unit": "cell-updates/s", "cores": 1, "seconds": t_cpu1,
-                              "sample": f"all {A} angles x 1 wavelength ({n * A} cell-updates)"},
+            "single_thread": {"value": n * len(sel) / t_cpu1, "unit": "cell-updates/s", "cores": 1, "seconds": t_cpu1,
+                              "sample": f"{len(sel)} of {A} angles x 1 wavelength ({n * len(sel)} cell-updates)"},
             "cpu_model": cpu_model(), "host_cores": cores,
         }
         out["parity_vs_oracle_max_rel_err"] = parity
