@@ -331,7 +331,8 @@ def test_execute_dev_with_torch_tensors_and_padding(grids, path):
                          dJ=Jd.data_ptr(), dI0_up=I0d.data_ptr(), stream=st.cuda_stream)
     st.synchronize()
     ms, launches = plan.last_sweep_timing()
-    assert ms > 0 and launches == (plan.num_levels if path == "levels" else (1 if path == "tiles" else launches))
+    # tiles: one persistent launch, preceded by the chip-wide coefficient launch when layers are <= 4096 sites
+    assert ms > 0 and (launches == plan.num_levels if path == "levels" else (launches in (1, 2) if path == "tiles" else launches > 0))
     J = Jd.cpu().numpy()
     ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=4)
     assert _rel(J[:, :nlam], ref) < RTOL

@@ -177,6 +177,7 @@ static void free_plan(vrt_plan *p)
     dev_free(p->t_gpos);
     dev_free(p->t_rank_s);
     dev_free(p->t_loc_ss);
+    dev_free(p->t_code_ss);
     dev_free(p->d_nlev); dev_free(p->d_angle_dir); dev_free(p->d_task_map);
     for (int d = 0; d < 2; d++) { dev_free(p->ws_S[d]); dev_free(p->ws_A[d]); dev_free(p->ws_J[d]); }
     dev_free(p->ws_AA);
@@ -434,6 +435,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             VRT_TRY_FREE(dev_alloc(&p->t_gpos, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_rank_s, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_loc_ss, tab));
+            if (max_layer <= 4096) VRT_TRY_FREE(dev_alloc(&p->t_code_ss, tab));
             uint32_t *d_vis_site = nullptr;
             VRT_TRY_FREE(dev_alloc(&d_vis_site, (size_t)n));
             const int maxL = (int)std::max(g->up.reduced.size(), g->down.reduced.size()) - 1;

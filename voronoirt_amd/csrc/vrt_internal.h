@@ -144,6 +144,7 @@ struct vrt_plan {
     uint32_t *t_gpos = nullptr;          // [A][n] compact in-layer coupling list (k_gpos)
     int32_t *t_rank_s = nullptr;         // [A][n] storage position -> sorted index (inverse of t_self)
     uint32_t *t_loc_ss = nullptr;        // [A][n] upwind tile slots of the sorted entries, in SORTED terms
+    uint32_t *t_code_ss = nullptr;       // [A][n] two-launch tile path: upwind slot + kind codes (layers <= 4096 sites)
     int32_t *d_nlev = nullptr, *d_angle_dir = nullptr;
     std::vector<int64_t> angle_visits;   // surviving visits per active angle (task cost)
     std::vector<int32_t> h_task_map;     // block -> angle | wavelength << 8

@@ -129,6 +129,33 @@ k_sorted_loc(int64_t n, const int32_t *__restrict__ lay, int nlayers, const uint
     loc_ss[i] = s1 | (s2 << 16);
 }
 
+// upwind slot + kind codes of the two-launch tile path (k_sweep_tiles_pre; layout described there)
+__global__ void __launch_bounds__(256)
+k_sorted_code(int64_t n, const int32_t *__restrict__ lay, int nlayers, const int32_t *__restrict__ self,
+              const int32_t *__restrict__ rank_s, const int32_t *__restrict__ t_u1,
+              const int32_t *__restrict__ t_u2, uint32_t *__restrict__ code_ss)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int lo_i = 0, hi_i = nlayers;                  // layer of sorted index i (sorting stays inside layers)
+    while (hi_i - lo_i > 1) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (lay[mid] <= i) lo_i = mid; else hi_i = mid;
+    }
+    const int lo = lay[lo_i], hi = lay[lo_i + 1];
+    const int lop = lo_i > 0 ? lay[lo_i - 1] : 0;
+    const int p = self[i];
+    uint32_t code = 0;
+    for (int r = 0; r < 2; r++) {
+        const int u = r == 0 ? t_u1[p] : t_u2[p];
+        uint32_t c = 0;
+        if (u >= lo && u < hi) c = (uint32_t)(rank_s[u] - lo) | (1u << 12);
+        else if (lo_i > 0 && u >= lop && u < lo) c = (uint32_t)(rank_s[u] - lop) | (2u << 12);
+        code |= c << (14 * r);
+    }
+    code_ss[i] = code;
+}
+
 int launch_sorted_tables(vrt_plan *p, int a)
 {
     vrt_grid *g = p->g;
@@ -140,6 +167,9 @@ int launch_sorted_tables(vrt_plan *p, int a)
                        p->t_loc + o, p->t_vis_s + o, p->t_loc_s + o, p->t_rank_s + o);
     hipLaunchKernelGGL(k_sorted_loc, grid, dim3(256), 0, g->stream, n, dir.d_lay, (int)dir.reduced.size() - 1,
                        p->t_loc_s + o, p->t_rank_s + o, p->t_loc_ss + o);
+    if (p->t_code_ss)
+        hipLaunchKernelGGL(k_sorted_code, grid, dim3(256), 0, g->stream, n, dir.d_lay, (int)dir.reduced.size() - 1,
+                           p->t_self + o, p->t_rank_s + o, p->t_u1 + o, p->t_u2 + o, p->t_code_ss + o);
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
@@ -552,6 +582,169 @@ k_sweep_tiles(TileArgs ta)
     if (timing && tid == 0) {
         ta.dbg[4 * task + 0] = cyc1; ta.dbg[4 * task + 1] = cyc2; ta.dbg[4 * task + 2] = cyc3;
         ta.dbg[4 * task + 3] = a;
+    }
+    if (tid == 0) I[n - 1] = 0.0;   // the never-visited site perm[n] keeps I = 0 (voronoi_utils.jl:266)
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-launch form of the persistent tile path.  Measured on BASELINE config C2 (12 tasks on 12
+// CUs): the coefficient phase of k_sweep_tiles is ALU-bound on its one CU (53 % of the critical
+// task; staging S, α of two layers in LDS so that every gather is an LDS read changed nothing:
+// 1.345 vs 1.338 ms).  But only ONE term of a site's coefficients depends on the sweep's results:
+//     I_c = c0 + H1 I_u1 + H2 I_u2,   c0 = Σ_r (a_r S_ur + b_r S_c) w_r,   H_r = e_r w_r
+// (irregular_ray_tracing.jl:73-76 re-associated; the reference adds e_r I_ur inside the bracket).
+// So a first chip-wide launch (k_tile_coeffs, no dependencies at all: every site x task in
+// parallel) computes c0, H1, H2 with all the exponentials, and the persistent workgroup of a task
+// (k_sweep_tiles_pre) only streams three doubles + two schedule words per site, adds the couplings
+// to the PREVIOUS layer from its LDS copy of that layer's final intensities, and runs the levels.
+// Everything is laid out in the SORTED order of the level loop (visit patterns wave-uniform), so
+// the workgroup's loads are perfectly coalesced and prefetched one layer ahead.
+//   t_code_ss[a][i] (plan time): the two upwinds of sorted entry i, 14 bits each:
+//     bits 0-11 slot in sorted terms, bits 12-13 kind (1 = own layer -> tile, 2 = previous layer,
+//     0 = neither: later layer / never-visited site, the intensity reads 0)
+// ---------------------------------------------------------------------------------------------
+constexpr int kPreMaxLayer = 4096;       // 12-bit slots
+
+// launch 1: c0, H1, H2 of every (task, sorted entry); planes [3][ntask][n]
+__global__ void __launch_bounds__(256)
+k_tile_coeffs(TileArgs ta, double *__restrict__ rec)
+{
+    const int64_t n = ta.n;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int task = blockIdx.y;
+    const int a = ta.task_map[task] & 0xFF;
+    const int l = ta.task_map[task] >> 8;
+    const int d = ta.angle_dir[a];
+    const size_t tab = (size_t)a * (size_t)n;
+    const int p = ta.t_self[tab + i];
+    const int u1 = ta.t_u1[tab + p], u2 = ta.t_u2[tab + p];
+    const size_t ntask = gridDim.y;
+    double *c0 = rec + (size_t)task * (size_t)n, *H1 = c0 + ntask * (size_t)n, *H2 = H1 + ntask * (size_t)n;
+    if (i < ta.lay[d][1] || u1 < 0 || u2 < 0) {          // boundary layer (no visits) / no upwind
+        c0[i] = 0.0; H1[i] = 0.0; H2[i] = 0.0;
+        return;
+    }
+    const double *__restrict__ S = ta.S[d] + (size_t)l * (size_t)n;
+    const double *__restrict__ Al =
+        ta.alpha_mode == VRT_ALPHA_SITE ? ta.alpha[d]
+        : ta.alpha_mode == VRT_ALPHA_SITE_LAM ? ta.alpha[d] + (size_t)l * (size_t)n
+                                              : ta.alpha_angle + ((size_t)a * ta.nlam + l) * (size_t)n;
+    const double S_c = S[p], a_c = Al[p];
+    double ca, cb, ce;
+    lin_weights(ta.t_r1[tab + p] * (a_c + Al[u1]) / 2.0, ca, cb, ce);       // trapezoidal, functions.jl:393
+    const double w1 = ta.t_w1[tab + p];
+    const double t1 = (ca * S[u1] + cb * S_c) * w1;
+    H1[i] = ce * w1;
+    lin_weights(ta.t_r2[tab + p] * (a_c + Al[u2]) / 2.0, ca, cb, ce);
+    const double w2 = ta.t_w2[tab + p];
+    const double t2 = (ca * S[u2] + cb * S_c) * w2;
+    H2[i] = ce * w2;
+    c0[i] = t1 + t2;
+}
+
+// launch 2: one persistent workgroup per task; LDS = tile of the current layer, final intensities
+// of the previous layer, constant terms (3 x tile_stride doubles), all in sorted order
+template <int K, int T>
+__global__ void __launch_bounds__(T)
+k_sweep_tiles_pre(TileArgs ta, const double *__restrict__ rec, const uint32_t *__restrict__ code_ss,
+                  const int32_t *__restrict__ rank_s)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int stride = ta.tile_stride;
+    double *cst = lds + 2 * (size_t)stride;
+    const int tid = threadIdx.x;
+    const int task = blockIdx.x;
+    const int a = ta.task_map[task] & 0xFF;
+    const int l = ta.task_map[task] >> 8;
+    const int d = ta.angle_dir[a];
+    const int64_t n = ta.n;
+    const size_t tab = (size_t)a * (size_t)n;
+    const size_t ntask = gridDim.x;
+    const double *__restrict__ c0 = rec + (size_t)task * (size_t)n;
+    const double *__restrict__ H1 = c0 + ntask * (size_t)n;
+    const double *__restrict__ H2 = H1 + ntask * (size_t)n;
+    const uint32_t *__restrict__ code = code_ss + tab;
+    const uint32_t *__restrict__ tvis = ta.t_vis_s + tab;
+    const int32_t *__restrict__ tself = ta.t_self + tab;
+    const int32_t *__restrict__ trank = rank_s + tab;
+    double *I = ta.I + ((size_t)a * ta.nlam + l) * (size_t)n;
+    const int32_t *__restrict__ lay = ta.lay[d];
+    const int32_t *__restrict__ nlev = ta.nlev + (size_t)a * (size_t)(ta.max_layers + 1);
+    const int L = ta.nlayers[d];
+
+    struct Entry { double c0, h1, h2; uint32_t code, vis; };
+    auto load_entries = [&](int layer, Entry (&e)[K]) {
+        const int lo = lay[layer - 1], cnt = lay[layer] - lo;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int slot = tid + k * T;
+            const int i = lo + min(slot, max(cnt - 1, 0));
+            e[k].c0 = c0[i]; e[k].h1 = H1[i]; e[k].h2 = H2[i];
+            e[k].code = code[i];
+            e[k].vis = slot < cnt ? tvis[i] : 0u;
+        }
+    };
+    int par = 0;      // lds[par * stride ..]: tile of the current layer, the other one: the previous layer
+    {
+        // layer 1 (boundary: I = I_0, written by k_boundary_sweep_order) is the first "previous" layer
+        const int lo1 = lay[0], cnt1 = lay[1] - lo1;
+        double *Ip = lds + (size_t)(par ^ 1) * stride;
+        for (int s = tid; s < cnt1; s += T) Ip[s] = I[tself[lo1 + s]];
+    }
+    Entry cur[K];
+    if (L >= 2) load_entries(2, cur);
+    __syncthreads();
+    for (int layer = 2; layer <= L; layer++) {          // irregular_ray_tracing.jl:37
+        const int lo = lay[layer - 1], hi = lay[layer];  // hi of the last layer = n-1: perm[n] is never visited
+        const int cnt = hi - lo;
+        double *Ic = lds + (size_t)par * stride;
+        const double *Ip = lds + (size_t)(par ^ 1) * stride;
+        Entry nxt[K];
+        if (layer < L) load_entries(layer + 1, nxt);     // lands during the level loop
+        double g1[K], g2[K];
+        uint32_t loc[K], vis[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t c1 = cur[k].code & 0x3FFFu, c2 = cur[k].code >> 14;
+            const uint32_t k1 = c1 >> 12, k2 = c2 >> 12, s1 = c1 & 0xFFFu, s2 = c2 & 0xFFFu;
+            double c = cur[k].c0;
+            if (k1 == 2u) c += cur[k].h1 * Ip[s1];                   // previous layer: final
+            if (k2 == 2u) c += cur[k].h2 * Ip[s2];
+            g1[k] = k1 == 1u ? cur[k].h1 : 0.0;                      // own layer: coupling on the tile
+            g2[k] = k2 == 1u ? cur[k].h2 : 0.0;
+            loc[k] = (k1 == 1u ? s1 : (uint32_t)cnt) | ((k2 == 1u ? s2 : (uint32_t)cnt) << 16);   // else the zero slot
+            vis[k] = cur[k].vis;
+            const int slot = tid + k * T;
+            if (slot < cnt) {
+                cst[slot] = c;
+                Ic[slot] = 0.0;                                      // I = zero(S), :23
+            }
+        }
+        if (tid == 0) Ic[cnt] = 0.0;                                 // the zero slot
+        __syncthreads();
+        const int nl = nlev[layer];
+        for (int t = 1; t <= nl; t++) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if ((vis[k] & 0xFFu) == (uint32_t)t) {               // a site's visits come at increasing levels
+                    Ic[tid + k * T] = cst[tid + k * T] + g1[k] * Ic[loc[k] & 0xFFFFu] + g2[k] * Ic[loc[k] >> 16];
+                    vis[k] >>= 8;
+                }
+            }
+            __syncthreads();
+        }
+        // the layer is final: to global in storage order (J reduction / I_out); it stays in LDS, in
+        // sorted order, as the next layer's "previous"
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int slot = tid + k * T;
+            if (slot < cnt) I[lo + slot] = Ic[trank[lo + slot] - lo];
+        }
+        par ^= 1;
+#pragma unroll
+        for (int k = 0; k < K; k++) cur[k] = nxt[k];
+        __syncthreads();       // the next layer zeroes what was "previous" until now
     }
     if (tid == 0) I[n - 1] = 0.0;   // the never-visited site perm[n] keeps I = 0 (voronoi_utils.jl:266)
 }
@@ -1366,7 +1559,25 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                 // layers of up to 3072 sites: 768 threads x 4 sites in ONE phase-1 batch (the 168 VGPRs of
                 // 3 waves per SIMD hold its 48 loads); larger layers: 1024 threads, batches of two
                 const bool wide = p->tile_max_layer_size <= 3072 && !(std::getenv("VRT_TILE_WIDE") && std::atoi(std::getenv("VRT_TILE_WIDE")) == 0);
-                if (wide && p->tile_max_layer_size <= 1536)
+                // layers of at most 4096 sites: the two-launch form (chip-wide I-independent
+                // coefficients, then persistent level workgroups; VRT_TILE_PRE=0: the one-launch kernel)
+                const bool pre = p->tile_max_layer_size <= kPreMaxLayer && p->t_code_ss &&
+                                 !(std::getenv("VRT_TILE_PRE") && std::atoi(std::getenv("VRT_TILE_PRE")) == 0);
+                if (pre) {
+                    const size_t ntask = (size_t)A * (size_t)nlam;
+                    if ((rc = ensure_dev(p->ws_cg[0], p->ws_cg_cap[0], 3 * ntask * (size_t)n))) return rc;
+                    hipLaunchKernelGGL(k_tile_coeffs, dim3((unsigned)((n + 255) / 256), (unsigned)ntask), dim3(256), 0, st,
+                                       ta, p->ws_cg[0]);
+                    const size_t lds_pre = 3 * (size_t)ta.tile_stride * sizeof(double);
+                    if (p->tile_max_layer_size <= 1536)
+                        hipLaunchKernelGGL((k_sweep_tiles_pre<2, 768>), grid, dim3(768), lds_pre, st, ta, p->ws_cg[0], p->t_code_ss, p->t_rank_s);
+                    else if (p->tile_max_layer_size <= 3072)
+                        hipLaunchKernelGGL((k_sweep_tiles_pre<4, 768>), grid, dim3(768), lds_pre, st, ta, p->ws_cg[0], p->t_code_ss, p->t_rank_s);
+                    else
+                        hipLaunchKernelGGL((k_sweep_tiles_pre<4, 1024>), grid, dim3(1024), lds_pre, st, ta, p->ws_cg[0], p->t_code_ss, p->t_rank_s);
+                    launches = 2;
+                }
+                else if (wide && p->tile_max_layer_size <= 1536)
                     hipLaunchKernelGGL((k_sweep_tiles<2, 2, 768>), grid, dim3(768), lds, st, ta);
                 else if (wide)
                     hipLaunchKernelGGL((k_sweep_tiles<4, 4, 768>), grid, dim3(768), lds, st, ta);
