@@ -914,3 +914,58 @@ def test_diagnostic_environment_variables_cannot_change_results(grids, monkeypat
     assert np.array_equal(J0, J1)
     assert _rel(J0, orc.J_voronoi(w, th, ph, S, al, so, nthreads=4)) < RTOL
     plan.close()
+
+
+def test_theta_90_is_skipped_when_the_direction_is_inferred_from_k(grids):
+    """vrt_plan_create (dirs == NULL) infers the sweep direction from k_z; the library's own
+    vrt_direction(90, ϕ) gives k_z = cos(π/2) = 6.1e-17, not 0, and must still count as θ = 90
+    (skipped, lambda_iteration.jl:98,104) instead of being solved as a horizontal 'down' ray."""
+    hs, so = grids["bcc"]
+    n = so.n
+    rng = np.random.default_rng(3)
+    S = 1 + rng.random((n, 2))
+    al = 1e-6 * (1 + rng.random((n, 2)))
+    ks = np.stack([vrt.direction(150.0, 20.0), vrt.direction(90.0, 33.0), vrt.direction(40.0, 200.0)])
+    assert 0 < ks[1, 0] < 1e-15
+    w = np.array([0.3, 0.4, 0.3])
+    plan = vrt.FormalPlan(hs, ks, 3)                       # no dirs: inferred
+    J, I = plan.execute(S, al, weights=w, want_I=True)
+    assert (I[1] == 0).all()                               # the horizontal direction was skipped
+    ref = orc.J_voronoi(w, np.array([150.0, 90.0, 40.0]), np.array([20.0, 33.0, 200.0]), S, al, so, nthreads=2)
+    assert _rel(J, ref) < RTOL
+    plan.close()
+
+
+def test_non_finite_input_stays_where_the_reference_keeps_it(grids, path):
+    """One site with S = Inf: the reference propagates Inf/NaN only to sites that actually read it
+    (0 * Inf never arises for an upwind outside the site's own layer, whose intensity reads 0).  All
+    three device paths must agree with the oracle on WHICH sites are finite."""
+    hs, so = grids["voronoi"]
+    n = so.n
+    rng = np.random.default_rng(17)
+    S = 1 + rng.random(n)
+    al = 5 * 10 ** rng.uniform(-3, 1, n)
+    bad = int(so.perm_up[so.layers_up[3]] - 1)             # a site in the 4th layer
+    S[bad] = np.inf
+    k = vrt.direction(140.0, 70.0)
+    I0 = rng.random(so.layers_up[1] - 1)
+    with np.errstate(all="ignore"):
+        ref = orc.Delaunay_upII(k, S, I0, al, so, 3)
+    got = vrt.Delaunay_upII(k, S, I0, al, hs, 3)
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+    m = np.isfinite(ref)
+    assert m.sum() > 0.5 * n and (~m).sum() >= 1
+    assert np.abs(got[m] - ref[m]).max() / np.abs(ref[m]).max() < RTOL
+
+
+def test_closing_the_grid_closes_its_plans(bcc_small):
+    """VoronoiSites.close() first closes every FormalPlan built on it (a plan holds a pointer to the
+    grid); closing such a plan afterwards, or letting it be collected, is a no-op."""
+    pos, nbr, bounds = bcc_small
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    plan = vrt.FormalPlan(hs, [vrt.direction(160.0, 10.0)], 3)
+    hs.close()
+    assert plan._h is None
+    plan.close()
+    with pytest.raises(Exception):
+        plan.execute(np.ones((hs.n, 1)), np.ones(hs.n))
