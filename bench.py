@@ -417,6 +417,44 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     return out
 
 
+def measure_c1(torch, vrt):
+    """BASELINE configs[0]: compare_searchlight.jl's regular-grid searchlight, 60^3, n1.dat (one
+    vertical up ray), through the regular-grid HIP solver; CPU oracle beside it."""
+    from oracle import oracle as orc
+    w, th, ph, _ = vrt.read_quadrature("n1.dat")
+    n = 60
+    z = x = y = np.linspace(0, 1, n)
+    S = np.zeros((n, n, n))
+    al = np.zeros((n, n, n))
+    I0 = np.zeros((n, n))
+    ii, jj = np.meshgrid(np.arange(1, n + 1), np.arange(1, n + 1), indexing="ij")
+    I0[(np.sqrt((ii / n - 0.5) ** 2 + (jj / n - 0.5) ** 2) < 0.1).T] = 1.0     # compare_searchlight.jl:180-190
+    dev = torch.device("cuda", torch.cuda.current_device())
+    solver = vrt.RegularSolver(z, x, y, device=dev.index)
+    Sd, Ad, I0d = (torch.from_numpy(a).to(dev) for a in (S, al, I0[None]))
+    out = torch.empty((1, n, n, n), device=dev, dtype=torch.float64)
+    k = vrt.direction(th[0], ph[0])[None]
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        solver.execute_dev(k, [True], Sd.data_ptr(), 0, Ad.data_ptr(), 0, I0d.data_ptr(), out.data_ptr(), 3, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        solver.execute_dev(k, [True], Sd.data_ptr(), 0, Ad.data_ptr(), 0, I0d.data_ptr(), out.data_ptr(), 3, st)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    t0 = time.time()
+    ref = orc.short_characteristics_up(orc.direction(th[0], ph[0]), S, I0, al, z, x, y, 3)
+    t_cpu = time.time() - t0
+    got = out[0].cpu().numpy()
+    solver.close()
+    return {"config": {"workload": "C1: regular 60^3 searchlight, n1.dat (theta 180, phi 0), alpha = S = 0, n_sweeps=3"},
+            "ms_per_step": ms, "value": n ** 3 / (ms * 1e-3), "unit": "cell-updates/s",
+            "cpu_baseline": {"value": n ** 3 / t_cpu, "unit": "cell-updates/s", "cores": 1, "kind": "port"},
+            "parity_vs_oracle_max_abs_err": float(np.abs(got - ref).max()),
+            "top_plane_equals_I0": bool(np.array_equal(got[1:-1, 1:-1, -1], I0[1:-1, 1:-1]))}
+
+
 def launch_own_ranks(args) -> int:
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves, before
     this process has touched a GPU, and exit with the job's code (rank 0 prints the JSON line)."""
@@ -463,6 +501,8 @@ def main():
         out["other_configs"] = {"C2": {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup",
                                                             "config", "roofline", "cpu_baseline",
                                                             "parity_vs_oracle_max_rel_err") if k in sec}}
+        if not args.no_cpu_baseline:
+            out["other_configs"]["C1"] = measure_c1(torch, vrt)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
