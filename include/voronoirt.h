@@ -73,6 +73,21 @@ int vrt_grid_create_from_file(const char *neighbours_file, int64_t n, const doub
                               const double bounds[6], int device, vrt_grid **out);
 void vrt_grid_destroy(vrt_grid *g);
 
+/* ---- in-process tessellation: replaces the fork/exec of the voro++ wrapper
+ * rt_preprocessing/output_sites.cc:35-49 (`voro`, src/functions.jl:13-23), the text round trip
+ * (src/io.jl:8-40) and its parse (src/voronoi_utils.jl:42-63).  Voronoi cells of the sites in the
+ * box, periodic in x and y, walls at z_min (-5) and z_max (-6); host code, multi-threaded, no GPU.
+ *   nbr (n, D1) column-major out: exactly the matrix read_cell builds (column 0 = count, then the
+ *   neighbour ids, 1-based); D1 = max_guess + 1 = 71 mirrors voronoi_utils.jl:42; *max_count
+ *   receives maximum(nbr[:,1]).
+ * The neighbour SET of every cell is the tessellation's; their ORDER inside a row (walls first,
+ * then by increasing distance) is not voro++'s, which cannot be known without voro++ -- and the
+ * reference's upwind rule depends on it (voronoi_utils.jl:378-386). */
+int vrt_tessellate(int64_t n, const double *pos_zxy, const double bounds[6], int64_t D1, int64_t *nbr,
+                   int64_t *max_count);
+/* writes such a matrix as the voro++ "%i %n" text file read_cell parses (one line per cell) */
+int vrt_write_neighbours_file(const char *path, int64_t n, const int64_t *nbr, int64_t D1);
+
 /* introspection (parity tests; all values exactly as the reference's Julia fields, 1-based) */
 int64_t vrt_grid_n(const vrt_grid *g);
 int64_t vrt_grid_max_neighbours(const vrt_grid *g);             /* D = size(neighbours,2)-1   */

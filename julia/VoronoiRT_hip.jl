@@ -182,6 +182,34 @@ function solve(up::Bool, k, S, I_0, α, sites::VoronoiSites, n_sweeps::Int)
     return I * I_unit
 end
 
+# ---- voro (src/functions.jl:13-23): the voro++ fork/exec, in-process --------------------------------
+# Reads the sites file the driver has just written (write_arrays, src/io.jl:16-20: "id\tx\ty\tz"),
+# tessellates with vrt_tessellate and writes the "%i %n" neighbours file read_cell parses, so the
+# driver's own `voro(...); read_cell(...)` sequence (compare_line.jl:100-103) runs unchanged.
+function voro_inprocess(sites_file::String, neighbours_file::String,
+                        x_min::Float64, x_max::Float64, y_min::Float64, y_max::Float64,
+                        z_min::Float64, z_max::Float64)
+    rows = [split(l) for l in eachline(sites_file) if !isempty(strip(l))]
+    n = length(rows)
+    pos = Matrix{Float64}(undef, 3, n)                      # (3, n) rows z, x, y
+    for r in rows
+        i = parse(Int, r[1])
+        pos[2, i] = parse(Float64, r[2]); pos[3, i] = parse(Float64, r[3]); pos[1, i] = parse(Float64, r[4])
+    end
+    bounds = Float64[z_min, z_max, x_min, x_max, y_min, y_max]
+    D1 = 71                                                  # max_guess + 1, voronoi_utils.jl:42
+    nbr = zeros(Int64, n, D1)
+    mx = Ref{Int64}(0)
+    GC.@preserve pos bounds nbr begin
+        check(ccall((:vrt_tessellate, libvrt), Cint,
+                    (Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int64}, Ref{Int64}),
+                    n, pos, bounds, D1, nbr, mx))
+        check(ccall((:vrt_write_neighbours_file, libvrt), Cint, (Cstring, Int64, Ptr{Int64}, Int64),
+                    neighbours_file, n, nbr, D1))
+    end
+    return nothing
+end
+
 # ---- regular-grid short characteristics (src/characteristics.jl:19-95, :110-180) ----------------
 # S_0, α are (nz, nx, ny) Julia arrays, I_0 is (nx, ny); `atmos` contributes its three axes only
 function regular_solve(up::Bool, k, S_0::AbstractArray{<:Any,3}, I_0::AbstractMatrix, α::AbstractArray{<:Any,3},
@@ -214,6 +242,12 @@ VoronoiRT.J_λ_voronoi(S_λ::Matrix{<:VoronoiRT.UnitsIntensity_λ}, α_cont::Vec
 VoronoiRT.J_λ_voronoi(S_λ::AbstractArray, α_cont::AbstractArray, sites::VoronoiRT.VoronoiSites,
                       quadrature::String) =
     VoronoiRTHip.J_continuum(S_λ, α_cont, sites, quadrature)
+# preprocessing (compare_line.jl:100, compare_continuum.jl, compare_searchlight.jl): the executable's
+# path is ignored, the tessellation runs inside the library
+VoronoiRT.voro(voro_executable::String, sites_file::String, neighbours_file::String,
+               x_min::Float64, x_max::Float64, y_min::Float64, y_max::Float64,
+               z_min::Float64, z_max::Float64) =
+    VoronoiRTHip.voro_inprocess(sites_file, neighbours_file, x_min, x_max, y_min, y_max, z_min, z_max)
 # single solves (compare_searchlight.jl:113,129,434)
 VoronoiRT.Delaunay_upII(k::Vector{Float64}, S, I_0, α, sites::VoronoiRT.VoronoiSites, n_sweeps::Int) =
     VoronoiRTHip.solve(true, k, S, I_0, α, sites, n_sweeps)

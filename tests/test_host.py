@@ -500,3 +500,80 @@ def test_sorted_thread_assignment_of_the_level_kernel(bcc_small, voro_small):
                             groups_plain += g
             assert groups_sorted <= groups_plain          # fewer (wave, level) pairs to execute
         hs.close()
+
+
+# ---- in-process tessellation ------------------------------------------------------
+def _rows_as_sets(M):
+    return [frozenset(M[1:M[0, i] + 1, i].tolist()) for i in range(M.shape[1])]
+
+
+@pytest.mark.parametrize("case", ["uniform", "stratified", "bcc"])
+def test_native_tessellation_matches_qhull_neighbour_sets(case):
+    """vrt_tessellate (host C++, no GPU): the Voronoi neighbour SET of every cell -- walls -5 / -6
+    included -- equals the one scipy/Qhull's Delaunay triangulation of the periodically extended,
+    wall-mirrored point set gives (synth.voronoi_neighbours), and on a jittered BCC lattice the
+    analytic 14 neighbours.  (The order inside a row is voro++'s secret; nothing can pin it.)"""
+    if case == "uniform":
+        rng = np.random.default_rng(11)
+        n = 2500
+        bounds = (0.0, 2.0, 0.0, 1.0, 0.0, 1.0)
+        pos = np.stack([rng.uniform(0, 2, n), rng.uniform(0, 1, n), rng.uniform(0, 1, n)], axis=1)
+        ref = synth.voronoi_neighbours(pos, bounds, margin=0.35, shuffle_seed=None)
+    elif case == "stratified":
+        pos, ref, bounds = synth.voronoi_grid(6000, seed=3, bounds=(-0.5e6, 14.0e6, 0.0, 6.0e6, 0.0, 6.0e6),
+                                              scale_height=5.0e6, margin=0.45)
+    else:
+        # jittered BCC lattice: the 14 lattice neighbours of synth.bcc_grid are the exact Voronoi
+        # neighbours away from the walls (its wall rows are a construction, not the tessellation's)
+        pos, lattice, bounds = synth.bcc_grid(7, 9, seed=4)
+        ref = synth.voronoi_neighbours(pos, bounds, margin=0.45, shuffle_seed=None)
+        h = 6.0e6 / 7
+        inner = (pos[:, 0] > bounds[0] + 1.5 * h) & (pos[:, 0] < bounds[1] - 1.5 * h)
+        lat = _rows_as_sets(lattice)
+    M = vrt.voro(pos, bounds)
+    if case == "bcc":
+        rows = _rows_as_sets(M)
+        assert inner.sum() > 300 and all(rows[i] == lat[i] and len(rows[i]) == 14 for i in np.nonzero(inner)[0])
+    assert M.shape[1] == pos.shape[0] and M.dtype == np.int64
+    got, want = _rows_as_sets(M), _rows_as_sets(ref)
+    wrong = [i for i in range(len(got)) if got[i] != want[i]]
+    assert not wrong, (len(wrong), wrong[:5])
+    assert M.shape[0] == ref.shape[0]                      # same D = maximum neighbour count
+    # symmetric relation, walls only where the cell touches them
+    for i in (0, len(got) // 2, len(got) - 1):
+        for j in got[i]:
+            if j > 0:
+                assert (i + 1) in got[j - 1]
+
+
+def test_native_tessellation_feeds_read_cell(tmp_path):
+    """voro -> "%i %n" text file -> read_cell: the file round trip reproduces the matrix, and the
+    grid built from either has the same layers and permutations."""
+    pos, _, bounds = synth.voronoi_grid(1500, seed=8, bounds=(0.0, 2.0, 0.0, 1.0, 0.0, 1.0), scale_height=0.7)
+    f = str(tmp_path / "neighbours.txt")
+    M = vrt.voro(pos, bounds, neighbours_file=f)
+    back = orc.read_neighbours(f, pos.shape[0])
+    assert np.array_equal(back, M)
+    a = vrt.VoronoiSites(pos, M, bounds, device=-1)
+    b = vrt.read_cell(f, pos.shape[0], pos, bounds, device=-1)
+    so = orc.make_sites(pos, M, bounds)
+    for key in ("layers_up", "layers_down", "perm_up", "perm_down"):
+        assert np.array_equal(getattr(a, key), getattr(b, key)) and np.array_equal(getattr(a, key), getattr(so, key))
+
+
+def test_native_tessellation_errors():
+    L = _lib.load()
+    rng = np.random.default_rng(0)
+    pos = rng.random((40, 3))
+    with pytest.raises(vrt.VrtError):                      # a site outside the box
+        vrt.voro(pos + 2.0, (0, 1, 0, 1, 0, 1))
+    M3 = vrt.voro(pos[:3], (0, 1, 0, 1, 0, 1))             # 3 sites in a periodic box: every cell reaches its own
+    rows = _rows_as_sets(M3)                               # images across the period; those faces name no neighbour
+    assert all((i + 1) not in rows[i] for i in range(3))
+    assert all(j <= 0 or (i + 1) in rows[j - 1] for i in range(3) for j in rows[i])
+    M = np.zeros((5, 40), dtype=np.int64)                  # a matrix too narrow for the rows
+    mx = ctypes.c_int64()
+    b = np.array([0, 1, 0, 1, 0, 1], dtype=np.float64)
+    rc = L.vrt_tessellate(40, pos.ctypes.data_as(_lib.p_dbl), b.ctypes.data_as(_lib.p_dbl), 5,
+                          M.ctypes.data_as(_lib.p_i64), ctypes.byref(mx))
+    assert rc == _lib.VRT_EGRID

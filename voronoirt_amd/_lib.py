@@ -34,6 +34,8 @@ PROTOTYPES = {
     "vrt_grid_create_from_file": (ctypes.c_int, [ctypes.c_char_p, c_i64, p_dbl, p_dbl,
                                                  ctypes.c_int, ctypes.POINTER(vp)]),
     "vrt_grid_destroy": (None, [vp]),
+    "vrt_tessellate": (ctypes.c_int, [c_i64, p_dbl, p_dbl, c_i64, p_i64, p_i64]),
+    "vrt_write_neighbours_file": (ctypes.c_int, [ctypes.c_char_p, c_i64, p_i64, c_i64]),
     "vrt_grid_n": (c_i64, [vp]),
     "vrt_grid_max_neighbours": (c_i64, [vp]),
     "vrt_grid_num_layer_offsets": (c_i64, [vp, ctypes.c_int]),

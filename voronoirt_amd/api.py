@@ -155,6 +155,24 @@ class VoronoiSites:
             pass
 
 
+def voro(positions, bounds, neighbours_file: str | None = None, max_guess: int = 70) -> np.ndarray:
+    """The reference's `voro` step (src/functions.jl:13-23: run the voro++ wrapper on the sites file)
+    in-process: Voronoi neighbours of `positions` (n, 3) [z, x, y] in `bounds` = (z_min, z_max,
+    x_min, x_max, y_min, y_max), periodic in x and y, walls -5 / -6 in z.  Returns the (D+1, n)
+    matrix `read_cell` builds; with `neighbours_file` also writes the voro++ "%i %n" text file.
+    Host code (no GPU needed)."""
+    L = _lib.load()
+    pos = _f64(positions)
+    n = pos.shape[0]
+    b = np.array([float(v) for v in bounds], dtype=np.float64)
+    M = np.zeros((max_guess + 1, n), dtype=np.int64)
+    mx = ctypes.c_int64()
+    check(L.vrt_tessellate(n, _d(pos), _d(b), max_guess + 1, _i(M), ctypes.byref(mx)))
+    if neighbours_file is not None:
+        check(L.vrt_write_neighbours_file(neighbours_file.encode(), n, _i(M), max_guess + 1))
+    return np.ascontiguousarray(M[: mx.value + 1])
+
+
 def read_cell(fname: str, n_sites: int, positions, bounds, device: int = 0) -> VoronoiSites:
     """read_cell (src/voronoi_utils.jl:36-85): parse the voro++ "%i %n" neighbour file, layer the
     grid from both walls, sort, and compute the Delaunay lines.  `bounds` =

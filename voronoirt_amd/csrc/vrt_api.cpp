@@ -1,6 +1,7 @@
 // extern "C" entry points of libvrt_hip.so (declared in include/voronoirt.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -653,6 +654,38 @@ int vrt_grid_create_from_file(const char *neighbours_file, int64_t n, const doub
     } catch (...) {
         return fail(VRT_EINVAL, "unexpected exception");
     }
+}
+
+int vrt_tessellate(int64_t n, const double *pos_zxy, const double bounds[6], int64_t D1, int64_t *nbr,
+                   int64_t *max_count)
+{
+    if (!pos_zxy || !bounds || !nbr) return fail(VRT_EINVAL, "NULL argument");
+    if (n < 2 || n >= ((int64_t)1 << 30)) return fail(VRT_EINVAL, "n must be in [2, 2^30)");
+    if (D1 < 5) return fail(VRT_EINVAL, "D1 must leave room for at least four neighbours");
+    try {
+        unsigned hw = std::thread::hardware_concurrency();
+        const int nthr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hw ? hw : 4), 64, n / 256 + 1}));
+        return tessellate_host(n, pos_zxy, bounds, D1, nbr, max_count, nthr);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_write_neighbours_file(const char *path, int64_t n, const int64_t *nbr, int64_t D1)
+{
+    if (!path || !nbr) return fail(VRT_EINVAL, "NULL argument");
+    FILE *f = std::fopen(path, "w");
+    if (!f) return fail(VRT_EIO, std::string("cannot write ") + path);
+    for (int64_t i = 0; i < n; i++) {       // voro++ "%i %n": id, then the neighbours (output_sites.cc:49)
+        std::fprintf(f, "%lld", (long long)(i + 1));
+        const int64_t cnt = std::min<int64_t>(nbr[i], D1 - 1);
+        for (int64_t q = 1; q <= cnt; q++) std::fprintf(f, " %lld", (long long)nbr[i + n * q]);
+        std::fputc('\n', f);
+    }
+    if (std::fclose(f) != 0) return fail(VRT_EIO, std::string("error writing ") + path);
+    return VRT_OK;
 }
 
 void vrt_grid_destroy(vrt_grid *g)

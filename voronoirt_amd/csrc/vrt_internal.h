@@ -187,6 +187,10 @@ int parse_neighbour_file(const char *path, int64_t n, std::vector<int64_t> &matr
 int build_grid_host(vrt_grid *g, int64_t n, const double *pos, const int64_t *nbr, int64_t D1,
                     const double bounds[6]);
 
+// ---- in-process tessellation (vrt_tessellate.cpp) ------------------------------------------------
+int tessellate_host(int64_t n, const double *pos, const double bounds[6], int64_t D1, int64_t *nbr_out,
+                    int64_t *max_count, int nthreads);
+
 // ---- schedule (vrt_schedule.cpp) -------------------------------------------------------------
 struct AngleSchedule {
     std::vector<uint32_t> site;      // live nodes sorted by level
