@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""diagnostics: a density-stratified TRUE Voronoi tessellation (scipy/Qhull, periodic in x, y) at a
-size where its largest BFS layer exceeds the LDS kernels' 8 192 sites: which path runs, how fast,
-parity of a wavelength sample against the oracle.  usage: python tools/real_grid_check.py [n_sites] [nlam]"""
+"""diagnostics: a density-stratified TRUE Voronoi tessellation (the library's own vrt_tessellate,
+periodic in x, y) at sizes where the largest BFS layer exceeds the pair kernel's 8 192 sites: which
+path runs, how fast, parity of a wavelength sample against the oracle.
+usage: python tools/real_grid_check.py [n_sites] [nlam] [scale_height_m]"""
 import os
 import sys
 import time
@@ -16,9 +17,17 @@ from voronoirt_amd import _lib, synth  # noqa: E402
 
 n_sites = int(sys.argv[1]) if len(sys.argv) > 1 else 250000
 nlam = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+H = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0e6
+bounds = (-0.5e6, 14.0e6, 0.0, 6.0e6, 0.0, 6.0e6)
+rng = np.random.default_rng(11)
+u = rng.random(n_sites)
+Lz = bounds[1] - bounds[0]
+pos = np.stack([bounds[0] - H * np.log(1.0 - u * (1.0 - np.exp(-Lz / H))),      # density ~ exp(-z/H): sample_grids.jl:223-230
+                bounds[2] + rng.random(n_sites) * (bounds[3] - bounds[2]),
+                bounds[4] + rng.random(n_sites) * (bounds[5] - bounds[4])], axis=1)
 t0 = time.time()
-pos, nbr, bounds = synth.voronoi_grid(n_sites, 11, bounds=(-0.5e6, 14.0e6, 0.0, 6.0e6, 0.0, 6.0e6), scale_height=2.0e6)[:3]
-print(f"tessellation of {n_sites} sites: {time.time() - t0:.1f} s", flush=True)
+nbr = vrt.voro(pos, bounds)
+print(f"tessellation of {n_sites} sites (vrt_tessellate): {time.time() - t0:.1f} s, D = {nbr.shape[0] - 1}", flush=True)
 t0 = time.time()
 hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
 lu, ld_ = np.diff(hs.layers_up), np.diff(hs.layers_down)
