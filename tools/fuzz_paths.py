@@ -53,6 +53,16 @@ for case in range(cases):
         J, I = plan.execute(S, al, weights=w, I0_up=I0, want_I=True)
         res[path] = (J.copy(), I.copy())
         plan.close()
+    # the single-wavelength level kernel (large layers / fp32 storage) on the same problem: bitwise the pair kernel
+    os.environ["VRT_PATH"] = "steps"
+    os.environ["VRT_STEP_SINGLE"] = "1"
+    plan = vrt.FormalPlan(hs, ks, n_sweeps)
+    J1, I1 = plan.execute(S, al, weights=w, I0_up=I0, want_I=True)
+    plan.close()
+    os.environ.pop("VRT_STEP_SINGLE")
+    if not (np.array_equal(J1, res["steps"][0]) and np.array_equal(I1, res["steps"][1])):
+        print(f"case {case} {desc}: single-wavelength level kernel differs from the pair kernel")
+        sys.exit(1)
     ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, n_sweeps=n_sweeps, nthreads=4)
     scale = max(np.abs(ref).max(), 1e-300)
     e_or = np.abs(res["levels"][0] - ref).max() / scale

@@ -76,6 +76,7 @@ static void free_grid(vrt_grid *g)
     dev_free(g->down.d_lay);
     dev_free(g->d_scalars);
     dev_free(g->d_small);
+    if (g->small_ev) (void)hipEventDestroy(g->small_ev);
     dev_free(g->up.d_store);
     dev_free(g->down.d_store);
     dev_free(g->up.d_srank);
@@ -1108,11 +1109,16 @@ int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *d
     return VRT_OK;
 }
 
-// wavelength-sized host arrays -> the grid's device scratch (caller holds g->mu)
+// wavelength-sized host arrays -> the grid's device scratch (caller holds g->mu).  The scratch is
+// shared by successive calls, possibly on different streams: the copy first waits for the kernel of
+// the previous call that read it (small_ev, recorded by small_done after that launch).
 static int upload_small(vrt_grid *g, const std::vector<double> &h, hipStream_t st)
 {
+    if (g->small_ev_valid) VRT_HIP_TRY(hipStreamWaitEvent(st, g->small_ev, 0));
     if (!g->d_small || g->small_cap < h.size()) {
+        if (g->small_ev_valid) VRT_HIP_TRY(hipEventSynchronize(g->small_ev));   // about to free it
         dev_free(g->d_small);
+    if (g->small_ev) (void)hipEventDestroy(g->small_ev);
         g->small_cap = 0;
         int rc = dev_alloc(&g->d_small, std::max<size_t>(h.size(), 256));
         if (rc) return rc;
@@ -1121,6 +1127,14 @@ static int upload_small(vrt_grid *g, const std::vector<double> &h, hipStream_t s
     // synchronous w.r.t. the host vector: the copy is enqueued on st and the vector dies at return
     VRT_HIP_TRY(hipMemcpyAsync(g->d_small, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st));
     VRT_HIP_TRY(hipStreamSynchronize(st));
+    return VRT_OK;
+}
+
+static int small_done(vrt_grid *g, hipStream_t st)
+{
+    if (!g->small_ev) VRT_HIP_TRY(hipEventCreateWithFlags(&g->small_ev, hipEventDisableTiming));
+    VRT_HIP_TRY(hipEventRecord(g->small_ev, st));
+    g->small_ev_valid = true;
     return VRT_OK;
 }
 
@@ -1144,8 +1158,9 @@ int vrt_line_opacity_dev(vrt_plan *p, int64_t nlam, const double *lambda, double
         std::lock_guard<std::mutex> lock(g->mu);
         std::vector<double> h(lambda, lambda + nlam);
         if ((rc = upload_small(g, h, (hipStream_t)stream))) return rc;
-        return launch_line_opacity(p, nlam, g->d_small, lambda0, c0, d_velocity, d_doppler_width, d_gamma,
-                                   d_line_strength, d_alpha_cont, d_alpha_native, (hipStream_t)stream);
+        rc = launch_line_opacity(p, nlam, g->d_small, lambda0, c0, d_velocity, d_doppler_width, d_gamma,
+                                 d_line_strength, d_alpha_cont, d_alpha_native, (hipStream_t)stream);
+        return rc ? rc : small_done(g, (hipStream_t)stream);
     } catch (const std::bad_alloc &) {
         return fail(VRT_ENOMEM, "out of host memory");
     } catch (...) {
@@ -1179,10 +1194,11 @@ int vrt_rates_populations_dev(vrt_grid *g, int64_t nlam, int64_t ld, const doubl
         h.insert(h.end(), sigma_bf1, sigma_bf1 + (blocks[3] - blocks[2]));
         h.insert(h.end(), sigma_bf2, sigma_bf2 + (blocks[5] - blocks[4]));
         if ((rc = upload_small(g, h, (hipStream_t)stream))) return rc;
-        return launch_rates_populations(g, nlam, ld, blocks, g->d_small, dJ, lambda0, c0, d_doppler_width,
-                                        d_gamma, sigma_bb_const, d_temperature, d_lte_populations, hc_over_kB,
-                                        pref_ij, pref_ji, d_C, d_atom_density, d_R, d_populations,
-                                        (hipStream_t)stream);
+        rc = launch_rates_populations(g, nlam, ld, blocks, g->d_small, dJ, lambda0, c0, d_doppler_width,
+                                      d_gamma, sigma_bb_const, d_temperature, d_lte_populations, hc_over_kB,
+                                      pref_ij, pref_ji, d_C, d_atom_density, d_R, d_populations,
+                                      (hipStream_t)stream);
+        return rc ? rc : small_done(g, (hipStream_t)stream);
     } catch (const std::bad_alloc &) {
         return fail(VRT_ENOMEM, "out of host memory");
     } catch (...) {

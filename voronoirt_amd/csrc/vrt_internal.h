@@ -93,6 +93,8 @@ struct vrt_grid {
     unsigned long long *d_scalars = nullptr;   // scratch of the Λ-iteration epilogue's reduction
     double *d_small = nullptr;                 // wavelength-sized host arrays of the physics kernels (λ, 2hc²/λ⁵, σ_bf)
     size_t small_cap = 0;
+    hipEvent_t small_ev = nullptr;             // last kernel that read d_small
+    bool small_ev_valid = false;
     // cache of single-angle plans for vrt_delaunay_up/down
     std::mutex mu;
     std::vector<vrt::PlanCacheEntry *> cache;
