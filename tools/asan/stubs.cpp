@@ -17,8 +17,15 @@ int launch_lambda_update(int64_t, int64_t, int64_t, const double *, const double
 int launch_permute_table(vrt_plan *, int, const uint32_t *) { return nodev(); }
 int launch_sorted_tables(vrt_plan *, int) { return nodev(); }
 int launch_gpos(vrt_plan *, int) { return nodev(); }
-int execute_tiles(vrt_plan *, int64_t, int64_t, const double *, const double *, int, const double *, const double *,
-                  const double *, double *, double *, hipStream_t) { return nodev(); }
+int execute_tiles(vrt_plan *, int64_t, int64_t, const void *, const void *, int, const void *, const void *,
+                  const double *, void *, void *, hipStream_t, bool) { return nodev(); }
+int alpha_to_native(vrt_plan *, int64_t, int64_t, const double *, double *, hipStream_t) { return nodev(); }
+int64_t steps_max_layer(bool f32) { return f32 ? 18432 : 12288; }
+int launch_line_opacity(vrt_plan *, int64_t, const double *, double, double, const double *, const double *, const double *,
+                        const double *, const double *, double *, hipStream_t) { return nodev(); }
+int launch_rates_populations(vrt_grid *, int64_t, int64_t, const int64_t *, const double *, const double *, double, double,
+                             const double *, const double *, double, const double *, const double *, double, double, double,
+                             const double *, const double *, double *, double *, hipStream_t) { return nodev(); }
 }  // namespace vrt
 
 using namespace vrt;

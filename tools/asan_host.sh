@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 out=gpurun_out/asan; mkdir -p $out
 g++ -std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer \
     -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Ivoronoirt_amd/csrc \
-    voronoirt_amd/csrc/vrt_api.cpp voronoirt_amd/csrc/vrt_grid.cpp voronoirt_amd/csrc/vrt_schedule.cpp tools/asan/stubs.cpp \
+    voronoirt_amd/csrc/vrt_api.cpp voronoirt_amd/csrc/vrt_grid.cpp voronoirt_amd/csrc/vrt_schedule.cpp voronoirt_amd/csrc/vrt_tessellate.cpp tools/asan/stubs.cpp \
     -L/opt/rocm/lib -lamdhip64 -lpthread -Wl,-rpath,/opt/rocm/lib -o $out/libvrt_hip.so
 VRT_LIB_PATH=$PWD/$out/libvrt_hip.so LD_PRELOAD=$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so) \
     ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
