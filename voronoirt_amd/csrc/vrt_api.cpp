@@ -185,6 +185,7 @@ static void free_plan(vrt_plan *p)
     dev_free(p->ws_AA);
     for (int i = 0; i < 2; i++) dev_free(p->ws_cg[i]);
     dev_free(p->d_step_angles);
+    dev_free(p->d_level_map);
     if (p->step_fork) (void)hipEventDestroy(p->step_fork);
     for (int i = 0; i < 4; i++) {
         if (p->step_join[i]) (void)hipEventDestroy(p->step_join[i]);
@@ -467,6 +468,12 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                     nlev[(size_t)a * (size_t)(maxL + 1) + l] = nl[l];
                 adir[(size_t)a] = p->dir_of_active[(size_t)a] > 0 ? 0 : 1;
                 p->angle_visits[(size_t)a] = lsched[(size_t)a].n_visits + n;   // + n: phase 1 touches every site
+                {
+                    double sum = 0.0;
+                    int cntl = 0;
+                    for (size_t l = 2; l < nl.size(); l++, cntl++) sum += nl[l];
+                    p->angle_mean_levels.push_back(cntl ? sum / cntl : 0.0);
+                }
             }
             dev_free(d_vis_site);
             VRT_TRY_FREE(dev_alloc(&p->d_nlev, nlev.size()));

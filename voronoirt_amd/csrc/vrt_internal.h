@@ -163,6 +163,10 @@ struct vrt_plan {
     int step_groups = 0;
     int32_t *d_step_angles = nullptr;
     std::vector<int> step_group_off;
+    std::vector<double> angle_mean_levels;   // mean in-layer level count per active angle (level-kernel task cost)
+    int32_t *d_level_map = nullptr;      // block -> task of the layer-step level kernels, per stream group (build_level_map)
+    std::vector<int> level_map_off;      //   offsets of the groups' maps (+ end); 8 ceil-blocks each
+    int level_map_units = 0, level_map_groups = 0;
     hipStream_t step_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t step_fork = nullptr, step_join[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_path = 0;                   // 1 = level kernels, 2 = layer tiles

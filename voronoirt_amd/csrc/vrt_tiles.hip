@@ -783,6 +783,7 @@ struct StepArgs {
     int pairs_per_thread;     // wavelength pairs one k_step_coeffs thread loops over
     int chunks;               // 256-slot chunks per layer (k_step_coeffs grid.x / 1)
     int xcd_map;              // 0: plain grid; 1, 2: contiguous chunk ranges per XCD (2: angle fastest)
+    const int32_t *level_map; // level kernels: block -> task (index into angle_list x wavelengths), -1 = padding; NULL: identity
     const int32_t *t_rank_s;  // single-wavelength level kernel: storage position -> sorted index
     const uint32_t *t_loc_ss; //   and the upwind tile slots in sorted terms
     int debug_skip_levels;    // diagnostics only (VRT_DEBUG_SKIP_LEVELS=1): wrong results
@@ -926,6 +927,18 @@ k_step_coeffs(StepArgs sa)
     }
 }
 
+// Task (angle-major index into angle_list x wavelengths) of a level workgroup.  Workgroups are dealt
+// round-robin to the 8 XCDs (block b and b + 8 share one); level_map (build_level_map) gives each
+// XCD a contiguous run of the tasks, cut at equal estimated cost: the wavelengths of an angle
+// read that angle's tables (16-20 B per site and workgroup) through ONE L2 instead of all eight
+// (C5: 7 MB of tables per layer do not fit a 4 MB L2), and the two wavelengths of a pair store
+// their halves of the same lines of I through the same L2.  -1: padding block.
+__device__ __forceinline__ int level_task(const StepArgs &sa, int ntask)
+{
+    if (sa.level_map) return sa.level_map[blockIdx.x];
+    return (int)blockIdx.x < ntask ? (int)blockIdx.x : -1;
+}
+
 template <int K>
 __global__ void __launch_bounds__(1024)
 k_step_levels(StepArgs sa)
@@ -933,7 +946,9 @@ k_step_levels(StepArgs sa)
     extern __shared__ __attribute__((aligned(16))) double2 tile2[];
     const TileArgs &ta = sa.ta;
     const int T = 1024, tid = threadIdx.x;
-    const int a = sa.angle_list[blockIdx.x / sa.npair], q = blockIdx.x % sa.npair;
+    const int lt = level_task(sa, sa.n_list * sa.npair);
+    if (lt < 0) return;
+    const int a = sa.angle_list[lt / sa.npair], q = lt % sa.npair;
     const int task = a * sa.npair + q;
     const int d = ta.angle_dir[a];
     if (sa.layer > ta.nlayers[d]) return;
@@ -1035,7 +1050,9 @@ k_step_levels1(StepArgs sa)
     T *tile1 = reinterpret_cast<T *>(tile_raw);
     const TileArgs &ta = sa.ta;
     const int TT = 1024, tid = threadIdx.x;
-    const int a = sa.angle_list[blockIdx.x / ta.nlam], l = blockIdx.x % ta.nlam;
+    const int lt = level_task(sa, sa.n_list * ta.nlam);
+    if (lt < 0) return;
+    const int a = sa.angle_list[lt / ta.nlam], l = lt % ta.nlam;
     const int d = ta.angle_dir[a];
     if (sa.layer > ta.nlayers[d]) return;
     const int lo = ta.lay[d][sa.layer - 1], hi = ta.lay[d][sa.layer];
@@ -1053,6 +1070,7 @@ k_step_levels1(StepArgs sa)
     const T *__restrict__ gg = reinterpret_cast<const T *>(sa.cg_g) + 2 * o;
     T c[K], g1[K], g2[K];
     uint32_t loc[K], vis[K];
+    const int dbgl = kDiag ? sa.debug_flags : 0;     // timing diagnostics (-DVRT_DIAG build only)
     {
         uint32_t self[K];            // live during the permutation only
         // coefficients arrive in storage order (coalesced) ...
@@ -1061,17 +1079,22 @@ k_step_levels1(StepArgs sa)
             const int i = tid + k * TT;
             const bool ok = i < cnt;
             const int ii = ok ? i : cnt - 1;
+            if (dbgl & 8) {              // no coefficient loads
+                c[k] = (T)(1.0 + ii); g1[k] = (T)0.25; g2[k] = (T)0.125;
+            } else {
             c[k] = cc[ii];
             const uint32_t gp = ta.t_gpos[tab + lo + ii];
             const T *gl = gg + (gp & 0xFFFFu);
             const bool in1 = (gp >> 30) & 1u, in2 = gp >> 31;
             g1[k] = in1 ? gl[0] : (T)0;
             g2[k] = in2 ? gl[in1 ? 1 : 0] : (T)0;
+            }
             self[k] = (uint32_t)(tself[lo + ii] - lo);
             loc[k] = tloc[lo + ii];
             vis[k] = ok ? tvis[lo + ii] : 0u;
         }
         // ... and are dealt to the threads in visit-pattern order through the still unused tile
+        if (!(dbgl & 256))               // (256: no permutation)
 #pragma unroll
         for (int arr = 0; arr < 3; arr++) {
             T *v = arr == 0 ? c : arr == 1 ? g1 : g2;
@@ -1089,11 +1112,12 @@ k_step_levels1(StepArgs sa)
         if (tid + k * TT < cnt) tile1[tid + k * TT] = (T)0;      // I = zero(S), irregular_ray_tracing.jl:23
     if (tid == 0) tile1[cnt] = (T)0;                             // the zero slot
     __syncthreads();
-    const int nl = ta.nlev[(size_t)a * (size_t)(ta.max_layers + 1) + sa.layer];
+    const int nl = (kDiag && sa.debug_skip_levels) ? 0 : ta.nlev[(size_t)a * (size_t)(ta.max_layers + 1) + sa.layer];
     for (int t = 1; t <= nl; t++) {
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if ((vis[k] & 0xFFu) == (uint32_t)t) {       // a site's visits come at increasing levels
+                if (dbgl & 512) { vis[k] >>= 8; continue; }   // (512: levels polled, no visits)
                 uint32_t lk = loc[k];
                 asm volatile("" : "+v"(lk));      // keep the two slots packed in ONE register (no hoisted addresses)
                 const uint32_t lx = lk & 0xFFFFu, ly = lk >> 16;           // kNoSlot -> the zero slot
@@ -1112,7 +1136,11 @@ k_step_levels1(StepArgs sa)
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int slot = tid + k * TT;
-        if (slot < cnt) I[(size_t)(lo + slot) << 1] = tile1[trank[lo + slot] - lo];
+        if (slot < cnt && (!(dbgl & 16) || tile1[slot] == (T)1.2345e30)) {
+            if (dbgl & 1024) I[(size_t)(lo + slot) + (size_t)(l & 1) * (size_t)(hi - lo)] = tile1[trank[lo + slot] - lo];   // (1024: contiguous stores)
+            else
+            I[(size_t)(lo + slot) << 1] = tile1[trank[lo + slot] - lo];
+        }
     }
     if (tid == 0 && sa.layer == ta.nlayers[d]) I[(size_t)(n - 1) << 1] = (T)0;   // never-visited site perm[n]
 }
@@ -1314,6 +1342,55 @@ static int ensure_step_streams(vrt_plan *p, int G)
     return VRT_OK;
 }
 
+// block -> task maps of the level kernels, one per stream group (see level_task): the group's tasks
+// (angle-major, `units` wavelengths or wavelength pairs per angle) are cut into 8 contiguous runs of
+// equal estimated cost -- a fixed part (loads, permutation, stores) plus the angle's mean level
+// count -- and XCD x (blocks x, x + 8, ...) walks run x.
+static int build_level_map(vrt_plan *p, int G, int units)
+{
+    if (p->d_level_map && p->level_map_groups == G && p->level_map_units == units) return VRT_OK;
+    if (p->d_level_map) { (void)hipFree(p->d_level_map); p->d_level_map = nullptr; }
+    double mean_all = 0.0;
+    for (double v : p->angle_mean_levels) mean_all += v;
+    mean_all = p->angle_mean_levels.empty() ? 1.0 : std::max(1.0, mean_all / (double)p->angle_mean_levels.size());
+    std::vector<int32_t> h_angles((size_t)p->A);
+    VRT_HIP_TRY(hipMemcpy(h_angles.data(), p->d_step_angles, sizeof(int32_t) * (size_t)p->A, hipMemcpyDeviceToHost));
+    std::vector<int32_t> map;
+    p->level_map_off.assign((size_t)G + 1, 0);
+    for (int gi = 0; gi < G; gi++) {
+        p->level_map_off[(size_t)gi] = (int)map.size();
+        const int j0 = p->step_group_off[(size_t)gi], n_list = p->step_group_off[(size_t)gi + 1] - j0;
+        const int ntask = n_list * units;
+        if (ntask == 0) continue;
+        std::vector<double> w((size_t)n_list);
+        double W = 0.0;
+        for (int j = 0; j < n_list; j++) {
+            const int a = h_angles[(size_t)(j0 + j)];
+            const double lv = (size_t)a < p->angle_mean_levels.size() ? p->angle_mean_levels[(size_t)a] : mean_all;
+            w[(size_t)j] = 1.7 * mean_all + lv;          // measured on C5: fixed part : level loop = 231 : 133
+            W += w[(size_t)j] * units;
+        }
+        std::vector<std::vector<int32_t>> runs(8);
+        double cum = 0.0;
+        for (int t = 0; t < ntask; t++) {
+            const double wt = w[(size_t)(t / units)];
+            const int x = std::min(7, (int)((cum + 0.5 * wt) * 8.0 / W));
+            runs[(size_t)x].push_back(t);
+            cum += wt;
+        }
+        size_t per = 0;
+        for (const auto &r : runs) per = std::max(per, r.size());
+        for (size_t j = 0; j < per; j++)
+            for (int x = 0; x < 8; x++) map.push_back(j < runs[(size_t)x].size() ? runs[(size_t)x][j] : -1);
+    }
+    p->level_map_off[(size_t)G] = (int)map.size();
+    VRT_HIP_TRY(hipMalloc((void **)&p->d_level_map, sizeof(int32_t) * std::max<size_t>(map.size(), 1)));
+    VRT_HIP_TRY(hipMemcpy(p->d_level_map, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice));
+    p->level_map_groups = G;
+    p->level_map_units = units;
+    return VRT_OK;
+}
+
 // sites per thread the single-wavelength level kernel is instantiated for (even counts)
 constexpr int kSingleMaxK64 = 12, kSingleMaxK32 = 18;
 
@@ -1469,7 +1546,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         // 1: S/alpha gathers off, 2: I gathers off, 4: coefficient stores off, 8: coefficient loads off,
         // 16: I stores off, 32: no linear_weights arithmetic, 64: level kernel keeps the storage-order thread assignment
         sa.debug_flags = (kDiag && std::getenv("VRT_DEBUG_FLAGS")) ? std::atoi(std::getenv("VRT_DEBUG_FLAGS")) : 0;
-        if ((sa.debug_flags & ~(64 | 128)) || sa.debug_skip_levels) {
+        if ((sa.debug_flags & ~(64 | 128)) || sa.debug_skip_levels) {   // (256, 512, 1024: single-wavelength level kernel)
             static bool warned = false;
             if (!warned) std::fprintf(stderr, "[vrt] VRT_DEBUG_FLAGS / VRT_DEBUG_SKIP_LEVELS set: timing diagnostics, the results are WRONG\n");
             warned = true;
@@ -1484,6 +1561,10 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         if (const char *e = std::getenv("VRT_STEP_STREAMS")) G = std::atoi(e);
         G = std::max(1, std::min({G, 4, A}));
         if ((rc = ensure_step_streams(p, G))) return rc;
+        // level workgroups -> XCDs: contiguous cost-balanced runs (VRT_STEP_LEVEL_MAP=0: round-robin)
+        const bool use_map = !(std::getenv("VRT_STEP_LEVEL_MAP") && std::atoi(std::getenv("VRT_STEP_LEVEL_MAP")) == 0);
+        if (use_map && (rc = build_level_map(p, G, single ? (int)nlam : npair))) return rc;
+        sa.level_map = nullptr;
         VRT_HIP_TRY(hipEventRecord(p->ev0, st));
         VRT_HIP_TRY(hipEventRecord(p->step_fork, st));
         launches = 0;
@@ -1515,18 +1596,28 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                 if (n_list == 0) continue;
                 sa.angle_list = p->d_step_angles + p->step_group_off[gi];
                 sa.n_list = n_list;
+                const size_t ntask_l = (size_t)n_list * (size_t)(single ? (int)nlam : npair);
+                size_t lblocks = ntask_l;
+                // only while a launch is a single round of the chip (<= one workgroup per CU): with several
+                // rounds the fixed split costs more in balance than the shared L2 gains (C5: 150 -> 153 ms;
+                // C3, 100 workgroups per launch: 9.83 -> 9.50 ms)
+                sa.level_map = nullptr;
+                if (use_map && ntask_l <= 256) {
+                    sa.level_map = p->d_level_map + p->level_map_off[(size_t)gi];
+                    lblocks = (size_t)(p->level_map_off[(size_t)gi + 1] - p->level_map_off[(size_t)gi]);
+                }
                 const dim3 g1(sa.xcd_map ? (unsigned)(8 * per_xcd * n_list * ngrp) : (unsigned)(sa.chunks * n_list * ngrp));
                 if (single) {
                     hipLaunchKernelGGL((k_step_coeffs<T, true>), g1, dim3(256), 0, sg, sa);
                     const int K1 = std::max(need_K, std::min(force_K, kF32 ? kSingleMaxK32 : kSingleMaxK64));
-                    launch_levels1_K<T>(std::max(K1, 1), dim3((unsigned)((size_t)n_list * (size_t)nlam)),
+                    launch_levels1_K<T>(std::max(K1, 1), dim3((unsigned)lblocks),
                                         (size_t)(cnt_l + 1) * sizeof(T), sg, sa);
                     launches += 2;
                     continue;
                 }
                 if constexpr (!kF32) {
                     const size_t lds = (size_t)(cnt_l + 1) * sizeof(double2);   // + the zero slot
-                    const dim3 g2((unsigned)((size_t)n_list * (size_t)npair));
+                    const dim3 g2((unsigned)lblocks);
                     hipLaunchKernelGGL((k_step_coeffs<double, false>), g1, dim3(256), 0, sg, sa);
                     switch (step_K) {
                     case 1: hipLaunchKernelGGL(k_step_levels<1>, g2, dim3(1024), lds, sg, sa); break;
