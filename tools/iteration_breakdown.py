@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""diagnostics: one device-resident Λ-iteration of the line case at C4 size (995 566 sites, ul7n12,
+51 line + 2 x 20 continuum wavelengths), entry point by entry point ("Keeping a
+Λ-iteration on the device"):
+
+    vrt_line_opacity_dev -> vrt_plan_execute_dev (native α) -> vrt_lambda_update_dev -> vrt_rates_populations_dev
+
+HIP-event time of each call on the launch stream + the bytes each one has to move (its own floor).
+Synthetic inputs with physical magnitudes (tests/test_physics.py's Ly-α-like atom).
+
+    python tools/iteration_breakdown.py [--a 59 --c 143] [--reps 5]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import voronoirt_amd as vrt                     # noqa: E402
+from voronoirt_amd import _lib, api, synth      # noqa: E402
+
+C0, H_PLANCK, K_B = 2.99792458e8, 6.62607015e-34, 1.380649e-23
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--a", type=int, default=59)
+ap.add_argument("--c", type=int, default=143)
+ap.add_argument("--reps", type=int, default=5)
+args = ap.parse_args()
+
+dev = torch.device("cuda", 0)
+pos, nbr, bounds = synth.bcc_grid(args.a, args.c, seed=2022)
+sites = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+n = sites.n
+w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+plan = vrt.FormalPlan(sites, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
+
+rng = np.random.default_rng(7)
+nbb, nbf = 51, 20
+lambda0 = 121.567e-9
+q = np.concatenate([-np.geomspace(600, 0.05, nbb // 2), [0.0], np.geomspace(0.05, 600, nbb // 2)])
+lam = np.concatenate([lambda0 * (1 + q * 2.5e3 / C0), np.linspace(22.8e-9, 91.17e-9, nbf), np.linspace(91.2e-9, 364.7e-9, nbf)])
+blocks = np.array([0, nbb, nbb, nbb + nbf, nbb + nbf, nbb + 2 * nbf], dtype=np.int64)
+nlam_all = lam.size
+T = rng.uniform(4e3, 2e4, n)
+doppler = lambda0 / C0 * np.sqrt(2 * K_B * T / 1.6735575e-27)
+gamma = 4.702e8 + 10 ** rng.uniform(6, 10, n)
+velocity = rng.normal(0, 8e3, (n, 3))
+z = pos[:, 0]
+strat = np.exp(-(z - bounds[0]) / 0.7e6)
+strength = 3e-2 * strat * doppler.mean() * (1 + 0.1 * rng.random(n))     # Δτ between neighbours spans the branches
+alpha_cont = 1e-4 * strat
+lte = np.stack([10 ** rng.uniform(14, 19, n), 10 ** rng.uniform(8, 12, n), 10 ** rng.uniform(10, 16, n)])
+Cmat = 10 ** rng.uniform(-2, 4, (n, 3, 3))
+for d in range(3):
+    Cmat[:, d, d] = 0.0
+atom = lte.sum(axis=0)
+planck2 = 2 * H_PLANCK * C0 ** 2 / lam ** 5
+sig1 = 7.9e-22 * (lam[51:71] / lam[70]) ** 3
+sig2 = 1.4e-21 * (lam[71:91] / lam[90]) ** 3
+
+t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+d_vel, d_dop, d_gam, d_str, d_ac = t(velocity), t(doppler), t(gamma), t(strength), t(alpha_cont)
+d_T, d_lte, d_C, d_atom = t(T), t(lte), t(Cmat), t(atom)
+gen = torch.Generator(device=dev)
+gen.manual_seed(1)
+S = 1.0 + torch.rand((n, nbb), generator=gen, device=dev, dtype=torch.float64)
+B = 1.0 + torch.rand((n, nbb), generator=gen, device=dev, dtype=torch.float64)
+eps = 1e-3 + 0.1 * torch.rand((n, nbb), generator=gen, device=dev, dtype=torch.float64)
+S_new = torch.empty_like(S)
+J = torch.zeros((n, nlam_all), device=dev, dtype=torch.float64)          # line block first, continuum blocks as given
+J[:, nbb:] = 1e-6 * torch.rand((n, 2 * nbf), generator=gen, device=dev, dtype=torch.float64)
+n1 = int(sites.layers_up[1] - 1)
+I0 = S[torch.as_tensor(sites.perm_up[:n1] - 1, device=dev)].contiguous()
+native = torch.empty(plan.native_alpha_count(nbb), device=dev, dtype=torch.float64)
+d_R = torch.empty((n, 3, 3), device=dev, dtype=torch.float64)
+d_pop = torch.empty((3, n), device=dev, dtype=torch.float64)
+st = torch.cuda.current_stream().cuda_stream
+
+
+def opacity():
+    plan.line_opacity_dev(lam[:nbb], lambda0, C0, d_vel.data_ptr(), d_dop.data_ptr(), d_gam.data_ptr(),
+                          d_str.data_ptr(), d_ac.data_ptr(), native.data_ptr(), stream=st)
+
+
+def solve():
+    # J of the line block into the first nbb columns of the (n, 91) array (ld = 91)
+    plan.execute_dev(nbb, nbb, S.data_ptr(), native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE, w, dJ=Jline.data_ptr(),
+                     dI0_up=I0.data_ptr(), stream=st)
+
+
+def update():
+    api.lambda_update_dev(sites, nbb, nbb, Jline.data_ptr(), B.data_ptr(), eps.data_ptr(), S.data_ptr(),
+                          S_new.data_ptr(), stream=st)
+
+
+def rates():
+    api.rates_populations_dev(sites, lam, blocks, nlam_all, J.data_ptr(), planck2, lambda0, C0, d_dop.data_ptr(),
+                              d_gam.data_ptr(), H_PLANCK * C0 / (4 * np.pi * lambda0) * 4.5e20, sig1, sig2,
+                              d_T.data_ptr(), d_lte.data_ptr(), H_PLANCK * C0 / K_B, 2 * np.pi / (H_PLANCK * C0) / 1000.0,
+                              2 * np.pi / (H_PLANCK * C0), d_C.data_ptr(), d_atom.data_ptr(), d_R.data_ptr(),
+                              d_pop.data_ptr(), stream=st)
+
+
+Jline = torch.zeros((n, nbb), device=dev, dtype=torch.float64)
+A = nq
+steps = (
+    ("vrt_line_opacity_dev", opacity, 8.0 * (A * n * (nbb + 1) + 8 * n)),               # writes α of every angle
+    ("vrt_plan_execute_dev (J)", solve, float(n) * A * nbb * (40.0 + 40.0 / nbb)),      # §8d algorithmic bytes
+    ("vrt_lambda_update_dev", update, 8.0 * 5 * n * nbb),                               # J, B, ε, S_old in, S_new out
+    ("vrt_rates_populations_dev", rates, 8.0 * (n * nlam_all + 30 * n)),               # J in; R, populations, C out
+)
+print(f"{n} sites, {A} angles, {nbb} line + {2 * nbf} continuum wavelengths")
+total = 0.0
+for name, fn, nbytes in steps:
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.reps
+    total += ms
+    print(f"{name:28s} {ms:8.3f} ms   {nbytes / 1e9:7.2f} GB it must move -> {nbytes / ms / 1e6:7.1f} GB/s of those")
+print(f"{'one iteration':28s} {total:8.3f} ms   (path {plan.last_path})")
+assert torch.isfinite(Jline).all() and torch.isfinite(d_pop).all()
+plan.close()
+sites.close()

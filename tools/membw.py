@@ -8,7 +8,7 @@ def timeit(f, n=10):
     for _ in range(n): f()
     torch.cuda.synchronize()
     return (time.time() - t) / n
-for mb in (100, 1000, 5000):
+for mb in (40, 100, 1000, 5000):
     n = mb * 1000 * 1000 // 8
     a = torch.rand(n, device=dev, dtype=torch.float64); b = torch.empty_like(a)
     t = timeit(lambda: b.copy_(a)); print(f"copy   {mb:5d} MB: {2*n*8/t/1e9:8.1f} GB/s (read+write)")

@@ -14,7 +14,7 @@
 //
 // The Voigt profile is Transparency.jl's `voigt_profile` (absent from the reference checkout,
 // version unpinned): its documented algorithm, Humlíček's w4 (JQSRT 27, 437, 1982), is restated
-// here operation for operation as in oracle/vrt_oracle_physics.c; parity for these two kernels is
+// here as in oracle/vrt_oracle_physics.c (per-site divisors inverted once in the opacity kernel); parity for these two kernels is
 // tolerance-based (1e-12 against that restatement; w4 itself is a 1e-4 approximation of the
 // Faddeeva function).  All quantities are plain numbers in one unit system chosen by the caller;
 // physical constants and unit factors come in as arguments.
@@ -83,11 +83,6 @@ __device__ double humlicek_w4_re(double x, double y)
 
 constexpr double kPi = 3.14159265358979323846;
 
-__device__ __forceinline__ double voigt_profile(double a, double v, double dD)
-{
-    return humlicek_w4_re(v, a) / (sqrt(kPi) * dD);
-}
-
 // ---- opacity prologue -------------------------------------------------------------------------------
 // one thread per storage position of the angle's direction; it walks the wavelength pairs, so the
 // site's seven line parameters are read once and every pair plane is written coalesced (16 B/lane)
@@ -105,6 +100,11 @@ k_line_opacity(int64_t n, int nlam, int npair, const int32_t *__restrict__ store
     const double v_los = velocity[3 * (size_t)site] * (-k0) + velocity[3 * (size_t)site + 1] * (-k1) +
                          velocity[3 * (size_t)site + 2] * (-k2);
     const double dD = doppler[site], gm = gamma[site], st = strength[site], ac = alpha_cont[site];
+    // the kernel is bound by its fp64 arithmetic (51 Voigt evaluations per site and angle), and a
+    // division costs a dozen dependent instructions: the three per-site divisors are inverted once
+    // (last-bit differences from the oracle's divisions; contract of this row: 1e-12)
+    const double r_dD = 1.0 / dD, r_a = 1.0 / (4.0 * kPi * c0 * dD), r_prof = 1.0 / (sqrt(kPi) * dD);
+    const double shift = lambda0 * v_los / c0;
     for (int q = 0; q < npair; q++) {
         double v2[2];
 #pragma unroll
@@ -112,9 +112,9 @@ k_line_opacity(int64_t n, int nlam, int npair, const int32_t *__restrict__ store
             const int l = 2 * q + h;
             if (l < nlam) {
                 const double lam = lambda[l];
-                const double a = gm * (lam * lam) / (4.0 * kPi * c0 * dD);            // broadening.jl:87-89
-                const double v = (lam - lambda0 + lambda0 * v_los / c0) / dD;          // line.jl:132
-                v2[h] = st * voigt_profile(a, v, dD) + ac;                             // line.jl:133, :219-225; lambda_iteration.jl:93-96
+                const double a = gm * (lam * lam) * r_a;                               // broadening.jl:87-89
+                const double v = (lam - lambda0 + shift) * r_dD;                       // line.jl:132
+                v2[h] = st * (humlicek_w4_re(v, a) * r_prof) + ac;                     // line.jl:133, :219-225; lambda_iteration.jl:93-96
             } else
                 v2[h] = ac;                                                            // padding wavelength: finite
         }
