@@ -721,6 +721,30 @@ def test_device_resident_lambda_iteration(grids):
     plan.close()
 
 
+def test_lambda_update_large_with_leading_dimension(grids):
+    """vrt_lambda_update_dev beyond one pass of its grid-stride loop (> 1 M elements) and with a
+    padded leading dimension: S_new and the convergence scalar against numpy, padding untouched."""
+    import torch
+    from voronoirt_amd.api import lambda_update_dev
+    hs, so = grids["bcc"]
+    n = so.n
+    nlam = max(8, 3_000_000 // n + 1)
+    ld = nlam + 3
+    rng = np.random.default_rng(5)
+    J, B, S_old = (1 + rng.random((n, ld)) for _ in range(3))
+    eps = 10 ** rng.uniform(-3, 0, n)
+    dev = torch.device("cuda", 0)
+    Jd, Bd, Sd, ed = (torch.from_numpy(a).to(dev) for a in (J, B, S_old, eps))
+    out = torch.full((n, ld), -7.0, dtype=torch.float64, device=dev)
+    d = lambda_update_dev(hs, nlam, ld, Jd.data_ptr(), Bd.data_ptr(), ed.data_ptr(), Sd.data_ptr(), out.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+    ref = (1 - eps)[:, None] * J[:, :nlam] + eps[:, None] * B[:, :nlam]
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :nlam], ref)
+    assert (got[:, nlam:] == -7.0).all()
+    assert d == np.abs(1 - S_old[:, :nlam] / ref).max()
+
+
 def test_concurrent_single_solves_on_one_handle(grids):
     """The reference calls Delaunay_*II concurrently from Threads.@threads with a shared `sites`
     (lambda_iteration.jl:91-107); the drop-in must be re-entrant on one grid handle."""
