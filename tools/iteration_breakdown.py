@@ -43,11 +43,11 @@ q = np.concatenate([-np.geomspace(600, 0.05, nbb // 2), [0.0], np.geomspace(0.05
 lam = np.concatenate([lambda0 * (1 + q * 2.5e3 / C0), np.linspace(22.8e-9, 91.17e-9, nbf), np.linspace(91.2e-9, 364.7e-9, nbf)])
 blocks = np.array([0, nbb, nbb, nbb + nbf, nbb + nbf, nbb + 2 * nbf], dtype=np.int64)
 nlam_all = lam.size
-T = rng.uniform(4e3, 2e4, n)
+z = pos[:, 0]
+T = (5e3 + 1.5e4 * (z - bounds[0]) / (bounds[1] - bounds[0])) * (1 + 0.05 * rng.random(n))   # smooth in height, as an atmosphere is
 doppler = lambda0 / C0 * np.sqrt(2 * K_B * T / 1.6735575e-27)
 gamma = 4.702e8 + 10 ** rng.uniform(6, 10, n)
 velocity = rng.normal(0, 8e3, (n, 3))
-z = pos[:, 0]
 strat = np.exp(-(z - bounds[0]) / 0.7e6)
 strength = 3e-2 * strat * doppler.mean() * (1 + 0.1 * rng.random(n))     # Δτ between neighbours spans the branches
 alpha_cont = 1e-4 * strat
