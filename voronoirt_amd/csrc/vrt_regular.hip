@@ -429,6 +429,7 @@ struct vrt_regular {
     int device = 0;
     int64_t nz = 0, nx = 0, ny = 0;
     double *d_g = nullptr;                 // z | x | y
+    std::vector<double> h_g;               // the same on the host (launch geometry)
     double *d_S = nullptr, *d_A = nullptr, *d_I = nullptr, *d_k = nullptr, *d_coef = nullptr;
     int *d_up = nullptr;
     int64_t cap_S = 0, cap_A = 0, cap_I = 0, cap_k = 0, cap_coef = 0;      // in solves
@@ -462,6 +463,9 @@ extern "C" int vrt_regular_create(int64_t nz, int64_t nx, int64_t ny, const doub
     vrt_regular *r = new vrt_regular;
     r->device = device;
     r->nz = nz; r->nx = nx; r->ny = ny;
+    r->h_g.assign(z, z + nz);
+    r->h_g.insert(r->h_g.end(), x, x + nx);
+    r->h_g.insert(r->h_g.end(), y, y + ny);
     hipError_t e = hipMalloc((void **)&r->d_g, sizeof(double) * (size_t)(nz + nx + ny));
     if (e == hipSuccess) e = hipMemcpy(r->d_g, z, sizeof(double) * nz, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(r->d_g + nz, x, sizeof(double) * nx, hipMemcpyHostToDevice);
@@ -550,6 +554,24 @@ extern "C" int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const do
     // one thread per point of a row (the yz/xz planes march row by row), at least two waves; many
     // such workgroups share a CU, which is where the batch's throughput comes from
     int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(128, (std::max(nx, ny) - 2 + 63) / 64 * 64));
+    // A batch too small to fill the chip whose rays are all steep enough to cut the horizontal plane
+    // first (every plane point-parallel: the searchlight / emergent-intensity case, θ = 180°) spends
+    // its threads on the plane loops instead: up to 1024 per solve (60³: 1.46 -> 0.73 ms per solve)
+    {
+        const double *hz = r->h_g.data(), *hx = hz + nz, *hy = hx + nx;
+        bool all_xy = true;
+        for (int64_t s = 0; s < n_solve && all_xy; s++) {
+            const double *ks = k + 3 * s;
+            const double r_x = std::fabs((hx[1] - hx[0]) / ks[1]), r_y = std::fabs((hy[1] - hy[0]) / ks[2]);
+            for (int64_t iz = 1; iz < nz && all_xy; iz++) {
+                const double r_z = std::fabs((hz[iz] - hz[iz - 1]) / ks[0]);
+                if (r_x < r_z || r_y < r_z) all_xy = false;          // the kernel's argmin (:72)
+            }
+        }
+        if (all_xy)
+            while (threads < 1024 && n_solve * threads * 2 <= 256 * 1024 && (int64_t)threads * 2 <= (nx - 2) * (ny - 2))
+                threads *= 2;
+    }
     if (const char *e = std::getenv("VRT_REG_THREADS")) threads = std::max(64, std::min(1024, std::atoi(e) / 64 * 64));
     if (threads <= 256)
         hipLaunchKernelGGL(k_regular_solve<256>, dim3((unsigned)n_solve), dim3((unsigned)threads), lds, st, ra);
