@@ -276,3 +276,38 @@ def test_bench_two_ranks_reproduce_the_one_rank_J(tmp_path, shard):
         assert np.array_equal(J1, J2)            # every wavelength is solved by exactly one rank
     else:
         assert np.abs(J1 - J2).max() <= 1e-13 * np.abs(J1).max()   # the all-reduce changes the summation order
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_weak_default(launcher):
+    """The driver's scaling run: `bench.py --gpus 2` with the default (weak, wavelength-block) sharding,
+    started by bench.py itself or — as the driver does — under `python -m torch.distributed.run`.
+    One JSON line from rank 0, n_gpus 2, scaling "weak", twice the one-rank cell-update count per step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VRT_BENCH_REHEARSE="1")
+    env.pop("VRT_PATH", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary",
+            "--no-critical-path"]
+    bench = os.path.join(root, "bench.py")
+    r1 = subprocess.run([sys.executable, bench, "--gpus", "1"] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    if launcher == "self":
+        cmd = [sys.executable, bench, "--gpus", "2"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29613", bench, "--gpus", "2"] + args
+    r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    lines = [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only
+    j1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
+    j2 = json.loads(lines[0])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["steps"] == 2 and j2["warmup"] == 1
+    u1, u2 = j1["value"] * j1["ms_per_step"], j2["value"] * j2["ms_per_step"]
+    assert abs(u2 - 2 * u1) < 1e-6 * u2                       # whole-job aggregate: both ranks' updates
