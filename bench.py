@@ -468,6 +468,8 @@ def launch_own_ranks(args) -> int:
 
 def main():
     args = parse_args()
+    # the host driver supports dmabuf IPC only: RCCL and cross-process tensor sharing need this
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_own_ranks(args))
 
