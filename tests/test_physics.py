@@ -212,3 +212,97 @@ def test_gpu_rates_and_populations_against_oracle(bcc_small):
     pops_ref = orc.revised_populations(R, r["C"], r["atom"])          # same R in: isolates the 2 x 2 solve
     assert np.array_equal(d_pop.cpu().numpy(), pops_ref)
     hs.close()
+
+
+# ---- the whole Λ-iteration, device-resident, against the same loop driven by the oracle --------------
+def _lambda_case(pos, bounds, seed):
+    """Inputs of Λ_voronoi's loop on n sites: a 2-level + continuum atom with 21 line + 2 x 6 continuum
+    wavelengths, magnitudes chosen so that the box is optically thick at line centre and thin in the
+    wings, radiative and collisional rates are comparable and the populations stay positive."""
+    n = pos.shape[0]
+    c = _line_case(n, seed, nbb=21, nbf=6)
+    rng = c["rng"]
+    lam, nlam = c["lam"], c["lam"].size
+    z = (pos[:, 0] - bounds[0]) / (bounds[1] - bounds[0])
+    T = 6e3 + 6e3 * z + 200 * rng.random(n)
+    doppler = c["lambda0"] / C0 * np.sqrt(2 * K_B * T / 1.6735575e-27)
+    n1 = 1e16 * np.exp(-3 * z) * (1 + 0.1 * rng.random(n))
+    lte = np.stack([n1, n1 * 1e-3 * (1 + rng.random(n)), n1 * 1e-2 * (1 + rng.random(n))])
+    B0 = (1.0 + z)[:, None] * (1 + 0.05 * rng.random((n, nlam)))
+    Cm = 10 ** rng.uniform(-1, 1, (n, 3, 3))
+    for d in range(3):
+        Cm[:, d, d] = 0.0
+    box = bounds[1] - bounds[0]
+    Bij = 1.0
+    strength_const = 60.0 / box * doppler.mean() / n1.mean()       # line-centre τ of order 100 across the box
+    return vrt.LineCase(
+        lam=lam, blocks=c["blocks"], lambda0=c["lambda0"], c0=C0, velocity=rng.normal(0, 3e3, (n, 3)), doppler=doppler,
+        gamma=4.7e8 + 10 ** rng.uniform(7, 9, n), alpha_cont=0.05 / box * np.exp(-2 * z), eps=10 ** rng.uniform(-2.5, -0.5, n),
+        temperature=T, atom_density=lte.sum(axis=0), B0=B0, lte=lte, C=Cm, planck2=2.0 * (c["lambda0"] / lam) ** 5,
+        sigma_bf1=1e-21 * (lam[21:27] / lam[26]) ** 3, sigma_bf2=2e-21 * (lam[27:33] / lam[32]) ** 3,
+        strength_const=strength_const, Bij=Bij, Bji=0.25 * Bij, sigma_bb_const=2e-32,
+        hc_over_kB=H_PLANCK * C0 / K_B, pref_ij=2e36, pref_ji=2e37)
+
+
+def _oracle_lambda_iteration(case, so, quadrature, maxiter, eps_conv=0.0):
+    """Λ_voronoi's loop (src/lambda_iteration.jl:253-283) with the oracle's restatements."""
+    w, th, ph, nq = vrt.read_quadrature(quadrature)
+    pops = case.lte.copy()
+    S_new, S_old = case.B0.copy(), np.zeros_like(case.B0)
+    bottom = so.perm_up[: so.layers_up[1] - 1] - 1
+    hist, diff, i = [], np.inf, 0
+    while diff > eps_conv and i < maxiter:
+        S_old = S_new.copy()
+        strength = case.strength_const * (pops[0] * case.Bij - pops[1] * case.Bji)
+        alpha = np.stack([orc.line_opacity(orc.direction(th[a], ph[a]), case.lam, case.lambda0, case.c0, case.velocity,
+                                           case.doppler, case.gamma, strength, case.alpha_cont) for a in range(nq)])
+        J = orc.J_voronoi(w, th, ph, S_old, alpha, so, I0_up=case.B0[bottom], nthreads=8)
+        S_new = (1 - case.eps)[:, None] * J + case.eps[:, None] * case.B0
+        diff = float(np.abs(1 - S_old / S_new).max())
+        R = orc.calculate_R(case.lam, case.blocks, J, case.planck2, case.lambda0, case.c0, case.doppler, case.gamma,
+                            case.sigma_bb_const, case.sigma_bf1, case.sigma_bf2, case.temperature, case.lte,
+                            case.hc_over_kB, case.pref_ij, case.pref_ji)
+        pops = orc.revised_populations(R, case.C, case.atom_density)
+        hist.append(diff)
+        i += 1
+    return J, S_new, pops, hist
+
+
+def test_oracle_lambda_iteration_is_well_posed(voro_small):
+    """The synthetic line case keeps the loop physical: finite fields, positive populations that sum
+    to the atom density, line-centre optical depths across the box above 10 and wing depths below 1,
+    and a contracting criterion."""
+    pos, nbr, bounds = voro_small
+    so = orc.make_sites(pos, nbr, bounds)
+    case = _lambda_case(pos, bounds, 11)
+    J, S, pops, hist = _oracle_lambda_iteration(case, so, "ul7n12.dat", 3)
+    assert np.isfinite(J).all() and np.isfinite(S).all() and (pops > 0).all()
+    assert np.allclose(pops.sum(axis=0), case.atom_density, rtol=1e-12)
+    assert hist[2] < hist[1] < hist[0]      # (hist[0] is 1/ε - 1 at the never-solved site perm_up[n], where J = 0)
+    assert np.abs(pops[1] / case.lte[1] - 1).max() > 1e-3          # the radiation field moved the populations
+    strength = case.strength_const * (case.lte[0] * case.Bij - case.lte[1] * case.Bji)
+    al = orc.line_opacity(orc.direction(180.0, 0.0), case.lam, case.lambda0, case.c0, case.velocity, case.doppler,
+                          case.gamma, strength, case.alpha_cont)
+    tau = al.mean(axis=0) * (bounds[1] - bounds[0])
+    assert tau[10] > 10 and tau[0] < 1 and tau[20] < 1
+
+
+@pytest.mark.gpu
+def test_gpu_lambda_voronoi_device_resident_loop(voro_small):
+    """vrt.Lambda_voronoi (opacity -> J -> S_new + criterion -> rates + populations, all on the device,
+    populations fed back into the opacity) against the same loop driven by the oracle."""
+    pos, nbr, bounds = voro_small
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    case = _lambda_case(pos, bounds, 11)
+    J, S, pops, hist = vrt.Lambda_voronoi(0.0, 4, hs, case, "ul7n12.dat")
+    J_ref, S_ref, pops_ref, hist_ref = _oracle_lambda_iteration(case, so, "ul7n12.dat", 4)
+    assert len(hist) == 4
+    assert np.abs(J - J_ref).max() < 1e-9 * np.abs(J_ref).max() and np.abs(S / S_ref - 1).max() < 1e-9   # (J = 0 at perm_up[n])
+    assert np.abs(pops / pops_ref - 1).max() < 1e-9
+    assert np.allclose(hist, hist_ref, rtol=1e-8)
+    # the convergence test stops it like the reference's criterion
+    J2, S2, pops2, hist2 = vrt.Lambda_voronoi(hist[1] * 1.0001, 10, hs, case, "ul7n12.dat")
+    assert len(hist2) == 2
+    assert np.abs(S2 / _oracle_lambda_iteration(case, so, "ul7n12.dat", 2)[1] - 1).max() < 1e-9
+    hs.close()
