@@ -546,6 +546,24 @@ def test_native_tessellation_matches_qhull_neighbour_sets(case):
                 assert (i + 1) in got[j - 1]
 
 
+@pytest.mark.parametrize("n, box, rel_h, seed", [
+    (300, (0.0, 1.0, 0.0, 3.0, 0.0, 0.5), None, 1003),        # anisotropic box only ~3 cells wide in y
+    (300, (0.0, 1.0, 0.0, 3.0, 0.0, 0.5), 0.3, 1007),
+    (1000, (0.0, 1.0, 0.0, 1.0, 0.0, 1.0), 0.15, 1008),       # top of the box almost empty: cells of half a period
+    (3000, (-0.5e6, 14.0e6, 0.0, 6.0e6, 0.0, 6.0e6), 0.15, 1002),
+])
+def test_native_tessellation_small_and_strongly_stratified(n, box, rel_h, seed):
+    """Cells that reach across a good part of a period (few sites, or a density scale height of a
+    seventh of the box): against Qhull on the point set extended by ALL eight periodic images
+    (margin > 1), 0 differing rows."""
+    H = None if rel_h is None else rel_h * (box[1] - box[0])
+    pos, _, bounds = synth.voronoi_grid(n, seed=seed, bounds=box, scale_height=H, margin=0.05)
+    ref = synth.voronoi_neighbours(pos, bounds, margin=1.01, shuffle_seed=None)
+    got, want = _rows_as_sets(vrt.voro(pos, bounds)), _rows_as_sets(ref)
+    wrong = [i for i in range(n) if got[i] != want[i]]
+    assert not wrong, (len(wrong), wrong[:5])
+
+
 def test_native_tessellation_feeds_read_cell(tmp_path):
     """voro -> "%i %n" text file -> read_cell: the file round trip reproduces the matrix, and the
     grid built from either has the same layers and permutations."""

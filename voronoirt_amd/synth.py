@@ -148,7 +148,11 @@ def voronoi_neighbours(positions: np.ndarray, bounds, margin: float = 0.3, shuff
     site in the augmented set is exactly the wall-cut cell voro++ reports, and a Delaunay edge
     to any bottom (top) mirror image is a face on the bottom (top) wall.  voro++ lists the faces
     of a cell in construction order, which is not reproducible here: rows are shuffled with
-    `shuffle_seed` (None keeps ascending ids).  `margin` must exceed a few cell diameters."""
+    `shuffle_seed` (None keeps ascending ids).  `margin` (fraction of the box whose sites get
+    periodic / mirror images) must exceed a few cell diameters: with few sites or a strongly
+    stratified density the sparse cells are larger than the default 0.3 and some of their neighbours
+    across the seam are missed (a valid neighbour graph for the solver tests, but not the exact
+    tessellation: `vrt.voro` is, see tests/test_host.py, which compares at margin > 1)."""
     from scipy.spatial import Delaunay
 
     base = np.ascontiguousarray(positions, dtype=np.float64)
