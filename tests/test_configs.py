@@ -300,8 +300,12 @@ def test_bench_two_ranks_weak_default(launcher):
     if launcher == "self":
         cmd = [sys.executable, bench, "--gpus", "2"] + args
     else:
+        import socket
+        with socket.socket() as sk:                           # a free port for the rendezvous
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-               "127.0.0.1", "--master-port", "29613", bench, "--gpus", "2"] + args
+               "127.0.0.1", "--master-port", str(port), bench, "--gpus", "2"] + args
     r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stderr[-2000:]
     lines = [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
