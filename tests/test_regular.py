@@ -192,3 +192,40 @@ def test_gpu_regular_rows_longer_than_the_workgroup(monkeypatch):
         f = orc.short_characteristics_up if ups[j] else orc.short_characteristics_down
         ref = f(ks[j], S, I0s[j], al, z, x, y, 3)
         assert np.abs(got[j] - ref).max() / np.abs(ref).max() < 1e-12
+
+
+# ---- analytic known answers that follow from the code (no reference run needed) ---------------------
+_KAT_ANGLES = ((170.0, 30.0), (100.0, 10.0), (100.0, 80.0), (10.0, 200.0), (80.0, 190.0), (80.0, 100.0))
+
+
+def _uniform_field_cases():
+    """(label, alpha) for a uniform source function S = I_0 = B on the random non-uniform grid:
+    * steep rays (xy planes): I = e I_u + a S_u + b S_c with a + b + e = 1 in every branch of
+      linear_weights (functions.jl:484-500) and bilinear weights that sum to 1 -> I == B for ANY α;
+    * every plane kind in the thick limit Δτ > 50: e = 0, a + b = 1 -> I == B whatever the carried
+      row of the yz / xz kernels holds."""
+    z, x, y, S, al, I0 = _random_problem(9, 12, 10, 4)
+    B = 2.75
+    S[:], I0[:] = B, B
+    thick = np.full_like(al, 5e4)                      # Δτ = r (α_c + α_u)/2 >> 50 on this grid
+    return z, x, y, S, I0, B, (("any", al), ("thick", thick))
+
+
+def _check_uniform(solve_up, solve_down, direction):
+    z, x, y, S, I0, B, cases = _uniform_field_cases()
+    for label, al in cases:
+        for theta, phi in _KAT_ANGLES:
+            if label == "any" and not (theta > 150 or theta < 30):
+                continue                               # inclined rays: only the thick limit is exact
+            f = solve_up if theta > 90 else solve_down
+            I = f(direction(theta, phi), S, I0, al, z, x, y, 3)
+            assert np.abs(I / B - 1).max() < 4e-15, (label, theta, phi)
+
+
+def test_oracle_uniform_field_stays_uniform():
+    _check_uniform(orc.short_characteristics_up, orc.short_characteristics_down, orc.direction)
+
+
+@pytest.mark.gpu
+def test_gpu_uniform_field_stays_uniform():
+    _check_uniform(vrt.short_characteristics_up, vrt.short_characteristics_down, vrt.direction)
