@@ -186,6 +186,22 @@ int vrt_layer_schedule(const vrt_grid *g, int dir, const int64_t *up, int n_swee
  * positions are sorted (stably) by visit pattern -- first, then second, ... visit level. */
 int vrt_layer_sorted_slots(const vrt_grid *g, int dir, const uint32_t *vis, int64_t *store, int64_t *self);
 
+/* Patch schedule of the fused layer kernel ("patches" path; introspection, host only): every BFS layer
+ * is cut into ranges of about `own_target` consecutive storage positions, and each range carries
+ * the in-layer dependency cone of its sites (own sites + a halo of neighbouring sites' visits it
+ * recomputes), at most `entry_cap` entries.  Step 1: counts[0..5] = patches, entries, visits
+ * executed over all patches, live visits of the unsplit schedule, largest entry count of a patch,
+ * layer offsets (= vrt_grid_num_layer_offsets + 1).  Step 2 (vrt_patch_schedule_get): layer_patch_off
+ * [counts[5]], patch_own_lo / patch_own_cnt / patch_nlev [patches], patch_ent_off [patches + 1],
+ * entry_pos (0-based storage position) / entry_vis / entry_loc [entries]; any pointer may be NULL. */
+typedef struct vrt_patch_schedule vrt_patch_schedule;
+int vrt_patch_schedule_build(const vrt_grid *g, int dir, const int64_t *up, int n_sweeps, int own_target,
+                             int entry_cap, vrt_patch_schedule **out, int64_t counts[6]);
+int vrt_patch_schedule_get(const vrt_patch_schedule *s, int32_t *layer_patch_off, int32_t *patch_own_lo,
+                           int32_t *patch_own_cnt, int32_t *patch_nlev, int64_t *patch_ent_off,
+                           int32_t *entry_pos, uint32_t *entry_vis, uint32_t *entry_loc);
+void vrt_patch_schedule_destroy(vrt_patch_schedule *s);
+
 /* ---- single solves: drop-in bodies for Delaunay_upII / Delaunay_downII --------------------
  * (src/irregular_ray_tracing.jl:15-20,96-101).  nI0 must equal layers[2]-1 of the direction.
  * The plan for k is cached inside the grid. */

@@ -29,7 +29,7 @@ def _valid_line_mask(so):
     return m
 
 
-@pytest.fixture(params=["tiles", "steps", "levels"])
+@pytest.fixture(params=["tiles", "steps", "levels", "patches"])
 def path(request, monkeypatch):
     """Both device paths: the LDS layer-tile kernel (default when the grid fits) and the
     one-launch-per-level kernels (general fallback)."""
@@ -452,10 +452,10 @@ def test_layers_of_8712_sites_run_on_the_single_wavelength_step_kernels(monkeypa
     hs.close()
 
 
-def test_layers_of_17298_sites_fp32_on_steps_fp64_on_levels(monkeypatch):
+def test_layers_of_17298_sites_fp32_on_steps_fp64_on_patches(monkeypatch):
     """17 298-site layers (C5's are 17 672): fp32 storage fits the single-wavelength step kernel
-    (float tile and coefficients, 18 sites per thread); fp64 does not (12 288) and must fall back to
-    the level path by itself, refusing VRT_PATH=steps."""
+    (float tile and coefficients, 18 sites per thread); fp64 does not (12 288) and runs on the fused
+    patch kernel by itself, refusing VRT_PATH=steps."""
     import torch
     monkeypatch.delenv("VRT_PATH", raising=False)
     hs, so, S, al, I0 = _large_layer_case(93, 6, 6)            # 2 * 93^2 = 17 298 sites per layer
@@ -474,7 +474,7 @@ def test_layers_of_17298_sites_fp32_on_steps_fp64_on_levels(monkeypatch):
     assert plan.last_path == "steps"
     assert _rel(Jd.cpu().numpy().astype(np.float64), ref) < 5e-6
     J, _ = plan.execute(S, al, weights=w, I0_up=I0)           # fp64: too large for the step kernels
-    assert plan.last_path == "levels"
+    assert plan.last_path == "patches"
     assert _rel(J, orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)) < RTOL
     monkeypatch.setenv("VRT_PATH", "steps")
     with pytest.raises(vrt.VrtError):
@@ -483,28 +483,54 @@ def test_layers_of_17298_sites_fp32_on_steps_fp64_on_levels(monkeypatch):
     hs.close()
 
 
-def test_layers_of_20000_sites_fall_back_to_the_level_kernels(monkeypatch):
-    """Beyond 18 432 sites per layer nothing holds a layer in one workgroup: both storage types run on
-    the general level path."""
+@pytest.mark.parametrize("a, nl", [(100, 4), (123, 3)])
+def test_layers_of_20000_and_30000_sites_run_on_the_patch_kernel(monkeypatch, a, nl):
+    """Beyond 18 432 sites per layer nothing holds a layer in one workgroup (the reference's
+    density-stratified grids have ~30 000-site layers at 1 M sites, src/sample_grids.jl:223-230):
+    the fused patch kernel cuts every layer into patches and solves each, with the halo of its
+    in-layer dependency cone, in a workgroup of its own.  fp64 and fp32 storage, against the oracle
+    and against the general level path; per-angle alpha in the native layout is accepted."""
     import torch
     monkeypatch.delenv("VRT_PATH", raising=False)
-    hs, so, S, al, I0 = _large_layer_case(100, 4, 7)           # 20 000 sites per layer
-    assert int(np.diff(so.layers_up).max()) == 20000
+    hs, so, S, al, I0 = _large_layer_case(a, nl, 7)
+    assert int(np.diff(so.layers_up).max()) == 2 * a * a
     n, nlam = so.n, S.shape[1]
     w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
     plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
     J, _ = plan.execute(S, al, weights=w, I0_up=I0)
-    assert plan.last_path == "levels"
+    assert plan.last_path == "patches"
     ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
     assert _rel(J, ref) < RTOL
+    monkeypatch.setenv("VRT_PATH", "levels")
+    J2, _ = plan.execute(S, al, weights=w, I0_up=I0)
+    assert plan.last_path == "levels" and _rel(J2, J) < 1e-13
+    monkeypatch.setenv("VRT_PATH", "steps")                   # no layer-step kernel holds such a layer
+    with pytest.raises(vrt.VrtError):
+        plan.execute(S, al, weights=w, I0_up=I0)
+    monkeypatch.delenv("VRT_PATH", raising=False)
     dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
     Sd, Ad, I0d = (torch.from_numpy(x.astype(np.float32)).to(dev).contiguous() for x in (S, al, I0))
     Jd = torch.zeros((n, nlam), dtype=torch.float32, device=dev)
     plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=Jd.data_ptr(),
-                     dI0_up=I0d.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, f32=True)
+                     dI0_up=I0d.data_ptr(), stream=st, f32=True)
     torch.cuda.synchronize()
-    assert plan.last_path == "levels"
+    assert plan.last_path == "patches"
     assert _rel(Jd.cpu().numpy().astype(np.float64), ref) < 5e-6
+    # per-angle alpha, caller layout -> native layout -> the same J bit for bit
+    al3 = np.stack([al * (1 + 0.05 * i) for i in range(nq)])
+    S64, A64, I064 = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (S, al3, I0))
+    Ja, Jn = torch.zeros((n, nlam), dtype=torch.float64, device=dev), torch.zeros((n, nlam), dtype=torch.float64, device=dev)
+    plan.execute_dev(nlam, nlam, S64.data_ptr(), A64.data_ptr(), _lib.ALPHA_ANGLE_SITE_LAM, w, dJ=Ja.data_ptr(),
+                     dI0_up=I064.data_ptr(), stream=st)
+    native = torch.empty(plan.native_alpha_count(nlam), dtype=torch.float64, device=dev)
+    plan.alpha_to_native_dev(nlam, nlam, A64.data_ptr(), native.data_ptr(), stream=st)
+    plan.execute_dev(nlam, nlam, S64.data_ptr(), native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE, w, dJ=Jn.data_ptr(),
+                     dI0_up=I064.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert plan.last_path == "patches" and torch.equal(Ja, Jn)
+    refa = orc.J_voronoi(w, th, ph, S[:, :2].copy(), al3[:, :, :2].copy(), so, I0_up=I0[:, :2].copy(), nthreads=8)
+    assert _rel(Ja[:, :2].cpu().numpy(), refa) < RTOL
     plan.close()
     hs.close()
 

@@ -16,7 +16,7 @@ import pytest
 import voronoirt_amd as vrt
 from oracle import oracle as orc
 from voronoirt_amd import _lib, distributed, synth
-from voronoirt_amd.api import build_layer_schedule, build_schedule
+from voronoirt_amd.api import build_patch_schedule, build_layer_schedule, build_schedule
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -317,6 +317,112 @@ def test_layer_tile_schedule_equals_serial_gauss_seidel(grid, bcc_small, voro_sm
     with pytest.raises(vrt.VrtError):     # 5 sweeps can need 5 visits: beyond the 4-slot encoding
         up, *_ = orc.upwind_table(so, orc.direction(109.7, 193.6))
         build_layer_schedule(hs, +1, up, 9)
+
+
+def _run_patches(so, hs, k, S, I0, alpha, dirn, n_sweeps, own, cap):
+    """numpy model of k_patch_solve (vrt_patch.hip): data in STORAGE order; every patch forms the
+    coefficients of its entries (own sites + halo), runs its levels on a private zero-initialised tile
+    and writes back the sites it owns.  Patches of a layer never see each other's results."""
+    up, dots, w, r, st = orc.upwind_table(so, k)
+    ps = build_patch_schedule(hs, dirn, up, n_sweeps, own, cap)
+    store = hs.storage_order(dirn) - 1
+    perm = so.perm_up if dirn > 0 else so.perm_down
+    lay = so.layers_up if dirn > 0 else so.layers_down
+    n = so.n
+    srank = np.empty(n, dtype=np.int64)
+    srank[store] = np.arange(n)
+    I = np.full(n, np.nan)
+    I[srank[perm[: lay[1] - 1] - 1]] = I0
+    lpo, eo = ps["layer_patch_off"], ps["patch_ent_off"]
+    assert ps["max_entries"] <= cap
+    covered = np.zeros(n, dtype=np.int32)
+    for layer in range(2, len(lay)):
+        lo, hi = lay[layer - 1] - 1, lay[layer] - 1
+        Inew = I.copy()
+        for q in range(lpo[layer], lpo[layer + 1]):
+            e0, e1 = eo[q], eo[q + 1]
+            ne = e1 - e0
+            pos = ps["entry_pos"][e0:e1].astype(np.int64)
+            olo, ocnt = ps["patch_own_lo"][q], ps["patch_own_cnt"][q]
+            assert np.array_equal(pos[:ocnt], np.arange(olo, olo + ocnt)) and lo <= olo and olo + ocnt <= hi
+            assert ((pos[ocnt:] >= lo) & (pos[ocnt:] < hi)).all() and np.unique(pos).size == ne
+            covered[olo:olo + ocnt] += 1
+            sites = store[pos]
+            s1, s2 = up[sites, 0] - 1, up[sites, 1] - 1
+            u1, u2 = srank[s1], srank[s2]
+            a1, b1, e1_ = _lw(r[sites, 0] * (alpha[sites] + alpha[s1]) / 2)
+            a2, b2, e2_ = _lw(r[sites, 1] * (alpha[sites] + alpha[s2]) / 2)
+            w1, w2 = w[sites, 0], w[sites, 1]
+            early1, in1 = u1 < lo, (u1 >= lo) & (u1 < hi)
+            early2, in2 = u2 < lo, (u2 >= lo) & (u2 < hi)
+            I1 = np.where(early1, I[np.minimum(u1, max(lo - 1, 0))], 0.0)     # the layer BEFORE this launch
+            I2 = np.where(early2, I[np.minimum(u2, max(lo - 1, 0))], 0.0)
+            assert not np.isnan(I1).any() and not np.isnan(I2).any()
+            t1 = np.where(early1, ((e1_ * I1 + a1 * S[s1]) + b1 * S[sites]) * w1, (a1 * S[s1] + b1 * S[sites]) * w1)
+            t2 = np.where(early2, ((e2_ * I2 + a2 * S[s2]) + b2 * S[sites]) * w2, (a2 * S[s2] + b2 * S[sites]) * w2)
+            c = t1 + t2
+            g1, g2 = np.where(in1, e1_ * w1, 0.0), np.where(in2, e2_ * w2, 0.0)
+            loc = ps["entry_loc"][e0:e1]
+            l1, l2 = (loc & 0xFFFF).astype(np.int64), (loc >> 16).astype(np.int64)
+            # a local slot names the upwind's entry; 0xFFFF only for upwinds outside the layer or the cone
+            has1, has2 = l1 != 0xFFFF, l2 != 0xFFFF
+            assert np.array_equal(pos[l1[has1]], u1[has1]) and np.array_equal(pos[l2[has2]], u2[has2])
+            assert in1[has1].all() and in2[has2].all()
+            l1, l2 = np.where(has1, l1, ne), np.where(has2, l2, ne)
+            tile = np.zeros(ne + 1)
+            v = ps["entry_vis"][e0:e1]
+            assert (v[:ocnt] != 0).all()
+            for t in range(1, ps["patch_nlev"][q] + 1):
+                hit = ((v & 0xFF) == t) | (((v >> 8) & 0xFF) == t) | (((v >> 16) & 0xFF) == t) | ((v >> 24) == t)
+                written = np.zeros(ne + 1, dtype=bool)
+                written[:ne][hit] = True
+                assert not (written[l1] & hit).any() and not (written[l2] & hit).any()
+                tile[:ne] = np.where(hit, c + g1 * tile[l1] + g2 * tile[l2], tile[:ne])
+            Inew[olo:olo + ocnt] = tile[:ocnt]
+        I = Inew
+    assert (covered[lay[1] - 1:n - 1] == 1).all() and (covered[:lay[1] - 1] == 0).all()
+    I[n - 1] = 0.0
+    out = np.empty(n)
+    out[store] = I
+    return out, ps
+
+
+@pytest.mark.parametrize("grid", ["bcc", "voronoi", "lattice"])
+def test_patch_schedule_equals_serial_gauss_seidel(grid, bcc_small, voro_small):
+    """The fused patch path: layers cut into patches of a few dozen sites, each with the in-layer
+    dependency cone of its sites as a halo; executing the patches independently reproduces the
+    reference's serial sweep -- and the unsplit layer schedule bit for bit."""
+    if grid == "lattice":
+        pos, nbr, bounds = synth.bcc_grid(6, 6, seed=3, permute_ids=False)
+    else:
+        pos, nbr, bounds = bcc_small if grid == "bcc" else voro_small
+    so = orc.make_sites(pos, nbr, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)
+    n = so.n
+    rng = np.random.default_rng(23)
+    S = 1 + rng.random(n)
+    alpha = 10 ** rng.uniform(-3, 3, n) / (bounds[3] - bounds[2]) * 10
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    halo = 0
+    for n_sweeps, own, cap in ((3, 24, 128), (3, 7, 128), (1, 40, 48), (2, 16, 4096), (4, 120, 160), (3, 60000, 65535)):
+        for t, p in list(zip(th, ph))[:: 1 if (n_sweeps, own) == (3, 24) else 5]:
+            k = orc.direction(t, p)
+            dirn = 1 if t > 90 else -1
+            lay = so.layers_up if dirn > 0 else so.layers_down
+            I0 = rng.random(lay[1] - 1)
+            ref = (orc.Delaunay_upII if dirn > 0 else orc.Delaunay_downII)(k, S, I0, alpha, so, n_sweeps)
+            got, ps = _run_patches(so, hs, k, S, I0, alpha, dirn, n_sweeps, own, min(cap, 65535))
+            assert np.allclose(got, ref, rtol=1e-10, atol=1e-300)
+            unsplit, nv = _run_layer_tiles(so, hs, k, S, I0, alpha, dirn, n_sweeps)
+            assert np.array_equal(got, unsplit)                 # same arithmetic on the same values
+            assert ps["live_visits"] == nv and ps["visits"] >= nv
+            if own >= 60000:                                    # one patch per layer: no halo at all
+                assert ps["visits"] == nv and ps["entries"] == n - (lay[1] - 1) - 1
+            halo += ps["entries"] - (n - (lay[1] - 1) - 1)
+    assert halo > 0                                              # the small patches did need halos
+    with pytest.raises(vrt.VrtError):     # the cone of a single site does not fit 4 entries
+        up, *_ = orc.upwind_table(so, orc.direction(109.7, 193.6))
+        build_patch_schedule(hs, +1, up, 3, 2, 4)
 
 
 def test_schedule_rejects_site_without_upwind(bcc_small):

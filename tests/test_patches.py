@@ -1,0 +1,153 @@
+"""GPU parity tests (-m gpu) of the fused patch kernel (voronoirt_amd/csrc/vrt_patch.hip, VRT_PATH=patches):
+layers cut into patches, each solved with the halo of its in-layer dependency cone by one workgroup.
+Against the oracle (1e-10, fp64), against the other device paths, over the kernel's launch shapes
+and with patches small enough that every layer of the test grids is split."""
+import numpy as np
+import pytest
+
+import voronoirt_amd as vrt
+from oracle import oracle as orc
+from voronoirt_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def grids(bcc_small, voro_small):
+    out = {}
+    for name, (pos, nbr, bounds) in (("bcc", bcc_small), ("voronoi", voro_small)):
+        out[name] = (vrt.VoronoiSites(pos, nbr, bounds, device=0), orc.make_sites(pos, nbr, bounds))
+    yield out
+    for hs, _ in out.values():
+        hs.close()
+
+
+def _case(so, nlam, seed, per_angle=0):
+    rng = np.random.default_rng(seed)
+    n = so.n
+    S = 1 + rng.random((n, nlam))
+    al = 10 ** rng.uniform(-3, 3, (n, 1)) * (1 + rng.random((n, nlam))) * 10 / (so.bounds[3] - so.bounds[2])
+    if per_angle:
+        al = np.stack([al * (1 + 0.1 * rng.random((n, nlam))) for _ in range(per_angle)])
+    I0u = rng.random((so.layers_up[1] - 1, nlam))
+    I0d = rng.random((so.layers_down[1] - 1, nlam))
+    return S, al, I0u, I0d
+
+
+@pytest.mark.parametrize("name", ["bcc", "voronoi"])
+@pytest.mark.parametrize("own", [0, 40, 150])
+@pytest.mark.parametrize("nlam", [1, 4, 7])
+def test_patches_J_matches_oracle_and_steps(grids, name, own, nlam, monkeypatch):
+    """J of ul7n12 x nlam wavelengths: default patch size (one or two patches per layer here) and patches
+    of ~40 / ~150 sites (every layer split, halos everywhere); shared and per-angle alpha; up AND down
+    boundary intensities.  Equal to the oracle at 1e-10 and to the layer-step path at rounding level."""
+    hs, so = grids[name]
+    if own:
+        monkeypatch.setenv("VRT_PATCH_OWN", str(own))
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
+    for per_angle in (0, nq):
+        S, al, I0u, I0d = _case(so, nlam, 3 + nlam, per_angle)
+        monkeypatch.setenv("VRT_PATH", "patches")
+        J, I = plan.execute(S, al, weights=w, I0_up=I0u, I0_down=I0d, want_I=True)
+        assert plan.last_path == "patches"
+        ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0u, I0_down=I0d, nthreads=4)
+        assert _rel(J, ref) < RTOL
+        monkeypatch.setenv("VRT_PATH", "steps")
+        J2, I2 = plan.execute(S, al, weights=w, I0_up=I0u, I0_down=I0d, want_I=True)
+        assert plan.last_path == "steps"
+        assert _rel(I, I2) < 1e-13 and _rel(J, J2) < 1e-13
+        # the never-visited last site of each direction keeps I = 0 (voronoi_utils.jl:266)
+        for a_i in range(nq):
+            last = (so.perm_up if th[a_i] > 90 else so.perm_down)[-1] - 1
+            assert (I[a_i, last] == 0.0).all()
+    plan.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 512), (1, 2, 512), (1, 4, 512), (2, 1, 512), (2, 2, 512), (4, 1, 512),
+                                   (1, 2, 1024), (1, 4, 1024), (2, 1, 256), (2, 2, 256), (4, 1, 256)])
+@pytest.mark.parametrize("f32", [False, True])
+def test_every_patch_kernel_instantiation(grids, shape, f32, monkeypatch):
+    """Every (entries per thread, wavelength pairs, threads) instantiation of k_patch_solve, fp64 and fp32
+    storage: same results (fp64: to rounding; fp32: 5e-6 against the fp64 oracle on the rounded inputs)."""
+    import torch
+    hs, so = grids["voronoi"]
+    K, Q, NT = shape
+    monkeypatch.setenv("VRT_PATCH_K", str(K))
+    monkeypatch.setenv("VRT_PATCH_Q", str(Q))
+    monkeypatch.setenv("VRT_PATCH_NT", str(NT))
+    monkeypatch.setenv("VRT_PATCH_OWN", "90")
+    monkeypatch.setenv("VRT_PATH", "patches")
+    n, nlam = so.n, 9
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
+    S, al, I0u, I0d = _case(so, nlam, 41)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    dt, npdt = (torch.float32, np.float32) if f32 else (torch.float64, np.float64)
+    Sd, Ad, Ud, Dd = (torch.from_numpy(x.astype(npdt)).to(dev).contiguous() for x in (S, al, I0u, I0d))
+    Jd = torch.zeros((n, nlam), dtype=dt, device=dev)
+    plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=Jd.data_ptr(),
+                     dI0_up=Ud.data_ptr(), dI0_down=Dd.data_ptr(), stream=st, f32=f32)
+    torch.cuda.synchronize()
+    assert plan.last_path == "patches"
+    r = lambda x: x.astype(npdt).astype(np.float64)
+    ref = orc.J_voronoi(w, th, ph, r(S), r(al), so, I0_up=r(I0u), I0_down=r(I0d), nthreads=4)
+    assert _rel(Jd.cpu().numpy().astype(np.float64), ref) < (5e-6 if f32 else RTOL)
+    plan.close()
+
+
+def test_patches_single_solves_and_sweep_counts(grids, monkeypatch):
+    """Delaunay_upII / Delaunay_downII (one problem, one wavelength) and n_sweeps 1, 2, 4 on the patch path."""
+    monkeypatch.setenv("VRT_PATH", "patches")
+    monkeypatch.setenv("VRT_PATCH_OWN", "64")
+    hs, so = grids["bcc"]
+    n = so.n
+    rng = np.random.default_rng(5)
+    S = 1 + rng.random(n)
+    alpha = 10 ** rng.uniform(-3, 3, n) / (so.bounds[3] - so.bounds[2]) * 10
+    for n_sweeps in (1, 2, 3, 4):
+        for t, p in ((109.7, 193.6), (70.3, 346.4), (152.7, 315.5)):
+            k = vrt.direction(t, p)
+            if t > 90:
+                I0 = rng.random(so.layers_up[1] - 1)
+                got = vrt.Delaunay_upII(k, S, I0, alpha, hs, n_sweeps)
+                ref = orc.Delaunay_upII(k, S, I0, alpha, so, n_sweeps)
+            else:
+                I0 = rng.random(so.layers_down[1] - 1)
+                got = vrt.Delaunay_downII(k, S, I0, alpha, hs, n_sweeps)
+                ref = orc.Delaunay_downII(k, S, I0, alpha, so, n_sweeps)
+            assert _rel(got, ref) < RTOL, (n_sweeps, t)
+
+
+def test_patches_on_a_tessellated_stratified_grid(monkeypatch):
+    """vrt.voro (the in-process tessellation, rt_preprocessing/output_sites.cc:35-49) -> VoronoiSites ->
+    J on the patch path: 20 000 density-stratified sites (src/sample_grids.jl:223-230)."""
+    monkeypatch.setenv("VRT_PATH", "patches")
+    monkeypatch.setenv("VRT_PATCH_OWN", "300")
+    n = 20000
+    bounds = (-0.5e6, 14.0e6, 0.0, 6.0e6, 0.0, 6.0e6)
+    rng = np.random.default_rng(4)
+    u = rng.random(n)
+    Lz, H = bounds[1] - bounds[0], 2.0e6
+    pos = np.stack([bounds[0] - H * np.log(1.0 - u * (1.0 - np.exp(-Lz / H))),
+                    bounds[2] + rng.random(n) * (bounds[3] - bounds[2]),
+                    bounds[4] + rng.random(n) * (bounds[5] - bounds[4])], axis=1)
+    nbr = vrt.voro(pos, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    nlam = 6
+    S, al = synth.synthetic_fields(pos, bounds, nlam, seed=9)
+    I0 = S[so.perm_up[: so.layers_up[1] - 1] - 1]
+    J = vrt.J_lambda_voronoi(S, al, hs, "ul7n12.dat", I0_up=I0)
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
+    assert _rel(J, ref) < RTOL
+    assert list(hs._plans.values())[0].last_path == "patches"
+    hs.close()

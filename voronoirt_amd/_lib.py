@@ -74,6 +74,11 @@ PROTOTYPES = {
     "vrt_layer_schedule": (ctypes.c_int, [vp, ctypes.c_int, p_i64, ctypes.c_int,
                                           ctypes.POINTER(ctypes.c_uint32), p_i32, p_i64]),
     "vrt_layer_sorted_slots": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), p_i64, p_i64]),
+    "vrt_patch_schedule_build": (ctypes.c_int, [vp, ctypes.c_int, p_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(vp), p_i64]),
+    "vrt_patch_schedule_get": (ctypes.c_int, [vp, p_i32, p_i32, p_i32, p_i32, p_i64, p_i32,
+                                              ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
+    "vrt_patch_schedule_destroy": (None, [vp]),
     "vrt_lambda_update_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp, vp, vp, p_dbl, vp]),
     "vrt_short_characteristics": (ctypes.c_int, [c_i64, c_i64, c_i64, p_dbl, p_dbl, p_dbl, c_i64, p_dbl,
                                                  p_int, p_dbl, c_i64, p_dbl, c_i64, p_dbl, ctypes.c_int,

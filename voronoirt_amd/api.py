@@ -301,7 +301,7 @@ class FormalPlan:
     @property
     def last_path(self) -> str:
         """Device path of the last execute: "levels", "tiles" or "steps" ("" before the first)."""
-        return {0: "", 1: "levels", 2: "tiles", 3: "steps"}[int(_lib.load().vrt_plan_last_path(self._h))]
+        return {0: "", 1: "levels", 2: "tiles", 3: "steps", 4: "patches"}[int(_lib.load().vrt_plan_last_path(self._h))]
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -398,6 +398,36 @@ def build_layer_schedule(sites: VoronoiSites, dir: int, up, n_sweeps: int = 3):
                                vis.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
                                nlev.ctypes.data_as(_lib.p_i32), ctypes.byref(nv)))
     return vis, nlev, nv.value
+
+
+def build_patch_schedule(sites: VoronoiSites, dir: int, up, n_sweeps: int = 3, own_target: int = 768,
+                         entry_cap: int = 1024) -> dict:
+    """Patch schedule of the fused layer kernel (introspection, host only): layers cut into ranges of
+    consecutive storage positions, each with its in-layer dependency cone (own sites + halo).
+    Returns a dict of numpy arrays (see vrt_patch_schedule_get) plus the counts."""
+    L = _lib.load()
+    up = np.ascontiguousarray(up, dtype=np.int64)
+    h = ctypes.c_void_p()
+    cnt = np.zeros(6, dtype=np.int64)
+    check(L.vrt_patch_schedule_build(sites.handle, int(dir), _i(up), int(n_sweeps), int(own_target), int(entry_cap),
+                                     ctypes.byref(h), _i(cnt)))
+    try:
+        P, E = int(cnt[0]), int(cnt[1])
+        out = {"layer_patch_off": np.zeros(int(cnt[5]), dtype=np.int32), "patch_own_lo": np.zeros(P, dtype=np.int32),
+               "patch_own_cnt": np.zeros(P, dtype=np.int32), "patch_nlev": np.zeros(P, dtype=np.int32),
+               "patch_ent_off": np.zeros(P + 1, dtype=np.int64), "entry_pos": np.zeros(E, dtype=np.int32),
+               "entry_vis": np.zeros(E, dtype=np.uint32), "entry_loc": np.zeros(E, dtype=np.uint32)}
+        u32 = ctypes.POINTER(ctypes.c_uint32)
+        check(L.vrt_patch_schedule_get(h, out["layer_patch_off"].ctypes.data_as(_lib.p_i32),
+                                       out["patch_own_lo"].ctypes.data_as(_lib.p_i32),
+                                       out["patch_own_cnt"].ctypes.data_as(_lib.p_i32),
+                                       out["patch_nlev"].ctypes.data_as(_lib.p_i32), _i(out["patch_ent_off"]),
+                                       out["entry_pos"].ctypes.data_as(_lib.p_i32),
+                                       out["entry_vis"].ctypes.data_as(u32), out["entry_loc"].ctypes.data_as(u32)))
+    finally:
+        L.vrt_patch_schedule_destroy(h)
+    out.update(patches=P, entries=E, visits=int(cnt[2]), live_visits=int(cnt[3]), max_entries=int(cnt[4]))
+    return out
 
 
 def layer_sorted_slots(sites: VoronoiSites, dir: int, vis):
@@ -561,7 +591,7 @@ def Lambda_voronoi(eps_conv: float, maxiter: int, sites: VoronoiSites, case: Lin
     I0_up = d_B[bottom].contiguous()                           # B_λ(λ_l, T) of the bottom layer, :99-101
     st = torch.cuda.current_stream().cuda_stream
     history = []
-    diff, i = float("inf"), 0
+    diff, i = 1.0, 0                                           # criterion(S_new = B, S_old = 0) = |1 - 0/B| = 1
     try:
         while diff > eps_conv and i < maxiter:                 # criterion, :325-349
             S_old.copy_(S_new)
@@ -581,6 +611,9 @@ def Lambda_voronoi(eps_conv: float, maxiter: int, sites: VoronoiSites, case: Lin
             pops = new_pops
             history.append(diff)
             i += 1
+            if diff != diff:                                   # the reference prints "NaN DIFF!" (:336-338); its
+                import warnings                                # NaN diff then ends the loop (NaN > ϵ is false)
+                warnings.warn(f"Lambda_voronoi: NaN DIFF! at iteration {i} -- stopping, results are not converged")
         torch.cuda.synchronize()
         return J.cpu().numpy(), S_new.cpu().numpy(), pops.cpu().numpy(), history
     finally:

@@ -77,6 +77,8 @@ static void free_grid(vrt_grid *g)
     dev_free(g->d_scalars);
     dev_free(g->d_small);
     if (g->small_ev) (void)hipEventDestroy(g->small_ev);
+    if (g->small_copy_ev) (void)hipEventDestroy(g->small_copy_ev);
+    if (g->h_small) (void)hipHostFree(g->h_small);
     dev_free(g->up.d_store);
     dev_free(g->down.d_store);
     dev_free(g->up.d_srank);
@@ -186,6 +188,9 @@ static void free_plan(vrt_plan *p)
     for (int i = 0; i < 2; i++) dev_free(p->ws_cg[i]);
     dev_free(p->d_step_angles);
     dev_free(p->d_level_map);
+    dev_free(p->d_patch_rec); dev_free(p->d_patch_rec2); dev_free(p->d_patch_work);
+    dev_free(p->e_pos); dev_free(p->e_u1); dev_free(p->e_u2); dev_free(p->e_vis); dev_free(p->e_loc);
+    dev_free(p->e_w1); dev_free(p->e_w2); dev_free(p->e_r1); dev_free(p->e_r2);
     if (p->step_fork) (void)hipEventDestroy(p->step_fork);
     for (int i = 0; i < 4; i++) {
         if (p->step_join[i]) (void)hipEventDestroy(p->step_join[i]);
@@ -368,6 +373,26 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
     p->h_up2.swap(up2);
     std::vector<LayerSchedule> lsched((size_t)A);
     std::vector<std::vector<int32_t>> sorted_self((size_t)A);   // thread assignment of k_step_levels
+    std::vector<PatchSchedule> psched((size_t)A);                // fused patch path (vrt_patch.cpp)
+    {
+        // shape of the patch kernel: K entries per thread x NT threads = largest dependency cone of a
+        // patch, Q wavelength pairs per workgroup; tuning knobs read ONCE, here
+        auto env_int = [](const char *name, int dflt) {
+            const char *e = std::getenv(name);
+            return e && *e ? std::atoi(e) : dflt;
+        };
+        p->patch_K = env_int("VRT_PATCH_K", 1);
+        p->patch_NT = env_int("VRT_PATCH_NT", 1024);
+        p->patch_Q = env_int("VRT_PATCH_Q", 2);
+        if (!patch_shape_exists(p->patch_K, p->patch_Q, p->patch_NT)) {
+            p->patch_K = 1; p->patch_NT = 1024; p->patch_Q = 2;
+        }
+        p->patch_cap = p->patch_K * p->patch_NT;
+    }
+    const int patch_own = std::max(1, std::min(p->patch_cap, [&]() {
+        const char *e = std::getenv("VRT_PATCH_OWN");
+        return e && *e ? std::atoi(e) : p->patch_cap * 3 / 4;
+    }()));
     {
         unsigned hw = std::thread::hardware_concurrency();
         int nthr = (int)std::min<unsigned>(hw ? hw : 4, 16);
@@ -380,8 +405,12 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                     build_layer_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
                                          p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n,
                                          lsched[(size_t)a]);
-                    if (lsched[(size_t)a].ok)
+                    if (lsched[(size_t)a].ok) {
                         build_sorted_slots(up ? g->up : g->down, n, lsched[(size_t)a].vis, sorted_self[(size_t)a]);
+                        build_patch_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
+                                             p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n,
+                                             patch_own, p->patch_cap, psched[(size_t)a]);
+                    }
                 }
             });
         for (auto &th : pool) th.join();
@@ -406,7 +435,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         VRT_HIP_TRY_FREE(hipMemcpy(p->d_angles_up, ups.data(), sizeof(int32_t) * ups.size(), hipMemcpyHostToDevice));
     if (!downs.empty())
         VRT_HIP_TRY_FREE(hipMemcpy(p->d_angles_down, downs.data(), sizeof(int32_t) * downs.size(), hipMemcpyHostToDevice));
-    // ---- layer-tile path: tables in sweep order + per-layer level counts ---------------------
+    // ---- layer paths: tables in storage order, per-layer level counts, patch schedules -------------
     {
         bool ok = A > 0;
         int64_t max_layer = 0, visits = 0;
@@ -415,15 +444,28 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             max_layer = std::max(max_layer, lsched[(size_t)a].max_layer_size);
             visits += lsched[(size_t)a].n_visits;
         }
+        // the boundary layer is a layer too: k_sweep_tiles_pre keeps it in LDS as the first "previous" layer
+        if (p->n_up > 0) max_layer = std::max(max_layer, g->up.n1);
+        if (p->n_down > 0) max_layer = std::max(max_layer, g->down.n1);
+        if (n >= ((int64_t)1 << 28)) ok = false;  // the layer kernels index 16-byte pair planes with 32-bit byte offsets
         // the layer-step level kernels hold a whole layer per workgroup: 8192 sites as fp64 wavelength
-        // pairs, 12 288 as fp64 single wavelengths, 18 432 as fp32 ones (vrt_tiles.hip)
-        if (max_layer > steps_max_layer(/*f32=*/true)) ok = false;
-        if (n >= ((int64_t)1 << 28)) ok = false;  // the tile kernels index 16-byte pair planes with 32-bit byte offsets
-        p->tile_ok = ok;
+        // pairs, 12 288 as fp64 single wavelengths, 18 432 as fp32 ones (vrt_tiles.hip); the fused
+        // patch kernel (vrt_patch.hip) has no such limit
+        const bool tile_ok = ok && max_layer <= steps_max_layer(/*f32=*/true);
+        bool patch_ok = ok;
+        int64_t n_patches = 0, n_entries = 0;
+        for (int a = 0; a < A && patch_ok; a++) {
+            patch_ok = psched[(size_t)a].ok;
+            n_patches += (int64_t)psched[(size_t)a].patch_own_lo.size();
+            n_entries += (int64_t)psched[(size_t)a].entry_pos.size();
+        }
+        if (n_entries >= ((int64_t)1 << 31) - 1 || n_patches >= ((int64_t)1 << 31) - 1) patch_ok = false;
+        p->tile_ok = tile_ok;
+        p->patch_ok = patch_ok;
         p->tile_max_layer_size = max_layer;
         p->tile_visits = visits;
         p->tile_K = max_layer <= 2048 ? 2 : max_layer <= 4096 ? 4 : 8;
-        if (ok) {
+        if (tile_ok || patch_ok) {
             VRT_TRY_FREE(dev_alloc(&p->t_u1, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_u2, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_w1, tab));
@@ -432,30 +474,76 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             VRT_TRY_FREE(dev_alloc(&p->t_r2, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_vis, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_loc, tab));
-            VRT_TRY_FREE(dev_alloc(&p->t_self, tab));
-            VRT_TRY_FREE(dev_alloc(&p->t_vis_s, tab));
-            VRT_TRY_FREE(dev_alloc(&p->t_loc_s, tab));
-            VRT_TRY_FREE(dev_alloc(&p->t_gpos, tab));
-            VRT_TRY_FREE(dev_alloc(&p->t_rank_s, tab));
-            VRT_TRY_FREE(dev_alloc(&p->t_loc_ss, tab));
-            if (max_layer <= 4096) VRT_TRY_FREE(dev_alloc(&p->t_code_ss, tab));
-            uint32_t *d_vis_site = nullptr;
-            VRT_TRY_FREE(dev_alloc(&d_vis_site, (size_t)n));
+            if (tile_ok) {
+                VRT_TRY_FREE(dev_alloc(&p->t_self, tab));
+                VRT_TRY_FREE(dev_alloc(&p->t_vis_s, tab));
+                VRT_TRY_FREE(dev_alloc(&p->t_loc_s, tab));
+                VRT_TRY_FREE(dev_alloc(&p->t_gpos, tab));
+                VRT_TRY_FREE(dev_alloc(&p->t_rank_s, tab));
+                VRT_TRY_FREE(dev_alloc(&p->t_loc_ss, tab));
+                if (max_layer <= 4096) VRT_TRY_FREE(dev_alloc(&p->t_code_ss, tab));
+            }
             const int maxL = (int)std::max(g->up.reduced.size(), g->down.reduced.size()) - 1;
             p->tile_max_layers = maxL;
+            if (patch_ok) {
+                const size_t ne = (size_t)n_entries;
+                VRT_TRY_FREE(dev_alloc(&p->e_pos, ne));
+                VRT_TRY_FREE(dev_alloc(&p->e_u1, ne));
+                VRT_TRY_FREE(dev_alloc(&p->e_u2, ne));
+                VRT_TRY_FREE(dev_alloc(&p->e_vis, ne));
+                VRT_TRY_FREE(dev_alloc(&p->e_loc, ne));
+                VRT_TRY_FREE(dev_alloc(&p->e_w1, ne));
+                VRT_TRY_FREE(dev_alloc(&p->e_w2, ne));
+                VRT_TRY_FREE(dev_alloc(&p->e_r1, ne));
+                VRT_TRY_FREE(dev_alloc(&p->e_r2, ne));
+                VRT_TRY_FREE(dev_alloc(&p->d_patch_rec, (size_t)n_patches));
+                VRT_TRY_FREE(dev_alloc(&p->d_patch_rec2, (size_t)n_patches));
+                p->h_patch_first.assign((size_t)A * (size_t)(maxL + 2), 0);
+                p->h_patch_rec.reserve((size_t)n_patches);
+                p->n_patches = n_patches;
+                p->n_patch_entries = n_entries;
+            }
+            uint32_t *d_vis_site = nullptr;
+            VRT_TRY_FREE(dev_alloc(&d_vis_site, (size_t)n));
             std::vector<int32_t> nlev((size_t)A * (size_t)(maxL + 1), 0), adir((size_t)A);
+            std::vector<int2> rec2;
             p->angle_visits.assign((size_t)A, 0);
+            int64_t ent_base = 0;
             for (int a = 0; a < A; a++) {
                 hipError_t e = hipMemcpy(d_vis_site, lsched[(size_t)a].vis.data(), sizeof(uint32_t) * n,
                                          hipMemcpyHostToDevice);
                 int rc2 = e == hipSuccess ? launch_permute_table(p, a, d_vis_site) : VRT_ENODEVICE;
-                if (!rc2) {     // sorted thread assignment of the layer-step level kernel
+                if (!rc2 && tile_ok) {     // sorted thread assignment of the layer-step level kernel
                     if (hipMemcpy(p->t_self + (size_t)a * n, sorted_self[(size_t)a].data(), sizeof(int32_t) * n,
                                   hipMemcpyHostToDevice) != hipSuccess)
                         rc2 = VRT_ENODEVICE;
-                    std::vector<int32_t>().swap(sorted_self[(size_t)a]);
                     if (!rc2) rc2 = launch_sorted_tables(p, a);
                     if (!rc2) rc2 = launch_gpos(p, a);
+                }
+                std::vector<int32_t>().swap(sorted_self[(size_t)a]);
+                if (!rc2 && patch_ok) {    // patch records + entry tables of this angle
+                    PatchSchedule &ps = psched[(size_t)a];
+                    const size_t np_a = ps.patch_own_lo.size(), ne_a = ps.entry_pos.size();
+                    const int32_t pbase = (int32_t)p->h_patch_rec.size();
+                    int32_t *first = p->h_patch_first.data() + (size_t)a * (size_t)(maxL + 2);
+                    for (int l = 0; l <= maxL + 1; l++)
+                        first[l] = pbase + ps.layer_patch_off[std::min<size_t>((size_t)l, ps.layer_patch_off.size() - 1)];
+                    for (size_t q = 0; q < np_a; q++) {
+                        p->h_patch_rec.push_back(make_int4((int)(ent_base + ps.patch_ent_off[q]),
+                                                           (int)(ps.patch_ent_off[q + 1] - ps.patch_ent_off[q]),
+                                                           ps.patch_own_lo[q], ps.patch_own_cnt[q]));
+                        rec2.push_back(make_int2(ps.patch_nlev[q], a));
+                    }
+                    if (ne_a) {
+                        if (hipMemcpy(p->e_pos + ent_base, ps.entry_pos.data(), sizeof(int32_t) * ne_a, hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemcpy(p->e_vis + ent_base, ps.entry_vis.data(), sizeof(uint32_t) * ne_a, hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemcpy(p->e_loc + ent_base, ps.entry_loc.data(), sizeof(uint32_t) * ne_a, hipMemcpyHostToDevice) != hipSuccess)
+                            rc2 = VRT_ENODEVICE;
+                        if (!rc2) rc2 = launch_patch_entries(p, a, ent_base, (int64_t)ne_a);
+                    }
+                    ent_base += (int64_t)ne_a;
+                    p->n_patch_visits += ps.n_visits;
+                    ps = PatchSchedule();
                 }
                 if (!rc2 && hipStreamSynchronize(g->stream) != hipSuccess) rc2 = VRT_ENODEVICE;
                 if (rc2) {
@@ -480,6 +568,10 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             VRT_TRY_FREE(dev_alloc(&p->d_angle_dir, (size_t)A));
             VRT_HIP_TRY_FREE(hipMemcpy(p->d_nlev, nlev.data(), sizeof(int32_t) * nlev.size(), hipMemcpyHostToDevice));
             VRT_HIP_TRY_FREE(hipMemcpy(p->d_angle_dir, adir.data(), sizeof(int32_t) * A, hipMemcpyHostToDevice));
+            if (patch_ok && n_patches) {
+                VRT_HIP_TRY_FREE(hipMemcpy(p->d_patch_rec, p->h_patch_rec.data(), sizeof(int4) * (size_t)n_patches, hipMemcpyHostToDevice));
+                VRT_HIP_TRY_FREE(hipMemcpy(p->d_patch_rec2, rec2.data(), sizeof(int2) * (size_t)n_patches, hipMemcpyHostToDevice));
+            }
         }
     }
 #undef VRT_TRY_FREE
@@ -519,8 +611,8 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
     if (alpha_mode == VRT_ALPHA_ANGLE_SITE_LAM && p->A != (int)p->n_angles_user)
         return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
     const bool steps_ok = p->tile_ok && p->tile_max_layer_size <= steps_max_layer(f32);
-    if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && (f32 || !steps_ok))
-        return fail(VRT_EINVAL, "native-layout alpha needs the fp64 layer-step path (layers <= 12288 sites)");
+    if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && !(p->patch_ok || (steps_ok && !f32)))
+        return fail(VRT_EINVAL, "native-layout alpha needs a layer path (at most 4 visits per site and 255 levels per layer)");
     {
         // Three device paths produce the same results:
         //   "levels"  one launch per dependency level over all angles; any grid;
@@ -540,13 +632,18 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         int path = 1;
         if (steps_ok)
             path = (tiles_ok && (int64_t)p->A * nlam <= 256 && p->tile_max_layer_size <= 4096) ? 2 : 3;
+        else if (p->patch_ok)
+            path = 4;
         if (force && std::strcmp(force, "levels") == 0) path = 1;
         if (force && std::strcmp(force, "tiles") == 0) path = 2;
         if (force && std::strcmp(force, "steps") == 0) path = 3;
-        if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE) path = 3;    // the layout IS the layer-step path's
+        if (force && std::strcmp(force, "patches") == 0) path = 4;
+        // the native layout IS the storage order of the layer paths
+        if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && path != 3 && path != 4) path = (steps_ok && !f32) ? 3 : 4;
+        if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && path == 3 && (f32 || !steps_ok)) path = 4;
         if (p->A == 0) path = 1;      // nothing to solve (every direction skipped): J = 0 via the level path
-        if ((path == 3 && !steps_ok) || (path == 2 && !tiles_ok))
-            return fail(VRT_EINVAL, "VRT_PATH=tiles/steps but the grid (or the fp32 storage type) does not fit those kernels");
+        if ((path == 3 && !steps_ok) || (path == 2 && !tiles_ok) || (path == 4 && !p->patch_ok))
+            return fail(VRT_EINVAL, "VRT_PATH=tiles/steps/patches but the grid (or the fp32 storage type) does not fit those kernels");
         if (path != 1) {
             p->last_path = path;
             return execute_tiles(p, nlam, ld, dS_, dalpha_, alpha_mode, dI0_up_, dI0_down_, weights, dJ_,
@@ -948,6 +1045,70 @@ int vrt_layer_sorted_slots(const vrt_grid *g, int dir, const uint32_t *vis, int6
     }
 }
 
+struct vrt_patch_schedule {
+    vrt::PatchSchedule s;
+};
+
+int vrt_patch_schedule_build(const vrt_grid *g, int dir, const int64_t *up, int n_sweeps, int own_target,
+                             int entry_cap, vrt_patch_schedule **out, int64_t counts[6])
+{
+    if (!g || !up || !out || !counts) return fail(VRT_EINVAL, "NULL argument");
+    if (n_sweeps < 1 || own_target < 1 || entry_cap < own_target || entry_cap > 65535)
+        return fail(VRT_EINVAL, "need n_sweeps >= 1 and 1 <= own_target <= entry_cap <= 65535");
+    *out = nullptr;
+    try {
+        const int64_t n = g->n;
+        std::vector<int32_t> u1((size_t)n), u2((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t a = up[2 * i], b = up[2 * i + 1];
+            if (a > n || b > n) return fail(VRT_EINVAL, "upwind id out of range");
+            u1[(size_t)i] = a >= 1 ? (int32_t)(a - 1) : kNoUpwind;
+            u2[(size_t)i] = b >= 1 ? (int32_t)(b - 1) : kNoUpwind;
+        }
+        vrt_patch_schedule *ps = new vrt_patch_schedule();
+        build_patch_schedule(direction_of(g, dir), dir > 0, n, n_sweeps, u1.data(), u2.data(), own_target, entry_cap,
+                             ps->s);
+        if (ps->s.bad_site >= 0) {
+            const std::string msg = "site " + std::to_string(ps->s.bad_site + 1) + " has no upwind neighbour";
+            delete ps;
+            return fail(VRT_EGRID, msg);
+        }
+        if (!ps->s.ok) {
+            delete ps;
+            return fail(VRT_EINVAL, "schedule does not fit the packed patch encoding");
+        }
+        counts[0] = (int64_t)ps->s.patch_own_lo.size();
+        counts[1] = (int64_t)ps->s.entry_pos.size();
+        counts[2] = ps->s.n_visits;
+        counts[3] = ps->s.n_live;
+        counts[4] = ps->s.max_entries;
+        counts[5] = (int64_t)ps->s.layer_patch_off.size();
+        *out = ps;
+        return VRT_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    }
+}
+
+int vrt_patch_schedule_get(const vrt_patch_schedule *s, int32_t *layer_patch_off, int32_t *patch_own_lo,
+                           int32_t *patch_own_cnt, int32_t *patch_nlev, int64_t *patch_ent_off,
+                           int32_t *entry_pos, uint32_t *entry_vis, uint32_t *entry_loc)
+{
+    if (!s) return fail(VRT_EINVAL, "NULL schedule");
+    const PatchSchedule &p = s->s;
+    if (layer_patch_off) std::copy(p.layer_patch_off.begin(), p.layer_patch_off.end(), layer_patch_off);
+    if (patch_own_lo) std::copy(p.patch_own_lo.begin(), p.patch_own_lo.end(), patch_own_lo);
+    if (patch_own_cnt) std::copy(p.patch_own_cnt.begin(), p.patch_own_cnt.end(), patch_own_cnt);
+    if (patch_nlev) std::copy(p.patch_nlev.begin(), p.patch_nlev.end(), patch_nlev);
+    if (patch_ent_off) std::copy(p.patch_ent_off.begin(), p.patch_ent_off.end(), patch_ent_off);
+    if (entry_pos) std::copy(p.entry_pos.begin(), p.entry_pos.end(), entry_pos);
+    if (entry_vis) std::copy(p.entry_vis.begin(), p.entry_vis.end(), entry_vis);
+    if (entry_loc) std::copy(p.entry_loc.begin(), p.entry_loc.end(), entry_loc);
+    return VRT_OK;
+}
+
+void vrt_patch_schedule_destroy(vrt_patch_schedule *s) { delete s; }
+
 int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out)
 {
     if (!g || !out) return fail(VRT_EINVAL, "NULL argument");
@@ -1118,22 +1279,29 @@ int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *d
 
 // wavelength-sized host arrays -> the grid's device scratch (caller holds g->mu).  The scratch is
 // shared by successive calls, possibly on different streams: the copy first waits for the kernel of
-// the previous call that read it (small_ev, recorded by small_done after that launch).
+// the previous call that read it (small_ev, recorded by small_done after that launch).  The values
+// are staged in a pinned host buffer of the grid, so nothing here drains the caller's stream; the
+// host only waits for its OWN previous copy out of that buffer (small_copy_ev, long done by then).
 static int upload_small(vrt_grid *g, const std::vector<double> &h, hipStream_t st)
 {
     if (g->small_ev_valid) VRT_HIP_TRY(hipStreamWaitEvent(st, g->small_ev, 0));
+    if (g->small_copy_valid) VRT_HIP_TRY(hipEventSynchronize(g->small_copy_ev));
     if (!g->d_small || g->small_cap < h.size()) {
-        if (g->small_ev_valid) VRT_HIP_TRY(hipEventSynchronize(g->small_ev));   // about to free it
+        if (g->small_ev_valid) VRT_HIP_TRY(hipEventSynchronize(g->small_ev));   // about to free what it read
         dev_free(g->d_small);
-    if (g->small_ev) (void)hipEventDestroy(g->small_ev);
+        if (g->h_small) { (void)hipHostFree(g->h_small); g->h_small = nullptr; }
         g->small_cap = 0;
-        int rc = dev_alloc(&g->d_small, std::max<size_t>(h.size(), 256));
+        const size_t cap = std::max<size_t>(2 * h.size(), 256);
+        int rc = dev_alloc(&g->d_small, cap);
         if (rc) return rc;
-        g->small_cap = std::max<size_t>(h.size(), 256);
+        VRT_HIP_TRY(hipHostMalloc((void **)&g->h_small, sizeof(double) * cap, hipHostMallocDefault));
+        g->small_cap = cap;
     }
-    // synchronous w.r.t. the host vector: the copy is enqueued on st and the vector dies at return
-    VRT_HIP_TRY(hipMemcpyAsync(g->d_small, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st));
-    VRT_HIP_TRY(hipStreamSynchronize(st));
+    std::memcpy(g->h_small, h.data(), sizeof(double) * h.size());
+    VRT_HIP_TRY(hipMemcpyAsync(g->d_small, g->h_small, sizeof(double) * h.size(), hipMemcpyHostToDevice, st));
+    if (!g->small_copy_ev) VRT_HIP_TRY(hipEventCreateWithFlags(&g->small_copy_ev, hipEventDisableTiming));
+    VRT_HIP_TRY(hipEventRecord(g->small_copy_ev, st));
+    g->small_copy_valid = true;
     return VRT_OK;
 }
 
@@ -1160,8 +1328,8 @@ int vrt_line_opacity_dev(vrt_plan *p, int64_t nlam, const double *lambda, double
         vrt_grid *g = p->g;
         int rc = use_device(g->device);
         if (rc) return rc;
-        if (!p->tile_ok || p->tile_max_layer_size > steps_max_layer(false))
-            return fail(VRT_EINVAL, "the native alpha layout needs the fp64 layer-step path (layers <= 12288 sites)");
+        if (!p->patch_ok && (!p->tile_ok || p->tile_max_layer_size > steps_max_layer(false)))
+            return fail(VRT_EINVAL, "the native alpha layout needs a layer path (at most 4 visits per site and 255 levels per layer)");
         std::lock_guard<std::mutex> lock(g->mu);
         std::vector<double> h(lambda, lambda + nlam);
         if ((rc = upload_small(g, h, (hipStream_t)stream))) return rc;

@@ -93,8 +93,11 @@ struct vrt_grid {
     unsigned long long *d_scalars = nullptr;   // scratch of the Λ-iteration epilogue's reduction
     double *d_small = nullptr;                 // wavelength-sized host arrays of the physics kernels (λ, 2hc²/λ⁵, σ_bf)
     size_t small_cap = 0;
+    double *h_small = nullptr;                 // pinned staging buffer of the same capacity
     hipEvent_t small_ev = nullptr;             // last kernel that read d_small
     bool small_ev_valid = false;
+    hipEvent_t small_copy_ev = nullptr;        // last copy out of h_small
+    bool small_copy_valid = false;
     // cache of single-angle plans for vrt_delaunay_up/down
     std::mutex mu;
     std::vector<vrt::PlanCacheEntry *> cache;
@@ -167,6 +170,21 @@ struct vrt_plan {
     int32_t *d_level_map = nullptr;      // block -> task of the layer-step level kernels, per stream group (build_level_map)
     std::vector<int> level_map_off;      //   offsets of the groups' maps (+ end); 8 ceil-blocks each
     int level_map_units = 0, level_map_groups = 0;
+    std::vector<int32_t> h_step_angles;  // host copy of d_step_angles
+    // fused patch path (vrt_patch.hip): per-angle patch schedules, concatenated over the active angles
+    bool patch_ok = false;
+    int patch_cap = 0, patch_K = 0, patch_NT = 0, patch_Q = 0;   // entries per patch <= cap = K * NT; pairs per workgroup
+    int64_t n_patches = 0, n_patch_entries = 0, n_patch_visits = 0;
+    std::vector<int32_t> h_patch_first;  // [A][tile_max_layers + 2]: index of the first patch of (angle, layer)
+    std::vector<int4> h_patch_rec;       // per patch: first entry, entries, first owned position, owned sites
+    int4 *d_patch_rec = nullptr;
+    int2 *d_patch_rec2 = nullptr;        // per patch: levels, active angle
+    int32_t *e_pos = nullptr, *e_u1 = nullptr, *e_u2 = nullptr;
+    uint32_t *e_vis = nullptr, *e_loc = nullptr;
+    double *e_w1 = nullptr, *e_w2 = nullptr, *e_r1 = nullptr, *e_r2 = nullptr;
+    int32_t *d_patch_work = nullptr;     // work lists of the launches (ensure_patch_work)
+    std::vector<int64_t> patch_work_off; //   [group][layer] offsets into it
+    int patch_work_groups = 0;
     hipStream_t step_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t step_fork = nullptr, step_join[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_path = 0;                   // 1 = level kernels, 2 = layer tiles
@@ -218,6 +236,25 @@ void build_layer_schedule(const Direction &dir, bool ascending, int64_t n, int n
                           const int32_t *up1, const int32_t *up2, LayerSchedule &out);
 void build_sorted_slots(const Direction &dir, int64_t n, const std::vector<uint32_t> &vis_site,
                         std::vector<int32_t> &self);
+// Patch schedule of the fused layer kernel (vrt_patch.cpp): every layer cut into ranges of
+// consecutive storage positions, each with the in-layer dependency cone of its sites.
+struct PatchSchedule {
+    std::vector<int32_t> layer_patch_off;   // patches of layer l (1-based): [off[l], off[l+1]); L + 2 entries
+    std::vector<int32_t> patch_own_lo;      // first owned storage position
+    std::vector<int32_t> patch_own_cnt;     // owned sites (consecutive storage positions)
+    std::vector<int32_t> patch_nlev;        // in-layer levels the patch has to run
+    std::vector<int64_t> patch_ent_off;     // entries of patch q: [off[q], off[q+1]); owned first, then the halo
+    std::vector<int32_t> entry_pos;         // storage position of the entry's site
+    std::vector<uint32_t> entry_vis;        // up to 4 x 8-bit visit levels the patch executes for it, increasing
+    std::vector<uint32_t> entry_loc;        // patch-local tile slots of its two upwinds, 16 bits each; 0xFFFF: reads 0
+    int64_t n_visits = 0;                   // visits executed over all patches (halo visits counted per patch)
+    int64_t n_live = 0;                     // live visits of the unsplit schedule
+    int64_t max_entries = 0;
+    int64_t bad_site = -1;
+    bool ok = false;
+};
+void build_patch_schedule(const Direction &dir, bool ascending, int64_t n, int n_sweeps, const int32_t *up1,
+                          const int32_t *up2, int own_target, int entry_cap, PatchSchedule &out);
 
 // ---- device launchers (vrt_kernels.hip) ------------------------------------------------------
 int launch_delaunay_lines(vrt_grid *g);
@@ -260,5 +297,13 @@ int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, const v
                   int alpha_mode, const void *dI0_up, const void *dI0_down,
                   const double *weights_user, void *dJ, void *dI_out, hipStream_t st, bool f32);
 int64_t steps_max_layer(bool f32);   // largest layer the layer-step level kernels hold
+
+// ---- fused patch path (vrt_patch.hip) ----------------------------------------------------------------
+struct TileArgs;
+bool patch_shape_exists(int K, int Q, int NT);
+int launch_patch_entries(vrt_plan *p, int a, int64_t first, int64_t count);
+int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angles, const std::vector<int> &group_off);
+int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, int group, int Q, hipStream_t st,
+                       bool f32);
 
 }  // namespace vrt

@@ -1,0 +1,300 @@
+// Fused patch kernel of the layer-ordered formal solve ("patches" path) for gfx950.
+//
+// One launch per BFS layer and direction stream.  A workgroup solves ONE patch of the layer -- a range
+// of consecutive storage positions plus the halo of its in-layer dependency cone
+// (vrt_patch.cpp) -- for one angle and a group of Q wavelength pairs, start to finish:
+//   1. integration coefficients of every entry (own + halo sites) straight into registers:
+//        I_c = c + g1 I_u1 + g2 I_u2,   c = Σ_r ((e_r I_ur [earlier layer] + a_r S_ur) + b_r S_c) w_r,
+//        g_r = e_r w_r [upwind r in this layer]            (irregular_ray_tracing.jl:66-76 re-associated)
+//   2. the patch's Gauss-Seidel levels on a private LDS tile (s_barrier between levels),
+//   3. the final intensities of the sites it owns -> I (storage order, wavelength pairs).
+// Nothing is handed from one kernel to another inside a layer (the layer-step path writes and
+// re-reads 35 B of coefficients per cell-update), no workgroup waits for another one, and a layer
+// may have any number of sites: it just has more patches.  The halo is recomputed, not exchanged:
+// every visit performs the same arithmetic on the same values as in the unsplit layer.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "vrt_device.h"
+#include "vrt_internal.h"
+
+namespace vrt {
+
+struct PatchArgs {
+    TileArgs ta;              // n, nlam, alpha_mode, angle_dir, lay, nlayers, S, alpha, alpha_angle, I (pair planes)
+    int npair;                // ceil(nlam / 2)
+    int layer;                // 1-based BFS layer being solved
+    int ngrp;                 // wavelength-pair groups per work item
+    int stride;               // tile slots per pair plane (> largest entry count: + the zero slot)
+    const int32_t *work;      // this launch's work list: patch index per (slot, XCD), -1 = padding
+    const int4 *rec;          // per patch: first entry, entries, first owned storage position, owned sites
+    const int2 *rec2;         // per patch: in-layer levels, active angle
+    const int32_t *e_pos, *e_u1, *e_u2;     // per entry: storage position of the site and of its two upwinds
+    const uint32_t *e_vis, *e_loc;           //   packed visit levels; patch-local tile slots of the upwinds
+    const double *e_w1, *e_w2, *e_r1, *e_r2; //   weights and path lengths (irregular_ray_tracing.jl:51,66)
+};
+
+// entry tables of one angle from its storage-order tables
+__global__ void __launch_bounds__(256)
+k_patch_entries(int64_t count, const int32_t *__restrict__ e_pos, const int32_t *__restrict__ t_u1,
+                const int32_t *__restrict__ t_u2, const double *__restrict__ t_w1, const double *__restrict__ t_w2,
+                const double *__restrict__ t_r1, const double *__restrict__ t_r2, int32_t *__restrict__ e_u1,
+                int32_t *__restrict__ e_u2, double *__restrict__ e_w1, double *__restrict__ e_w2,
+                double *__restrict__ e_r1, double *__restrict__ e_r2)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    const int p = e_pos[e];
+    e_u1[e] = t_u1[p]; e_u2[e] = t_u2[p];
+    e_w1[e] = t_w1[p]; e_w2[e] = t_w2[p];
+    e_r1[e] = t_r1[p]; e_r2[e] = t_r2[p];
+}
+
+int launch_patch_entries(vrt_plan *p, int a, int64_t first, int64_t count)
+{
+    if (count <= 0) return VRT_OK;
+    const size_t o = (size_t)a * (size_t)p->g->n;
+    hipLaunchKernelGGL(k_patch_entries, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, p->g->stream, count,
+                       p->e_pos + first, p->t_u1 + o, p->t_u2 + o, p->t_w1 + o, p->t_w2 + o, p->t_r1 + o,
+                       p->t_r2 + o, p->e_u1 + first, p->e_u2 + first, p->e_w1 + first, p->e_w2 + first,
+                       p->e_r1 + first, p->e_r2 + first);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+// T: storage type of S, α, I; K entries per thread; Q wavelength pairs per workgroup; NT threads
+template <typename T, int K, int Q, int NT>
+__global__ void __launch_bounds__(NT)
+k_patch_solve(PatchArgs pa)
+{
+    typedef typename Pair<T>::type T2;
+    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
+    const TileArgs &ta = pa.ta;
+    const int tid = threadIdx.x;
+    // block -> (work item, pair group): blocks b, b + 8, ... share an XCD (MI355X_MICROARCH.md, speed
+    // only); the pair groups of an item follow each other on ONE XCD and read its entry tables
+    // through that L2, and consecutive items of an XCD are neighbouring patches / angles of a patch
+    const int x = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
+    const int item = pa.work[sj * 8 + x];
+    if (item < 0) return;
+    const int q0 = grp * Q;
+    if (q0 >= pa.npair) return;
+    const int4 rec = pa.rec[item];
+    const int2 rec2 = pa.rec2[item];
+    const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
+    const int nlev = rec2.x, a = rec2.y;
+    const int d = ta.angle_dir[a];
+    const int lo = ta.lay[d][pa.layer - 1], hi = ta.lay[d][pa.layer];
+    const int64_t n = ta.n;
+    const int stride = pa.stride;
+
+    int pos[K], u1[K], u2[K];
+    uint32_t vis[K], loc[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = tid + k * NT;
+        const bool ok = i < n_ent;
+        const int e = ent_off + (ok ? i : n_ent - 1);
+        pos[k] = pa.e_pos[e];
+        u1[k] = pa.e_u1[e];
+        u2[k] = pa.e_u2[e];
+        loc[k] = pa.e_loc[e];
+        vis[k] = ok ? pa.e_vis[e] : 0u;
+    }
+    double2 c[K][Q], g1[K][Q], g2[K][Q];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = tid + k * NT;
+        const int e = ent_off + (i < n_ent ? i : n_ent - 1);
+        const double w1 = pa.e_w1[e], w2 = pa.e_w2[e], r1 = pa.e_r1[e], r2 = pa.e_r2[e];
+        const int p = pos[k], v1 = u1[k], v2 = u2[k];
+        const bool early1 = v1 < lo, in1 = (v1 >= lo) & (v1 < hi);     // else: later layer / perm[n] reads 0
+        const bool early2 = v2 < lo, in2 = (v2 >= lo) & (v2 < hi);
+        const int i1 = min(v1, lo - 1), i2 = min(v2, lo - 1);          // only used when early (earlier layer: final)
+#pragma unroll
+        for (int qi = 0; qi < Q; qi++) {
+            const int q = q0 + qi;
+            if (q >= pa.npair) {                                       // (wave-uniform) last, partial group
+                c[k][qi] = g1[k][qi] = g2[k][qi] = make_double2(0.0, 0.0);
+                continue;
+            }
+            const T2 *__restrict__ S = reinterpret_cast<const T2 *>(ta.S[d]) + (size_t)q * (size_t)n;
+            const T2 *__restrict__ I = reinterpret_cast<const T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)n;
+            double2 a_c, a_1, a_2;
+            if (ta.alpha_mode == VRT_ALPHA_SITE) {                     // one opacity per site for every λ
+                const T *__restrict__ Al = reinterpret_cast<const T *>(ta.alpha[d]);
+                const double c0 = Al[p], c1 = Al[v1], c2 = Al[v2];
+                a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
+            } else {
+                const T2 *__restrict__ Al =
+                    ta.alpha_mode == VRT_ALPHA_SITE_LAM
+                        ? reinterpret_cast<const T2 *>(ta.alpha[d]) + (size_t)q * (size_t)n
+                        : reinterpret_cast<const T2 *>(ta.alpha_angle) + ((size_t)a * pa.npair + q) * (size_t)n;
+                a_c = ld2(Al, p); a_1 = ld2(Al, v1); a_2 = ld2(Al, v2);
+            }
+            const double2 S_c = ld2(S, p), S_1 = ld2(S, v1), S_2 = ld2(S, v2);
+            const double2 I_1 = ld2(I, i1), I_2 = ld2(I, i2);
+            double t1, t2;
+            upwind_term(r1, w1, a_c.x, a_1.x, S_c.x, S_1.x, I_1.x, early1, in1, t1, g1[k][qi].x);
+            upwind_term(r2, w2, a_c.x, a_2.x, S_c.x, S_2.x, I_2.x, early2, in2, t2, g2[k][qi].x);
+            c[k][qi].x = t1 + t2;
+            upwind_term(r1, w1, a_c.y, a_1.y, S_c.y, S_1.y, I_1.y, early1, in1, t1, g1[k][qi].y);
+            upwind_term(r2, w2, a_c.y, a_2.y, S_c.y, S_2.y, I_2.y, early2, in2, t2, g2[k][qi].y);
+            c[k][qi].y = t1 + t2;
+        }
+    }
+    // ---- the patch's Gauss-Seidel levels on the LDS tile: plane qi at ptile + qi * stride ----------------
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = tid + k * NT;
+        if (i < n_ent) {
+#pragma unroll
+            for (int qi = 0; qi < Q; qi++) ptile[qi * stride + i] = make_double2(0.0, 0.0);   // I = zero(S), :23
+        }
+        // an upwind outside the cone reads the zero slot (coupling x a finite 0)
+        const uint32_t l1 = loc[k] & 0xFFFFu, l2 = loc[k] >> 16;
+        loc[k] = (l1 == 0xFFFFu ? (uint32_t)n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)n_ent : l2) << 16);
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int qi = 0; qi < Q; qi++) ptile[qi * stride + n_ent] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    for (int t = 1; t <= nlev; t++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if ((vis[k] & 0xFFu) == (uint32_t)t) {          // a site's visits come at increasing levels
+                const uint32_t l1 = loc[k] & 0xFFFFu, l2 = loc[k] >> 16;
+#pragma unroll
+                for (int qi = 0; qi < Q; qi++) {
+                    const double2 xv = ptile[qi * stride + l1], yv = ptile[qi * stride + l2];
+                    double2 r;
+                    r.x = c[k][qi].x + g1[k][qi].x * xv.x + g2[k][qi].x * yv.x;
+                    r.y = c[k][qi].y + g1[k][qi].y * xv.y + g2[k][qi].y * yv.y;
+                    ptile[qi * stride + tid + k * NT] = r;
+                }
+                vis[k] >>= 8;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- final intensities of the owned sites (entries 0 .. own_cnt-1 = positions own_lo ..) -------------
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = tid + k * NT;
+        if (i < own_cnt) {
+#pragma unroll
+            for (int qi = 0; qi < Q; qi++) {
+                const int q = q0 + qi;
+                if (q < pa.npair) {
+                    T2 *I = reinterpret_cast<T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)n;
+                    I[own_lo + i] = from_d2<T>(ptile[qi * stride + i]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int K, int Q, int NT>
+static void launch_one(dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa)
+{
+    hipLaunchKernelGGL((k_patch_solve<T, K, Q, NT>), grid, dim3(NT), lds, st, pa);
+}
+
+template <typename T>
+static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa)
+{
+#define VRT_PATCH_CASE(k, q, nt) \
+    if (K == k && Q == q && NT == nt) { launch_one<T, k, q, nt>(grid, lds, st, pa); return VRT_OK; }
+    VRT_PATCH_CASE(1, 1, 512) VRT_PATCH_CASE(1, 2, 512) VRT_PATCH_CASE(1, 4, 512)
+    VRT_PATCH_CASE(2, 1, 512) VRT_PATCH_CASE(2, 2, 512)
+    VRT_PATCH_CASE(4, 1, 512)
+    VRT_PATCH_CASE(1, 2, 1024) VRT_PATCH_CASE(1, 4, 1024)
+    VRT_PATCH_CASE(2, 1, 256) VRT_PATCH_CASE(2, 2, 256) VRT_PATCH_CASE(4, 1, 256)
+#undef VRT_PATCH_CASE
+    return fail(VRT_EINVAL, "no patch kernel for this (entries per thread, pairs, threads) shape");
+}
+
+bool patch_shape_exists(int K, int Q, int NT)
+{
+    static const int shapes[][3] = {{1, 1, 512}, {1, 2, 512}, {1, 4, 512}, {2, 1, 512}, {2, 2, 512}, {4, 1, 512},
+                                    {1, 2, 1024}, {1, 4, 1024}, {2, 1, 256}, {2, 2, 256}, {4, 1, 256}};
+    for (const auto &s : shapes)
+        if (s[0] == K && s[1] == Q && s[2] == NT) return true;
+    return false;
+}
+
+// work lists of the launches: per (stream group, layer) the patches of the group's angles, sorted by
+// (first owned position, angle) and cut into 8 runs of equal count; XCD x (blocks x, x + 8, ...)
+// walks run x, so that neighbouring patches -- and the angles of one patch, which read the same S
+// lines -- meet in one L2
+int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angles, const std::vector<int> &group_off)
+{
+    if (p->d_patch_work && p->patch_work_groups == G) return VRT_OK;
+    if (p->d_patch_work) { (void)hipFree(p->d_patch_work); p->d_patch_work = nullptr; }
+    const int maxL = p->tile_max_layers;
+    std::vector<int32_t> work;
+    p->patch_work_off.assign((size_t)G * (size_t)(maxL + 2) + 1, 0);
+    std::vector<std::pair<int64_t, int32_t>> items;
+    for (int gi = 0; gi < G; gi++)
+        for (int layer = 0; layer <= maxL + 1; layer++) {
+            p->patch_work_off[(size_t)gi * (size_t)(maxL + 2) + (size_t)layer] = (int64_t)work.size();
+            if (layer < 2 || layer > maxL) continue;
+            items.clear();
+            for (int j = group_off[(size_t)gi]; j < group_off[(size_t)gi + 1]; j++) {
+                const int a = group_angles[(size_t)j];
+                const int32_t *first = p->h_patch_first.data() + (size_t)a * (size_t)(maxL + 2);
+                for (int32_t q = first[layer]; q < first[layer + 1]; q++)
+                    items.push_back({(int64_t)p->h_patch_rec[(size_t)q].z * 64 + (j - group_off[(size_t)gi]), q});
+            }
+            std::sort(items.begin(), items.end());
+            const size_t m = items.size();
+            if (m == 0) continue;
+            const size_t slots = (m + 7) / 8;
+            const size_t base = work.size();
+            work.resize(base + slots * 8, -1);
+            for (int x = 0; x < 8; x++) {
+                const size_t b0 = m * (size_t)x / 8, b1 = m * (size_t)(x + 1) / 8;
+                for (size_t t = b0; t < b1; t++) work[base + (t - b0) * 8 + (size_t)x] = items[t].second;
+            }
+        }
+    p->patch_work_off.back() = (int64_t)work.size();
+    VRT_HIP_TRY(hipMalloc((void **)&p->d_patch_work, sizeof(int32_t) * std::max<size_t>(work.size(), 1)));
+    VRT_HIP_TRY(hipMemcpy(p->d_patch_work, work.data(), sizeof(int32_t) * work.size(), hipMemcpyHostToDevice));
+    p->patch_work_groups = G;
+    return VRT_OK;
+}
+
+// one layer of one stream group
+int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, int group, int Q, hipStream_t st,
+                       bool f32)
+{
+    const int maxL = p->tile_max_layers;
+    const size_t wo = (size_t)group * (size_t)(maxL + 2) + (size_t)layer;
+    const int64_t w0 = p->patch_work_off[wo], w1 = p->patch_work_off[wo + 1];
+    if (w1 <= w0) return VRT_OK;
+    PatchArgs pa;
+    pa.ta = ta;
+    pa.npair = npair;
+    pa.layer = layer;
+    pa.ngrp = (npair + Q - 1) / Q;
+    pa.stride = p->patch_cap + 1;
+    pa.work = p->d_patch_work + w0;
+    pa.rec = p->d_patch_rec;
+    pa.rec2 = p->d_patch_rec2;
+    pa.e_pos = p->e_pos; pa.e_u1 = p->e_u1; pa.e_u2 = p->e_u2;
+    pa.e_vis = p->e_vis; pa.e_loc = p->e_loc;
+    pa.e_w1 = p->e_w1; pa.e_w2 = p->e_w2; pa.e_r1 = p->e_r1; pa.e_r2 = p->e_r2;
+    const dim3 grid((unsigned)((w1 - w0) * pa.ngrp));
+    const size_t lds = (size_t)Q * (size_t)pa.stride * sizeof(double2);
+    const int rc = f32 ? launch_shape<float>(p->patch_K, Q, p->patch_NT, grid, lds, st, pa)
+                       : launch_shape<double>(p->patch_K, Q, p->patch_NT, grid, lds, st, pa);
+    return rc;
+}
+
+}  // namespace vrt

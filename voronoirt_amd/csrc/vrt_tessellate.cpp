@@ -186,7 +186,8 @@ int tessellate_host(int64_t n, const double *pos, const double bounds[6], int64_
     const double eps = 1e-11 * std::max({Lx, Ly, Lz});
     std::vector<int64_t> worst((size_t)nthreads, 0);
     std::vector<int64_t> bad((size_t)nthreads, -1);
-    auto work = [&](int t) {
+    std::vector<int> oom((size_t)nthreads, 0);       // a worker must not throw: std::terminate would take the host down
+    auto work_body = [&](int t) {
         Cell cell;
         std::vector<std::pair<double, std::pair<int32_t, V3>>> cand;
         for (int64_t i = t; i < n; i += nthreads) {
@@ -259,9 +260,27 @@ int tessellate_host(int64_t n, const double *pos, const double bounds[6], int64_
             if (overflow && bad[(size_t)t] < 0) bad[(size_t)t] = i;
         }
     };
+    auto work = [&](int t) {
+        try {
+            work_body(t);
+        } catch (...) {
+            oom[(size_t)t] = 1;
+        }
+    };
     std::vector<std::thread> pool;
-    for (int t = 0; t < nthreads; t++) pool.emplace_back(work, t);
+    bool spawn_failed = false;
+    for (int t = 0; t < nthreads; t++) {
+        try {
+            pool.emplace_back(work, t);
+        } catch (...) {                              // thread creation failed: this thread does the share
+            spawn_failed = true;
+            work(t);
+        }
+    }
     for (auto &th : pool) th.join();
+    (void)spawn_failed;
+    for (int t = 0; t < nthreads; t++)
+        if (oom[(size_t)t]) return fail(VRT_ENOMEM, "out of host memory in the tessellation");
     int64_t mx = 0;
     for (int t = 0; t < nthreads; t++) {
         mx = std::max(mx, worst[(size_t)t]);

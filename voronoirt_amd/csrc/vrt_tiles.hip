@@ -23,21 +23,10 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "vrt_device.h"
 #include "vrt_internal.h"
 
 namespace vrt {
-
-// Timing diagnostics that switch pieces of the memory traffic off (and give WRONG results) exist
-// only in the -DVRT_DIAG build (voronoirt_amd/libvrt_hip_diag.so, used by tools/flags_sweep.sh):
-// in the product library every such branch folds away at compile time and no environment
-// variable can change a result.
-#ifdef VRT_DIAG
-constexpr bool kDiag = true;
-#else
-constexpr bool kDiag = false;
-#endif
-
-constexpr uint32_t kNoSlot = 0xFFFFu;   // t_loc entry of an upwind outside the site's own layer (layers <= 8192 sites)
 
 // ---- table in sweep order -----------------------------------------------------------------------
 // t_u1/t_u2: sweep positions of the upwind sites; everything else copied from the site-order table.
@@ -233,29 +222,6 @@ int launch_gpos(vrt_plan *p, int a)
     return VRT_OK;
 }
 
-// ---- layout changes -----------------------------------------------------------------------------
-// Storage-order arrays are wavelength-major in blocks of `lb` wavelengths: element (l, p) lives at
-// ((l / lb) * n + p) * lb + l % lb.  lb = 1 (plain planes [λ][pos]) for the persistent tile
-// kernel; lb = 2 (wavelength PAIRS interleaved per site, [λ/2][pos][2]) for the layer-step
-// kernels, whose 16-byte accesses fetch two wavelengths per gathered cache line.  Planes are
-// padded to a multiple of lb wavelengths.
-__device__ __forceinline__ size_t sw_index(int l, int64_t p, int64_t n, int lb)
-{
-    return lb == 1 ? (size_t)l * (size_t)n + (size_t)p
-                   : (((size_t)(l >> 1) * (size_t)n + (size_t)p) << 1) + (size_t)(l & 1);
-}
-
-// storage types: T = double, or float for the fp32 VALUE path (BASELINE config C5: S, α, I, J held as
-// float, all arithmetic fp64); a wavelength pair is one 16-byte (double2) or 8-byte (float2) access
-template <typename T> struct Pair;
-template <> struct Pair<double> { typedef double2 type; };
-template <> struct Pair<float> { typedef float2 type; };
-__device__ __forceinline__ double2 to_d2(double2 v) { return v; }
-__device__ __forceinline__ double2 to_d2(float2 v) { return make_double2((double)v.x, (double)v.y); }
-template <typename T> __device__ __forceinline__ typename Pair<T>::type from_d2(double2 v);
-template <> __device__ __forceinline__ double2 from_d2<double>(double2 v) { return v; }
-template <> __device__ __forceinline__ float2 from_d2<float>(double2 v) { return make_float2((float)v.x, (float)v.y); }
-
 // out[l][p] = in[order[p]][l]   (caller's (nλ, n) site-major rows -> wavelength-major sweep order)
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -341,98 +307,6 @@ k_boundary_sweep_order(int64_t n, int nlam, int lb, int64_t n1, const int32_t *_
     }
 }
 
-// ---- the solver ---------------------------------------------------------------------------------
-// linear_weights (functions.jl:484-500) with the arithmetic trimmed for the ALU-bound phase 1:
-// one Newton-refined reciprocal shared by the thick and the exponential branch, the Taylor
-// branch's /3 and /6 as multiplications, and exp(-x) for the only range it is needed in
-// (5e-4 <= x <= 50: no overflow, underflow, NaN or subnormal handling).  Each piece is accurate
-// to ~1 ulp; results differ from the oracle's libm at the 1e-16 level (contract: 1e-10).
-__device__ __forceinline__ double exp_neg(double x)       // exp(-x), 5e-4 <= x <= 50
-{
-    const double t = -x;
-    const double kf = rint(t * 1.4426950408889634074);    // k = round(t / ln 2), |k| <= 73
-    double r = fma(-kf, 6.93147180369123816490e-01, t);   // Cody-Waite: ln2 = hi + lo
-    r = fma(-kf, 1.90821492927058770002e-10, r);           // |r| <= 0.3466
-    double p = 1.0 / 6227020800.0;                         // Taylor to r^13/13!: remainder < 4e-18
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)kf);
-}
-
-__device__ __forceinline__ void lin_weights(double dtau, double &a, double &b, double &e)
-{
-    // reciprocal of dtau (only consumed when dtau >= 5e-4): hardware estimate + 2 Newton steps
-    double rc = __builtin_amdgcn_rcp(dtau);
-    rc = fma(fma(-dtau, rc, 1.0), rc, rc);
-    rc = fma(fma(-dtau, rc, 1.0), rc, rc);
-    const double ee = exp_neg(fmin(fmax(dtau, 5e-4), 50.0));
-    if (dtau < 5e-4) {
-        e = 1.0 - dtau + 0.5 * (dtau * dtau);
-        a = dtau * (0.5 - dtau * (1.0 / 3.0));
-        b = dtau * (0.5 - dtau * (1.0 / 6.0));
-    } else if (dtau > 50.0) {
-        e = 0.0;
-        a = rc;
-        b = 1.0 - a;
-    } else {
-        e = ee;
-        a = (1.0 - e) * rc - e;
-        b = 1.0 - a - e;
-    }
-}
-
-// 32-bit byte offsets from a wave-uniform base: lets the compiler use the saddr + voffset form of
-// global_load (one VGPR per address instead of a 64-bit pair) -- the phase-1 batches are
-// register-bound.  Planes are n * 8 bytes < 4 GiB.
-__device__ __forceinline__ double ldd(const double *base, unsigned idx)
-{
-    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (size_t)(idx << 3));
-}
-__device__ __forceinline__ int ldi(const int32_t *base, unsigned idx)
-{
-    return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(base) + (size_t)(idx << 2));
-}
-__device__ __forceinline__ uint32_t ldu(const uint32_t *base, unsigned idx)
-{
-    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(base) + (size_t)(idx << 2));
-}
-
-struct TileArgs {
-    int64_t n;
-    int nlam;
-    int A;
-    int alpha_mode;
-    int max_layers;                 // stride of nlev
-    int tile_stride;                // doubles per LDS array (>= largest layer)
-    const int32_t *task_map;        // block -> angle | wavelength << 8 (XCD-aware, see build_task_map)
-    const int32_t *angle_dir;       // [A] 0 = up, 1 = down
-    const int32_t *lay[2];          // per direction: 0-based [lo, hi) boundaries, lay[d][L+1]
-    int nlayers[2];                 // number of BFS layers per direction
-    const int32_t *nlev;            // [A][max_layers + 1] in-layer level counts (index = layer)
-    const int32_t *t_u1, *t_u2;     // [A][n] sweep positions of the upwinds
-    const double *t_w1, *t_w2, *t_r1, *t_r2;
-    const uint32_t *t_vis;
-    const uint32_t *t_loc;          // [A][n] packed in-layer tile slots of the two upwinds
-    const int32_t *t_self;          // [A][n] sorted thread order of k_step_levels (build_sorted_slots)
-    const uint32_t *t_vis_s, *t_loc_s;
-    const uint32_t *t_gpos;         // [A][n] compact in-layer coupling list positions (k_gpos)
-    const double *S[2];             // per direction [nlam][n]
-    const double *alpha[2];         // SITE: [n]; SITE_LAM: [nlam][n] per direction
-    const double *alpha_angle;      // ANGLE: [A][nlam][n]
-    double *I;                      // [A][nlam][n]
-    long long *dbg;                 // diagnostics (VRT_TILE_DEBUG=1): per task phase cycles, else NULL
-};
 
 // K sites per thread, phase-1 batches of B sites (their 12 B loads are in flight together), T threads
 // (768 = 3 waves per SIMD leaves 168 VGPRs per thread for B = 4; 1024 allows B = 2)
@@ -765,53 +639,6 @@ k_sweep_tiles_pre(TileArgs ta, const double *__restrict__ rec, const uint32_t *_
 // in-layer dependency structure (levels, tile slots) is the same for every wavelength of an
 // angle, so a level visit of the pair costs the same LDS instructions (b128) as one wavelength.
 // ---------------------------------------------------------------------------------------------
-struct DirWeights {
-    double w[kMaxAngles];
-    int32_t idx[kMaxAngles];
-    int count;
-};
-
-struct StepArgs {
-    TileArgs ta;              // S, alpha, I in pair layout; ta.nlam = the caller's wavelength count
-    int npair;                // ceil(nlam / 2)
-    int layer;                // 1-based BFS layer being solved
-    int cg_stride;            // slots (double2 each) per (angle, wavelength pair) in the coefficient buffers
-    double2 *cg_c;            // constant terms, cg_stride per (angle, pair)
-    double2 *cg_g;            // in-layer couplings, compact list (t_gpos), 2 cg_stride per (angle, pair)
-    const int32_t *angle_list;      // the angles this launch works on (one stream's share)
-    int n_list;
-    int pairs_per_thread;     // wavelength pairs one k_step_coeffs thread loops over
-    int chunks;               // 256-slot chunks per layer (k_step_coeffs grid.x / 1)
-    int xcd_map;              // 0: plain grid; 1, 2: contiguous chunk ranges per XCD (2: angle fastest)
-    const int32_t *level_map; // level kernels: block -> task (index into angle_list x wavelengths), -1 = padding; NULL: identity
-    const int32_t *t_rank_s;  // single-wavelength level kernel: storage position -> sorted index
-    const uint32_t *t_loc_ss; //   and the upwind tile slots in sorted terms
-    int debug_skip_levels;    // diagnostics only (VRT_DEBUG_SKIP_LEVELS=1): wrong results
-    int debug_flags;          // diagnostics only (VRT_DEBUG_FLAGS bit mask): wrong results, see execute_tiles
-};
-
-__device__ __forceinline__ double2 ld2(const double2 *base, unsigned idx)
-{
-    return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + ((size_t)idx << 4));
-}
-__device__ __forceinline__ double2 ld2(const float2 *base, unsigned idx)     // fp32 storage, fp64 arithmetic
-{
-    return to_d2(*reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + ((size_t)idx << 3)));
-}
-
-// one upwind's share of the visit: t = ((e I_u + a S_u) + b S_c) w  (I_u dropped unless the upwind
-// lies in an earlier layer), g = e w if the upwind lies in the site's own layer
-__device__ __forceinline__ void upwind_term(double r, double w, double a_c, double a_u, double S_c,
-                                            double S_u, double I_u, bool early, bool inl, double &t,
-                                            double &g, bool cheap = false)
-{
-    double ca, cb, ce;
-    if (cheap) { ca = a_c; cb = a_u; ce = r; }                     // diagnostics: no linear_weights
-    else
-    lin_weights(r * (a_c + a_u) / 2.0, ca, cb, ce);                // trapezoidal, functions.jl:393
-    t = early ? ((ce * I_u + ca * S_u) + cb * S_c) * w : (ca * S_u + cb * S_c) * w;
-    g = inl ? ce * w : 0.0;
-}
 
 // block = 256 consecutive slots (a Morton-coherent patch: the upwind gathers of neighbouring
 // slots share lines through L1) of one angle; each thread keeps its slot's upwind-table entry
@@ -1331,6 +1158,8 @@ static int ensure_step_streams(vrt_plan *p, int G)
     p->step_group_off[(size_t)G] = (int)list.size();
     if (!p->d_step_angles) VRT_HIP_TRY(hipMalloc((void **)&p->d_step_angles, sizeof(int32_t) * (size_t)std::max(A, 1)));
     VRT_HIP_TRY(hipMemcpy(p->d_step_angles, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice));
+    p->h_step_angles = list;
+    if (p->d_patch_work) { (void)hipFree(p->d_patch_work); p->d_patch_work = nullptr; }   // work lists follow the groups
     if (!p->step_fork) VRT_HIP_TRY(hipEventCreateWithFlags(&p->step_fork, hipEventDisableTiming));
     for (int gi = 0; gi < 4; gi++) {
         if (gi < G && !p->step_stream[gi]) {
@@ -1432,10 +1261,11 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     vrt_grid *g = p->g;
     const int64_t n = g->n;
     const int A = p->A;
-    const bool steps = p->last_path == 3;
+    const bool patches = p->last_path == 4;          // fused patch kernel (vrt_patch.hip): same layouts as steps
+    const bool steps = p->last_path == 3 || patches;
     // the pair level kernel (fp64 storage, layers <= 8192 sites) or the single-wavelength one
     // (VRT_STEP_SINGLE=1 selects the single-wavelength kernel on any grid: same results, for the tests)
-    const bool single = steps && (kF32 || p->tile_max_layer_size > 8192 ||
+    const bool single = steps && !patches && (kF32 || p->tile_max_layer_size > 8192 ||
                                   (std::getenv("VRT_STEP_SINGLE") && std::atoi(std::getenv("VRT_STEP_SINGLE")) == 1));
     // storage layout: wavelength pairs side by side on the layer-step path, plain planes on the
     // persistent tile path (sw_index); planes are padded to a whole number of blocks
@@ -1529,8 +1359,10 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         // kernel -> one plane of T per (angle, wavelength)
         const size_t cgn = single ? dcount((size_t)A * (size_t)nl_pad * (size_t)stride)
                                   : (size_t)A * (size_t)nl_pad * (size_t)stride;
-        if ((rc = ensure_dev(p->ws_cg[0], p->ws_cg_cap[0], cgn))) return rc;
-        if ((rc = ensure_dev(p->ws_cg[1], p->ws_cg_cap[1], 2 * cgn))) return rc;
+        if (!patches) {
+            if ((rc = ensure_dev(p->ws_cg[0], p->ws_cg_cap[0], cgn))) return rc;
+            if ((rc = ensure_dev(p->ws_cg[1], p->ws_cg_cap[1], 2 * cgn))) return rc;
+        }
         StepArgs sa;
         sa.ta = ta;
         sa.cg_stride = stride;
@@ -1568,8 +1400,9 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         G = std::max(1, std::min({G, 4, A}));
         if ((rc = ensure_step_streams(p, G))) return rc;
         // level workgroups -> XCDs: contiguous cost-balanced runs (VRT_STEP_LEVEL_MAP=0: round-robin)
-        const bool use_map = !(std::getenv("VRT_STEP_LEVEL_MAP") && std::atoi(std::getenv("VRT_STEP_LEVEL_MAP")) == 0);
+        const bool use_map = !patches && !(std::getenv("VRT_STEP_LEVEL_MAP") && std::atoi(std::getenv("VRT_STEP_LEVEL_MAP")) == 0);
         if (use_map && (rc = build_level_map(p, G, single ? (int)nlam : npair))) return rc;
+        if (patches && (rc = ensure_patch_work(p, G, p->h_step_angles, p->step_group_off))) return rc;
         sa.level_map = nullptr;
         VRT_HIP_TRY(hipEventRecord(p->ev0, st));
         VRT_HIP_TRY(hipEventRecord(p->step_fork, st));
@@ -1600,6 +1433,13 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                 hipStream_t sg = G == 1 ? st : p->step_stream[gi];
                 const int n_list = p->step_group_off[gi + 1] - p->step_group_off[gi];
                 if (n_list == 0) continue;
+                if (patches) {               // ONE fused launch per layer and stream
+                    // pairs per workgroup: the plan's Q, or 1 when that would leave half of every group empty
+                    const int Q = (npair % p->patch_Q != 0 && npair < 2 * p->patch_Q && patch_shape_exists(p->patch_K, 1, p->patch_NT)) ? 1 : p->patch_Q;
+                    if ((rc = launch_patch_layer(p, sa.ta, npair, layer, gi, Q, sg, kF32))) return rc;
+                    launches += 1;
+                    continue;
+                }
                 sa.angle_list = p->d_step_angles + p->step_group_off[gi];
                 sa.n_list = n_list;
                 const size_t ntask_l = (size_t)n_list * (size_t)(single ? (int)nlam : npair);
