@@ -503,7 +503,7 @@ def test_layers_of_20000_and_30000_sites_run_on_the_patch_kernel(monkeypatch, a,
     assert _rel(J, ref) < RTOL
     monkeypatch.setenv("VRT_PATH", "levels")
     J2, _ = plan.execute(S, al, weights=w, I0_up=I0)
-    assert plan.last_path == "levels" and _rel(J2, J) < 1e-13
+    assert plan.last_path == "levels" and _rel(J2, J) < 5e-12
     monkeypatch.setenv("VRT_PATH", "steps")                   # no layer-step kernel holds such a layer
     with pytest.raises(vrt.VrtError):
         plan.execute(S, al, weights=w, I0_up=I0)

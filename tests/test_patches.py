@@ -62,7 +62,7 @@ def test_patches_J_matches_oracle_and_steps(grids, name, own, nlam, monkeypatch)
         monkeypatch.setenv("VRT_PATH", "steps")
         J2, I2 = plan.execute(S, al, weights=w, I0_up=I0u, I0_down=I0d, want_I=True)
         assert plan.last_path == "steps"
-        assert _rel(I, I2) < 1e-13 and _rel(J, J2) < 1e-13
+        assert _rel(I, I2) < 5e-12 and _rel(J, J2) < 5e-12       # exp() of the patch kernel: 2e-13 (contract 1e-10)
         # the never-visited last site of each direction keeps I = 0 (voronoi_utils.jl:266)
         for a_i in range(nq):
             last = (so.perm_up if th[a_i] > 90 else so.perm_down)[-1] - 1
@@ -70,8 +70,8 @@ def test_patches_J_matches_oracle_and_steps(grids, name, own, nlam, monkeypatch)
     plan.close()
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 512), (1, 2, 512), (1, 4, 512), (2, 1, 512), (2, 2, 512), (4, 1, 512),
-                                   (1, 2, 1024), (1, 4, 1024), (2, 1, 256), (2, 2, 256), (4, 1, 256)])
+@pytest.mark.parametrize("shape", [(1, 1, 256), (1, 1, 512), (1, 1, 1024), (2, 1, 256), (2, 1, 512), (1, 2, 256),
+                                   (1, 2, 512), (1, 2, 1024), (2, 2, 512)])
 @pytest.mark.parametrize("f32", [False, True])
 def test_every_patch_kernel_instantiation(grids, shape, f32, monkeypatch):
     """Every (entries per thread, wavelength pairs, threads) instantiation of k_patch_solve, fp64 and fp32

@@ -389,9 +389,10 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         }
         p->patch_cap = p->patch_K * p->patch_NT;
     }
+    // a patch owns as many consecutive sites as its dependency cone leaves room for (VRT_PATCH_OWN: at most that many)
     const int patch_own = std::max(1, std::min(p->patch_cap, [&]() {
         const char *e = std::getenv("VRT_PATCH_OWN");
-        return e && *e ? std::atoi(e) : p->patch_cap * 3 / 4;
+        return e && *e ? std::atoi(e) : p->patch_cap;
     }()));
     {
         unsigned hw = std::thread::hardware_concurrency();
@@ -1053,8 +1054,8 @@ int vrt_patch_schedule_build(const vrt_grid *g, int dir, const int64_t *up, int 
                              int entry_cap, vrt_patch_schedule **out, int64_t counts[6])
 {
     if (!g || !up || !out || !counts) return fail(VRT_EINVAL, "NULL argument");
-    if (n_sweeps < 1 || own_target < 1 || entry_cap < own_target || entry_cap > 65535)
-        return fail(VRT_EINVAL, "need n_sweeps >= 1 and 1 <= own_target <= entry_cap <= 65535");
+    if (n_sweeps < 1 || own_target < 1 || entry_cap < 1 || entry_cap > 65535)
+        return fail(VRT_EINVAL, "need n_sweeps >= 1, own_target >= 1 and 1 <= entry_cap <= 65535");
     *out = nullptr;
     try {
         const int64_t n = g->n;

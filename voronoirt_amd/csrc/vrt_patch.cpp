@@ -37,7 +37,8 @@ void build_patch_schedule(const Direction &dir, bool ascending, int64_t n, int n
     out.layer_patch_off.assign((size_t)nl + 1, 0);
     out.ok = true;
     if (own_target < 1) own_target = 1;
-    if (entry_cap < own_target) entry_cap = own_target;
+    if (entry_cap < 1) entry_cap = 1;
+    if (entry_cap > 65535) entry_cap = 65535;
 
     // ---- passes A (trace, redundant visits dropped) with read-from edges ----------------------
     Trace tr;
@@ -116,113 +117,125 @@ void build_patch_schedule(const Direction &dir, bool ascending, int64_t n, int n
     }
 
     // ---- patches and their dependency cones ---------------------------------------------------------
+    // Greedy along the storage order: a patch takes the next site as long as the union of the cones of
+    // its sites stays within entry_cap entries (and it owns at most own_target sites), so every
+    // workgroup's lanes are filled whatever the halo width of the angle and the layer.
     std::vector<int32_t> srank((size_t)n);          // site -> storage position
     for (int64_t p = 0; p < n; p++) srank[(size_t)dir.store[(size_t)p]] = (int32_t)p;
     std::vector<int32_t> last_live((size_t)n, -1);  // trace index of the site's final visit
     for (size_t x = 0; x < T; x++)
         if (live[x]) last_live[tr.site[x]] = (int32_t)x;
     std::vector<int32_t> stamp(T, -1);               // patch that has marked the visit
-    std::vector<int32_t> slot_of((size_t)n, -1), slot_patch((size_t)n, -1);   // local tile slot of a site in the current patch
-    std::vector<int32_t> stack, marked, halo;
+    std::vector<int32_t> slot_of((size_t)n, -1), in_patch((size_t)n, -1);   // local tile slot of a site / patch it is an entry of
+    std::vector<int32_t> stack, marked, sites, new_marks, new_sites, halo, llw, llr;
     int32_t patch_id = 0;
 
-    struct Range { int32_t lo, cnt; };
-    std::vector<Range> todo;
     for (int64_t layer = 2; layer <= nl - 1; layer++) {
         out.layer_patch_off[(size_t)layer] = patch_id;
         const int32_t lo = (int32_t)(r[(size_t)layer - 1] - 1), hi = (int32_t)(r[(size_t)layer] - 1);
-        const int32_t cnt = hi - lo;
         const int64_t x0 = tr.layer_off[(size_t)layer];
-        if (cnt <= 0) continue;
-        // balanced cut into ceil(cnt / own_target) ranges; a range whose cone exceeds entry_cap is halved
-        const int32_t P = (cnt + own_target - 1) / own_target;
-        todo.clear();
-        for (int32_t q = P - 1; q >= 0; q--) {
-            const int32_t a = (int32_t)((int64_t)cnt * q / P), b = (int32_t)((int64_t)cnt * (q + 1) / P);
-            todo.push_back({lo + a, b - a});
-        }
-        while (!todo.empty()) {
-            const Range rg = todo.back();
-            todo.pop_back();
-            // cone: final visits of the owned sites + everything they (transitively) read inside the layer
-            stack.clear();
+        int32_t p = lo;
+        while (p < hi) {
+            const int32_t own_lo = p;
             marked.clear();
-            for (int32_t p = rg.lo; p < rg.lo + rg.cnt; p++) {
-                const int32_t x = last_live[(size_t)dir.store[(size_t)p]];
-                if (x < 0) continue;                          // cannot happen for a visited layer
-                stamp[(size_t)x] = patch_id;
-                stack.push_back(x);
+            sites.clear();
+            while (p < hi && p - own_lo < own_target) {
+                // cone of the next site: its final visit + everything it (transitively) reads inside the layer
+                new_marks.clear();
+                new_sites.clear();
+                stack.clear();
+                const int32_t xs = last_live[(size_t)dir.store[(size_t)p]];
+                if (xs >= 0 && stamp[(size_t)xs] != patch_id) {
+                    stamp[(size_t)xs] = patch_id;
+                    stack.push_back(xs);
+                }
+                while (!stack.empty()) {
+                    const int32_t x = stack.back();
+                    stack.pop_back();
+                    new_marks.push_back(x);
+                    const int32_t i = (int32_t)tr.site[(size_t)x];
+                    if (in_patch[(size_t)i] != patch_id) {
+                        in_patch[(size_t)i] = patch_id;
+                        new_sites.push_back(i);
+                    }
+                    const int32_t s1 = tr.src1[(size_t)x], s2 = tr.src2[(size_t)x];
+                    if (s1 >= x0 && stamp[(size_t)s1] != patch_id) { stamp[(size_t)s1] = patch_id; stack.push_back(s1); }
+                    if (s2 >= x0 && stamp[(size_t)s2] != patch_id) { stamp[(size_t)s2] = patch_id; stack.push_back(s2); }
+                }
+                if ((int64_t)sites.size() + (int64_t)new_sites.size() > entry_cap) {
+                    for (int32_t x : new_marks) stamp[(size_t)x] = -1;          // does not fit any more: next patch
+                    for (int32_t i : new_sites) in_patch[(size_t)i] = -1;
+                    break;
+                }
+                marked.insert(marked.end(), new_marks.begin(), new_marks.end());
+                sites.insert(sites.end(), new_sites.begin(), new_sites.end());
+                p++;
             }
-            while (!stack.empty()) {
-                const int32_t x = stack.back();
-                stack.pop_back();
-                marked.push_back(x);
-                const int32_t s1 = tr.src1[(size_t)x], s2 = tr.src2[(size_t)x];
-                if (s1 >= x0 && stamp[(size_t)s1] != patch_id) { stamp[(size_t)s1] = patch_id; stack.push_back(s1); }
-                if (s2 >= x0 && stamp[(size_t)s2] != patch_id) { stamp[(size_t)s2] = patch_id; stack.push_back(s2); }
+            const int32_t own_cnt = p - own_lo;
+            if (own_cnt == 0) {                              // the cone of a single site exceeds the cap: the
+                out.ok = false;                              // patch kernel cannot hold it (other paths take over)
+                return;
             }
             // entries: owned sites in storage order, then the halo sites by storage position
             halo.clear();
-            for (int32_t x : marked) {
-                const int32_t i = (int32_t)tr.site[(size_t)x];
-                const int32_t p = srank[(size_t)i];
-                if (p >= rg.lo && p < rg.lo + rg.cnt) continue;
-                if (slot_patch[(size_t)i] != patch_id) {
-                    slot_patch[(size_t)i] = patch_id;
-                    halo.push_back(p);
-                }
-            }
-            const int64_t entries = (int64_t)rg.cnt + (int64_t)halo.size();
-            if (entries > entry_cap && rg.cnt > 1) {       // too wide a cone: halve the range and redo both halves
-                for (int32_t p : halo) slot_patch[(size_t)dir.store[(size_t)p]] = -1;
-                for (int32_t x : marked) stamp[(size_t)x] = -1;
-                const int32_t h = rg.cnt / 2;
-                todo.push_back({rg.lo + h, rg.cnt - h});
-                todo.push_back({rg.lo, h});
-                continue;
-            }
-            if (entries > entry_cap || entries > 65535) {   // a single site whose cone exceeds the cap: the
-                out.ok = false;                             // patch kernel cannot hold it (other paths take over)
-                return;
+            for (int32_t i : sites) {
+                const int32_t ps = srank[(size_t)i];
+                if (ps < own_lo || ps >= p) halo.push_back(ps);
             }
             std::sort(halo.begin(), halo.end());
+            const int64_t entries = (int64_t)own_cnt + (int64_t)halo.size();
             const int64_t e0 = (int64_t)out.entry_pos.size();
-            for (int32_t j = 0; j < rg.cnt; j++) {
-                const int32_t i = dir.store[(size_t)(rg.lo + j)];
+            for (int32_t j = 0; j < own_cnt; j++) {
+                const int32_t i = dir.store[(size_t)(own_lo + j)];
                 slot_of[(size_t)i] = j;
-                slot_patch[(size_t)i] = patch_id;
-                out.entry_pos.push_back(rg.lo + j);
+                in_patch[(size_t)i] = patch_id;
+                out.entry_pos.push_back(own_lo + j);
             }
             for (size_t j = 0; j < halo.size(); j++) {
-                const int32_t i = dir.store[(size_t)halo[j]];
-                slot_of[(size_t)i] = rg.cnt + (int32_t)j;
+                slot_of[(size_t)dir.store[(size_t)halo[j]]] = own_cnt + (int32_t)j;
                 out.entry_pos.push_back(halo[j]);
             }
             out.entry_vis.resize(out.entry_pos.size(), 0u);
             out.entry_loc.resize(out.entry_pos.size(), 0u);
-            // packed visit levels of the marked visits, increasing (a site's visits come at increasing levels)
+            // Levels INSIDE the patch: the cone's visits in trace order, ordered by the same read-after-write,
+            // write-after-read and write-after-write rules as the layer's levels but among themselves only --
+            // a patch does not wait for levels in which nothing of its cone happens.  Packed increasing.
             std::sort(marked.begin(), marked.end());
+            llw.assign((size_t)entries, 0);
+            llr.assign((size_t)entries, 0);
             int32_t nlev = 0;
             for (int32_t x : marked) {
                 const int32_t i = (int32_t)tr.site[(size_t)x];
-                uint32_t &v = out.entry_vis[(size_t)(e0 + slot_of[(size_t)i])];
+                const int32_t si = slot_of[(size_t)i];
+                const int32_t u1 = up1[i], u2 = up2[i];
+                const int32_t c1 = (dir.layer_of[(size_t)u1] == layer && in_patch[(size_t)u1] == patch_id) ? slot_of[(size_t)u1] : -1;
+                const int32_t c2 = (dir.layer_of[(size_t)u2] == layer && in_patch[(size_t)u2] == patch_id) ? slot_of[(size_t)u2] : -1;
+                int32_t lv = std::max(llw[(size_t)si], llr[(size_t)si]);
+                if (c1 >= 0) lv = std::max(lv, llw[(size_t)c1]);
+                if (c2 >= 0) lv = std::max(lv, llw[(size_t)c2]);
+                lv += 1;
+                if (c1 >= 0) llr[(size_t)c1] = std::max(llr[(size_t)c1], lv);
+                if (c2 >= 0) llr[(size_t)c2] = std::max(llr[(size_t)c2], lv);
+                llw[(size_t)si] = lv;
+                llr[(size_t)si] = 0;
+                uint32_t &v = out.entry_vis[(size_t)(e0 + si)];
                 int sh = 0;
                 while (sh < 32 && ((v >> sh) & 0xFFu)) sh += 8;
-                v |= (uint32_t)tr.lv[(size_t)x] << sh;
-                nlev = std::max<int32_t>(nlev, tr.lv[(size_t)x]);
+                v |= (uint32_t)lv << sh;
+                nlev = std::max(nlev, lv);
             }
             for (int64_t e = e0; e < (int64_t)out.entry_pos.size(); e++) {
                 const int32_t i = dir.store[(size_t)out.entry_pos[(size_t)e]];
                 uint32_t l[2];
                 for (int q = 0; q < 2; q++) {
                     const int32_t u = q == 0 ? up1[i] : up2[i];
-                    l[q] = (dir.layer_of[(size_t)u] == layer && slot_patch[(size_t)u] == patch_id) ? (uint32_t)slot_of[(size_t)u]
-                                                                                                     : 0xFFFFu;
+                    l[q] = (dir.layer_of[(size_t)u] == layer && in_patch[(size_t)u] == patch_id) ? (uint32_t)slot_of[(size_t)u]
+                                                                                                  : 0xFFFFu;
                 }
                 out.entry_loc[(size_t)e] = l[0] | (l[1] << 16);
             }
-            out.patch_own_lo.push_back(rg.lo);
-            out.patch_own_cnt.push_back(rg.cnt);
+            out.patch_own_lo.push_back(own_lo);
+            out.patch_own_cnt.push_back(own_cnt);
             out.patch_ent_off.push_back(e0);
             out.patch_nlev.push_back(nlev);
             out.n_visits += (int64_t)marked.size();

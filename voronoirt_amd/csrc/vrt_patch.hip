@@ -28,8 +28,10 @@ struct PatchArgs {
     TileArgs ta;              // n, nlam, alpha_mode, angle_dir, lay, nlayers, S, alpha, alpha_angle, I (pair planes)
     int npair;                // ceil(nlam / 2)
     int layer;                // 1-based BFS layer being solved
-    int ngrp;                 // wavelength-pair groups per work item
+    int ngrp;                 // workgroups per work item: each walks ppw wavelength pairs
+    int ppw;
     int stride;               // tile slots per pair plane (> largest entry count: + the zero slot)
+    int cap;                  // entries per patch at most (K * NT): length of the LDS table arrays
     const int32_t *work;      // this launch's work list: patch index per (slot, XCD), -1 = padding
     const int4 *rec;          // per patch: first entry, entries, first owned storage position, owned sites
     const int2 *rec2;         // per patch: in-layer levels, active angle
@@ -66,8 +68,71 @@ int launch_patch_entries(vrt_plan *p, int a, int64_t first, int64_t count)
     return VRT_OK;
 }
 
-// T: storage type of S, α, I; K entries per thread; Q wavelength pairs per workgroup; NT threads
-template <typename T, int K, int Q, int NT>
+// exp(-x) for 5e-4 <= x <= 50 to ~2e-13 relative (the parity contract is 1e-10): Cody-Waite reduction as
+// exp_neg (vrt_device.h), Taylor to r^10/10! (remainder 0.3466^11/11! = 2e-13)
+__device__ __forceinline__ double exp_neg10(double x)
+{
+    const double t = -x;
+    const double kf = rint(t * 1.4426950408889634074);
+    double r = fma(-kf, 6.93147180369123816490e-01, t);
+    r = fma(-kf, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 3628800.0;
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+
+// linear_weights (functions.jl:484-500) without control flow: the branches are cheap next to the one
+// exponential they share, and a straight-line body lets the compiler keep every load of an entry in flight
+// together (with branches it waits for the opacities before it even issues the source-function loads).
+// The thick branch (Δτ > 50: e = 0, a = 1/Δτ, b = 1 - a) needs no select for a and b: with e = exp(-50) = 2e-22
+// the general formulas round to exactly those values; only e itself is set to 0.
+__device__ __forceinline__ void lin_weights_sel(double dtau, double &a, double &b, double &e)
+{
+    double rc = __builtin_amdgcn_rcp(dtau);                 // only consumed when dtau >= 5e-4
+    rc = fma(fma(-dtau, rc, 1.0), rc, rc);                  // v_rcp_f64 is good to ~2^-23: one Newton step -> 1e-14
+    const double ee = exp_neg10(fmin(fmax(dtau, 5e-4), 50.0));
+    const double a_mid = (1.0 - ee) * rc - ee, b_mid = 1.0 - a_mid - ee;
+    const double e_thin = 1.0 - dtau + 0.5 * (dtau * dtau);
+    const double a_thin = dtau * (0.5 - dtau * (1.0 / 3.0)), b_thin = dtau * (0.5 - dtau * (1.0 / 6.0));
+    const bool thin = dtau < 5e-4;
+    e = thin ? e_thin : (dtau > 50.0 ? 0.0 : ee);
+    a = thin ? a_thin : a_mid;
+    b = thin ? b_thin : b_mid;
+}
+
+// one upwind's share of a visit: t = ((e I_u + a S_u) + b S_c) w with I_u gathered as 0 unless the upwind lies
+// in an earlier layer; g = e wg, wg = w if the upwind lies in the site's own layer, else 0
+__device__ __forceinline__ void upwind_term_sel(double r, double w, double wg, double a_c, double a_u, double S_c,
+                                                double S_u, double I_u, double &t, double &g)
+{
+    double ca, cb, ce;
+    lin_weights_sel(r * (a_c + a_u) / 2.0, ca, cb, ce);            // trapezoidal, functions.jl:393
+    t = ((ce * I_u + ca * S_u) + cb * S_c) * w;
+    g = ce * wg;
+}
+
+// wavelength pair `idx` of a plane: 32-bit byte offset from a wave-uniform base (planes are < 4 GiB: n < 2^28),
+// so the load takes the saddr + voffset form -- one address VGPR, no 64-bit vector arithmetic
+template <typename T2>
+__device__ __forceinline__ double2 ldpair(const T2 *base, int idx)
+{
+    const unsigned off = (unsigned)idx * (unsigned)sizeof(T2);
+    return to_d2(*reinterpret_cast<const T2 *>(reinterpret_cast<const char *>(base) + off));
+}
+
+// T: storage type of S, α, I; AM: alpha mode (VRT_ALPHA_SITE, _SITE_LAM, _ANGLE_SITE_LAM); K entries per thread;
+// Q wavelength pairs solved at a time; NT threads.  A workgroup walks `ppw` wavelength pairs with ONE read of its
+// patch's entry table, Q pairs at a time.
+template <typename T, int AM, int K, int Q, int NT>
 __global__ void __launch_bounds__(NT)
 k_patch_solve(PatchArgs pa)
 {
@@ -82,8 +147,8 @@ k_patch_solve(PatchArgs pa)
     const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
     const int item = pa.work[sj * 8 + x];
     if (item < 0) return;
-    const int q0 = grp * Q;
-    if (q0 >= pa.npair) return;
+    const int qbeg = grp * pa.ppw, qend = min(pa.npair, qbeg + pa.ppw);
+    if (qbeg >= qend) return;
     const int4 rec = pa.rec[item];
     const int2 rec2 = pa.rec2[item];
     const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
@@ -93,139 +158,155 @@ k_patch_solve(PatchArgs pa)
     const int64_t n = ta.n;
     const int stride = pa.stride;
 
-    int pos[K], u1[K], u2[K];
-    uint32_t vis[K], loc[K];
+    // ---- the patch's entry table, kept for every pair of this workgroup: each thread parks the entries it
+    // owns in LDS slots only it ever reads (a register file extension: no barrier, no bank conflict) -- the
+    // table costs no registers across the gather and level phases, which decides how many workgroups a CU holds
+    double *s_w1 = reinterpret_cast<double *>(ptile + Q * stride);
+    double *s_w2 = s_w1 + pa.cap, *s_r1 = s_w2 + pa.cap, *s_r2 = s_r1 + pa.cap;
+    int *s_pos = reinterpret_cast<int *>(s_r2 + pa.cap);
+    int *s_u1 = s_pos + pa.cap, *s_u2 = s_u1 + pa.cap;
+    uint32_t *s_vis = reinterpret_cast<uint32_t *>(s_u2 + pa.cap), *s_loc = s_vis + pa.cap;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int i = tid + k * NT;
         const bool ok = i < n_ent;
         const int e = ent_off + (ok ? i : n_ent - 1);
-        pos[k] = pa.e_pos[e];
-        u1[k] = pa.e_u1[e];
-        u2[k] = pa.e_u2[e];
-        loc[k] = pa.e_loc[e];
-        vis[k] = ok ? pa.e_vis[e] : 0u;
-    }
-    double2 c[K][Q], g1[K][Q], g2[K][Q];
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int i = tid + k * NT;
-        const int e = ent_off + (i < n_ent ? i : n_ent - 1);
-        const double w1 = pa.e_w1[e], w2 = pa.e_w2[e], r1 = pa.e_r1[e], r2 = pa.e_r2[e];
-        const int p = pos[k], v1 = u1[k], v2 = u2[k];
-        const bool early1 = v1 < lo, in1 = (v1 >= lo) & (v1 < hi);     // else: later layer / perm[n] reads 0
-        const bool early2 = v2 < lo, in2 = (v2 >= lo) & (v2 < hi);
-        const int i1 = min(v1, lo - 1), i2 = min(v2, lo - 1);          // only used when early (earlier layer: final)
-#pragma unroll
-        for (int qi = 0; qi < Q; qi++) {
-            const int q = q0 + qi;
-            if (q >= pa.npair) {                                       // (wave-uniform) last, partial group
-                c[k][qi] = g1[k][qi] = g2[k][qi] = make_double2(0.0, 0.0);
-                continue;
-            }
-            const T2 *__restrict__ S = reinterpret_cast<const T2 *>(ta.S[d]) + (size_t)q * (size_t)n;
-            const T2 *__restrict__ I = reinterpret_cast<const T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)n;
-            double2 a_c, a_1, a_2;
-            if (ta.alpha_mode == VRT_ALPHA_SITE) {                     // one opacity per site for every λ
-                const T *__restrict__ Al = reinterpret_cast<const T *>(ta.alpha[d]);
-                const double c0 = Al[p], c1 = Al[v1], c2 = Al[v2];
-                a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
-            } else {
-                const T2 *__restrict__ Al =
-                    ta.alpha_mode == VRT_ALPHA_SITE_LAM
-                        ? reinterpret_cast<const T2 *>(ta.alpha[d]) + (size_t)q * (size_t)n
-                        : reinterpret_cast<const T2 *>(ta.alpha_angle) + ((size_t)a * pa.npair + q) * (size_t)n;
-                a_c = ld2(Al, p); a_1 = ld2(Al, v1); a_2 = ld2(Al, v2);
-            }
-            const double2 S_c = ld2(S, p), S_1 = ld2(S, v1), S_2 = ld2(S, v2);
-            const double2 I_1 = ld2(I, i1), I_2 = ld2(I, i2);
-            double t1, t2;
-            upwind_term(r1, w1, a_c.x, a_1.x, S_c.x, S_1.x, I_1.x, early1, in1, t1, g1[k][qi].x);
-            upwind_term(r2, w2, a_c.x, a_2.x, S_c.x, S_2.x, I_2.x, early2, in2, t2, g2[k][qi].x);
-            c[k][qi].x = t1 + t2;
-            upwind_term(r1, w1, a_c.y, a_1.y, S_c.y, S_1.y, I_1.y, early1, in1, t1, g1[k][qi].y);
-            upwind_term(r2, w2, a_c.y, a_2.y, S_c.y, S_2.y, I_2.y, early2, in2, t2, g2[k][qi].y);
-            c[k][qi].y = t1 + t2;
-        }
-    }
-    // ---- the patch's Gauss-Seidel levels on the LDS tile: plane qi at ptile + qi * stride ----------------
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int i = tid + k * NT;
-        if (i < n_ent) {
-#pragma unroll
-            for (int qi = 0; qi < Q; qi++) ptile[qi * stride + i] = make_double2(0.0, 0.0);   // I = zero(S), :23
-        }
+        s_pos[i] = pa.e_pos[e];
+        s_u1[i] = pa.e_u1[e];
+        s_u2[i] = pa.e_u2[e];
+        s_vis[i] = ok ? pa.e_vis[e] : 0u;
         // an upwind outside the cone reads the zero slot (coupling x a finite 0)
-        const uint32_t l1 = loc[k] & 0xFFFFu, l2 = loc[k] >> 16;
-        loc[k] = (l1 == 0xFFFFu ? (uint32_t)n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)n_ent : l2) << 16);
+        const uint32_t lc = pa.e_loc[e], l1 = lc & 0xFFFFu, l2 = lc >> 16;
+        s_loc[i] = (l1 == 0xFFFFu ? (uint32_t)n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)n_ent : l2) << 16);
+        s_w1[i] = pa.e_w1[e]; s_w2[i] = pa.e_w2[e]; s_r1[i] = pa.e_r1[e]; s_r2[i] = pa.e_r2[e];
     }
     if (tid == 0) {
 #pragma unroll
-        for (int qi = 0; qi < Q; qi++) ptile[qi * stride + n_ent] = make_double2(0.0, 0.0);
+        for (int qi = 0; qi < Q; qi++) ptile[qi * stride + n_ent] = make_double2(0.0, 0.0);   // the zero slot
     }
-    __syncthreads();
-    for (int t = 1; t <= nlev; t++) {
+    for (int q0 = qbeg; q0 < qend; q0 += Q) {
+        // ---- integration coefficients of the entries for pairs q0 .. q0 + Q - 1 --------------------------
+        double2 c[K][Q], g1[K][Q], g2[K][Q];
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if ((vis[k] & 0xFFu) == (uint32_t)t) {          // a site's visits come at increasing levels
-                const uint32_t l1 = loc[k] & 0xFFFFu, l2 = loc[k] >> 16;
+            const int i = tid + k * NT;
+            const int p = s_pos[i], v1 = s_u1[i], v2 = s_u2[i];
+            // the intensity of an upwind counts when it lies in an EARLIER layer (final); an upwind in this
+            // layer enters through the tile, one in a later layer reads 0 (:23): those gather the never-visited
+            // site perm[n] at storage position n - 1, whose intensity is 0 in every plane
+            const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
+            const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
 #pragma unroll
-                for (int qi = 0; qi < Q; qi++) {
-                    const double2 xv = ptile[qi * stride + l1], yv = ptile[qi * stride + l2];
-                    double2 r;
-                    r.x = c[k][qi].x + g1[k][qi].x * xv.x + g2[k][qi].x * yv.x;
-                    r.y = c[k][qi].y + g1[k][qi].y * xv.y + g2[k][qi].y * yv.y;
-                    ptile[qi * stride + tid + k * NT] = r;
+            for (int qi = 0; qi < Q; qi++) {
+                const int q = min(q0 + qi, qend - 1);                      // a partial last step repeats its last pair
+                const T2 *__restrict__ S = reinterpret_cast<const T2 *>(ta.S[d]) + (size_t)q * (size_t)n;
+                const T2 *__restrict__ I = reinterpret_cast<const T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)n;
+                // every load of the entry first (8 independent 16-byte gathers in flight), arithmetic after
+                double2 a_c, a_1, a_2;
+                if constexpr (AM == VRT_ALPHA_SITE) {                      // one opacity per site for every λ
+                    const T *__restrict__ Al = reinterpret_cast<const T *>(ta.alpha[d]);
+                    const double c0 = Al[p], c1 = Al[v1], c2 = Al[v2];
+                    a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
+                } else {
+                    const T2 *__restrict__ Al =
+                        AM == VRT_ALPHA_SITE_LAM
+                            ? reinterpret_cast<const T2 *>(ta.alpha[d]) + (size_t)q * (size_t)n
+                            : reinterpret_cast<const T2 *>(ta.alpha_angle) + ((size_t)a * pa.npair + q) * (size_t)n;
+                    a_c = ldpair(Al, p); a_1 = ldpair(Al, v1); a_2 = ldpair(Al, v2);
                 }
-                vis[k] >>= 8;
+                const double2 S_c = ldpair(S, p), S_1 = ldpair(S, v1), S_2 = ldpair(S, v2);
+                const double2 I_1 = ldpair(I, i1), I_2 = ldpair(I, i2);
+                const double w1 = s_w1[i], w2 = s_w2[i], r1 = s_r1[i], r2 = s_r2[i];
+                const double wg1 = in1 ? w1 : 0.0, wg2 = in2 ? w2 : 0.0;
+                double t1, t2;
+                upwind_term_sel(r1, w1, wg1, a_c.x, a_1.x, S_c.x, S_1.x, I_1.x, t1, g1[k][qi].x);
+                upwind_term_sel(r2, w2, wg2, a_c.x, a_2.x, S_c.x, S_2.x, I_2.x, t2, g2[k][qi].x);
+                c[k][qi].x = t1 + t2;
+                upwind_term_sel(r1, w1, wg1, a_c.y, a_1.y, S_c.y, S_1.y, I_1.y, t1, g1[k][qi].y);
+                upwind_term_sel(r2, w2, wg2, a_c.y, a_2.y, S_c.y, S_2.y, I_2.y, t2, g2[k][qi].y);
+                c[k][qi].y = t1 + t2;
+            }
+        }
+        // ---- the patch's Gauss-Seidel levels on the LDS tile: plane qi at ptile + qi * stride ----------------
+        // (a thread only ever WRITES its own slots; the previous step's level loop ended with a barrier, so
+        // nobody still reads them)
+        uint32_t vis[K], loc[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            vis[k] = s_vis[tid + k * NT];
+            loc[k] = s_loc[tid + k * NT];
+            if (tid + k * NT < n_ent) {
+#pragma unroll
+                for (int qi = 0; qi < Q; qi++) ptile[qi * stride + tid + k * NT] = make_double2(0.0, 0.0);   // I = zero(S), :23
             }
         }
         __syncthreads();
-    }
-    // ---- final intensities of the owned sites (entries 0 .. own_cnt-1 = positions own_lo ..) -------------
+        for (int t = 1; t <= nlev; t++) {
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int i = tid + k * NT;
-        if (i < own_cnt) {
+            for (int k = 0; k < K; k++) {
+                if ((vis[k] & 0xFFu) == (uint32_t)t) {          // a site's visits come at increasing levels
+                    const uint32_t l1 = loc[k] & 0xFFFFu, l2 = loc[k] >> 16;
 #pragma unroll
-            for (int qi = 0; qi < Q; qi++) {
-                const int q = q0 + qi;
-                if (q < pa.npair) {
-                    T2 *I = reinterpret_cast<T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)n;
-                    I[own_lo + i] = from_d2<T>(ptile[qi * stride + i]);
+                    for (int qi = 0; qi < Q; qi++) {
+                        const double2 xv = ptile[qi * stride + l1], yv = ptile[qi * stride + l2];
+                        double2 r;
+                        r.x = c[k][qi].x + g1[k][qi].x * xv.x + g2[k][qi].x * yv.x;
+                        r.y = c[k][qi].y + g1[k][qi].y * xv.y + g2[k][qi].y * yv.y;
+                        ptile[qi * stride + tid + k * NT] = r;
+                    }
+                    vis[k] >>= 8;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- final intensities of the owned sites (entries 0 .. own_cnt-1 = positions own_lo ..; own slots) ----
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int i = tid + k * NT;
+            if (i < own_cnt) {
+#pragma unroll
+                for (int qi = 0; qi < Q; qi++) {
+                    const int q = q0 + qi;
+                    if (q < qend) {
+                        T2 *I = reinterpret_cast<T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)n;
+                        const unsigned off = (unsigned)(own_lo + i) * (unsigned)sizeof(T2);
+                        *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + off) = from_d2<T>(ptile[qi * stride + i]);
+                    }
                 }
             }
         }
     }
 }
 
-template <typename T, int K, int Q, int NT>
-static void launch_one(dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa)
-{
-    hipLaunchKernelGGL((k_patch_solve<T, K, Q, NT>), grid, dim3(NT), lds, st, pa);
-}
+// the instantiated launch shapes (entries per thread, pairs at a time, threads)
+#define VRT_PATCH_SHAPES(X) \
+    X(1, 1, 256) X(1, 1, 512) X(1, 1, 1024) X(2, 1, 256) X(2, 1, 512) X(1, 2, 256) X(1, 2, 512) X(1, 2, 1024) X(2, 2, 512)
 
-template <typename T>
+template <typename T, int AM>
 static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa)
 {
 #define VRT_PATCH_CASE(k, q, nt) \
-    if (K == k && Q == q && NT == nt) { launch_one<T, k, q, nt>(grid, lds, st, pa); return VRT_OK; }
-    VRT_PATCH_CASE(1, 1, 512) VRT_PATCH_CASE(1, 2, 512) VRT_PATCH_CASE(1, 4, 512)
-    VRT_PATCH_CASE(2, 1, 512) VRT_PATCH_CASE(2, 2, 512)
-    VRT_PATCH_CASE(4, 1, 512)
-    VRT_PATCH_CASE(1, 2, 1024) VRT_PATCH_CASE(1, 4, 1024)
-    VRT_PATCH_CASE(2, 1, 256) VRT_PATCH_CASE(2, 2, 256) VRT_PATCH_CASE(4, 1, 256)
+    if (K == k && Q == q && NT == nt) { hipLaunchKernelGGL((k_patch_solve<T, AM, k, q, nt>), grid, dim3(nt), lds, st, pa); return VRT_OK; }
+    VRT_PATCH_SHAPES(VRT_PATCH_CASE)
 #undef VRT_PATCH_CASE
     return fail(VRT_EINVAL, "no patch kernel for this (entries per thread, pairs, threads) shape");
 }
 
+template <typename T>
+static int launch_mode(int am, int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa)
+{
+    switch (am) {
+    case VRT_ALPHA_SITE: return launch_shape<T, VRT_ALPHA_SITE>(K, Q, NT, grid, lds, st, pa);
+    case VRT_ALPHA_SITE_LAM: return launch_shape<T, VRT_ALPHA_SITE_LAM>(K, Q, NT, grid, lds, st, pa);
+    default: return launch_shape<T, VRT_ALPHA_ANGLE_SITE_LAM>(K, Q, NT, grid, lds, st, pa);
+    }
+}
+
 bool patch_shape_exists(int K, int Q, int NT)
 {
-    static const int shapes[][3] = {{1, 1, 512}, {1, 2, 512}, {1, 4, 512}, {2, 1, 512}, {2, 2, 512}, {4, 1, 512},
-                                    {1, 2, 1024}, {1, 4, 1024}, {2, 1, 256}, {2, 2, 256}, {4, 1, 256}};
-    for (const auto &s : shapes)
-        if (s[0] == K && s[1] == Q && s[2] == NT) return true;
+#define VRT_PATCH_CASE(k, q, nt) if (K == k && Q == q && NT == nt) return true;
+    VRT_PATCH_SHAPES(VRT_PATCH_CASE)
+#undef VRT_PATCH_CASE
     return false;
 }
 
@@ -274,6 +355,8 @@ int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angl
 int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, int group, int Q, hipStream_t st,
                        bool f32)
 {
+    // workgroups per launch: enough to fill the chip twice over with both direction streams running
+    static const int target_wgs = std::getenv("VRT_PATCH_TARGET") ? std::max(1, std::atoi(std::getenv("VRT_PATCH_TARGET"))) : 512;
     const int maxL = p->tile_max_layers;
     const size_t wo = (size_t)group * (size_t)(maxL + 2) + (size_t)layer;
     const int64_t w0 = p->patch_work_off[wo], w1 = p->patch_work_off[wo + 1];
@@ -282,8 +365,15 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     pa.ta = ta;
     pa.npair = npair;
     pa.layer = layer;
-    pa.ngrp = (npair + Q - 1) / Q;
+    {
+        const int64_t items = w1 - w0;                         // work-list slots (a few of them padding)
+        const int steps_all = (npair + Q - 1) / Q;             // Q pairs at a time
+        const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(steps_all, (target_wgs + items - 1) / items));
+        pa.ppw = (steps_all + nsplit - 1) / nsplit * Q;
+        pa.ngrp = (npair + pa.ppw - 1) / pa.ppw;
+    }
     pa.stride = p->patch_cap + 1;
+    pa.cap = p->patch_cap;
     pa.work = p->d_patch_work + w0;
     pa.rec = p->d_patch_rec;
     pa.rec2 = p->d_patch_rec2;
@@ -291,9 +381,9 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     pa.e_vis = p->e_vis; pa.e_loc = p->e_loc;
     pa.e_w1 = p->e_w1; pa.e_w2 = p->e_w2; pa.e_r1 = p->e_r1; pa.e_r2 = p->e_r2;
     const dim3 grid((unsigned)((w1 - w0) * pa.ngrp));
-    const size_t lds = (size_t)Q * (size_t)pa.stride * sizeof(double2);
-    const int rc = f32 ? launch_shape<float>(p->patch_K, Q, p->patch_NT, grid, lds, st, pa)
-                       : launch_shape<double>(p->patch_K, Q, p->patch_NT, grid, lds, st, pa);
+    const size_t lds = (size_t)Q * (size_t)pa.stride * sizeof(double2) + (size_t)pa.cap * (4 * sizeof(double) + 5 * sizeof(int32_t));
+    const int rc = f32 ? launch_mode<float>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa)
+                       : launch_mode<double>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa);
     return rc;
 }
 
