@@ -32,6 +32,8 @@ struct PatchArgs {
     int ppw;
     int stride;               // tile slots per pair plane (> largest entry count: + the zero slot)
     int cap;                  // entries per patch at most (K * NT): length of the LDS table arrays
+    int dbg;                  // timing diagnostics (-DVRT_DIAG build only, WRONG results): 1 no levels, 2 gathers ->
+                              //   coalesced centre reads, 4 no weights arithmetic, 8 no stores
     const int32_t *work;      // this launch's work list: patch index per (slot, XCD), -1 = padding
     const int4 *rec;          // per patch: first entry, entries, first owned storage position, owned sites
     const int2 *rec2;         // per patch: in-layer levels, active angle
@@ -90,34 +92,77 @@ __device__ __forceinline__ double exp_neg10(double x)
     return ldexp(p, (int)kf);
 }
 
-// linear_weights (functions.jl:484-500) without control flow: the branches are cheap next to the one
-// exponential they share, and a straight-line body lets the compiler keep every load of an entry in flight
-// together (with branches it waits for the opacities before it even issues the source-function loads).
+// The kernel is bound by its fp64 arithmetic (two exponentials and a dozen weights per site, angle and
+// wavelength; MI355X issues a wave's fp64 instruction in 4 cycles), so the weights are written with explicit
+// fused multiply-adds -- a third fewer instructions than the reference's expression order, results within a few
+// ulp of it (the parity contract is 1e-10; the build-wide -ffp-contract=off stays for the neighbour search).
+//
+// linear_weights (functions.jl:484-500) without control flow inside a lane; `MODE` is wave-uniform:
+//   0  no lane has 5e-4 <= Δτ <= 50: thin or thick only, no exponential (optically thin upper layers and
+//      thick bottom layers are most of a stratified atmosphere; a wave's lanes are neighbouring sites of a layer)
+//   1  no lane is thin: no Taylor branch
+//   2  general
 // The thick branch (Δτ > 50: e = 0, a = 1/Δτ, b = 1 - a) needs no select for a and b: with e = exp(-50) = 2e-22
 // the general formulas round to exactly those values; only e itself is set to 0.
-__device__ __forceinline__ void lin_weights_sel(double dtau, double &a, double &b, double &e)
+template <int MODE>
+__device__ __forceinline__ void lin_weights_fma(double dtau, double &a, double &b, double &e)
 {
     double rc = __builtin_amdgcn_rcp(dtau);                 // only consumed when dtau >= 5e-4
     rc = fma(fma(-dtau, rc, 1.0), rc, rc);                  // v_rcp_f64 is good to ~2^-23: one Newton step -> 1e-14
-    const double ee = exp_neg10(fmin(fmax(dtau, 5e-4), 50.0));
-    const double a_mid = (1.0 - ee) * rc - ee, b_mid = 1.0 - a_mid - ee;
-    const double e_thin = 1.0 - dtau + 0.5 * (dtau * dtau);
-    const double a_thin = dtau * (0.5 - dtau * (1.0 / 3.0)), b_thin = dtau * (0.5 - dtau * (1.0 / 6.0));
+    double e_thin = 0.0, a_thin = 0.0, b_thin = 0.0;
+    if (MODE != 1) {
+        e_thin = fma(dtau, fma(0.5, dtau, -1.0), 1.0);
+        a_thin = dtau * fma(dtau, -1.0 / 3.0, 0.5);
+        b_thin = dtau * fma(dtau, -1.0 / 6.0, 0.5);
+    }
     const bool thin = dtau < 5e-4;
-    e = thin ? e_thin : (dtau > 50.0 ? 0.0 : ee);
-    a = thin ? a_thin : a_mid;
-    b = thin ? b_thin : b_mid;
+    if (MODE == 0) {
+        e = thin ? e_thin : 0.0;
+        a = thin ? a_thin : rc;
+        b = thin ? b_thin : 1.0 - rc;
+        return;
+    }
+    const double ee = exp_neg10(fmin(dtau, 50.0));
+    const double a_mid = fma(1.0 - ee, rc, -ee), b_mid = (1.0 - a_mid) - ee;
+    const double e_mid = dtau > 50.0 ? 0.0 : ee;
+    if (MODE == 1) {
+        e = e_mid; a = a_mid; b = b_mid;
+    } else {
+        e = thin ? e_thin : e_mid;
+        a = thin ? a_thin : a_mid;
+        b = thin ? b_thin : b_mid;
+    }
 }
 
-// one upwind's share of a visit: t = ((e I_u + a S_u) + b S_c) w with I_u gathered as 0 unless the upwind lies
-// in an earlier layer; g = e wg, wg = w if the upwind lies in the site's own layer, else 0
-__device__ __forceinline__ void upwind_term_sel(double r, double w, double wg, double a_c, double a_u, double S_c,
-                                                double S_u, double I_u, double &t, double &g)
+// one wavelength of an entry: both upwinds' shares of a visit, t_r = ((e_r I_ur + a_r S_ur) + b_r S_c) w_r with
+// I_ur gathered as 0 unless upwind r lies in an earlier layer; g_r = e_r wg_r, wg_r = w_r if upwind r lies in the
+// site's own layer, else 0.  c = t_1 + t_2.  dt_r = r_r (α_c + α_ur) / 2 (trapezoidal, functions.jl:393).
+template <int MODE>
+__device__ __forceinline__ void entry_terms(double dt1, double dt2, double w1, double w2, double wg1, double wg2,
+                                            double S_c, double S_1, double S_2, double I_1, double I_2, double &c,
+                                            double &g1, double &g2)
 {
-    double ca, cb, ce;
-    lin_weights_sel(r * (a_c + a_u) / 2.0, ca, cb, ce);            // trapezoidal, functions.jl:393
-    t = ((ce * I_u + ca * S_u) + cb * S_c) * w;
-    g = ce * wg;
+    double ca1, cb1, ce1, ca2, cb2, ce2;
+    lin_weights_fma<MODE>(dt1, ca1, cb1, ce1);
+    lin_weights_fma<MODE>(dt2, ca2, cb2, ce2);
+    const double t1 = fma(cb1, S_c, fma(ce1, I_1, ca1 * S_1)) * w1;
+    const double t2 = fma(cb2, S_c, fma(ce2, I_2, ca2 * S_2)) * w2;
+    c = t1 + t2;
+    g1 = ce1 * wg1;
+    g2 = ce2 * wg2;
+}
+
+// the same with the wave-uniform choice of MODE from the two optical depths of every lane
+__device__ __forceinline__ void entry_lambda(double rh1, double rh2, double w1, double w2, double wg1, double wg2,
+                                             double a_c, double a_1, double a_2, double S_c, double S_1, double S_2,
+                                             double I_1, double I_2, double &c, double &g1, double &g2)
+{
+    const double d1 = rh1 * (a_c + a_1), d2 = rh2 * (a_c + a_2);
+    const bool mid = ((d1 >= 5e-4) & (d1 <= 50.0)) | ((d2 >= 5e-4) & (d2 <= 50.0));
+    const bool thin = (d1 < 5e-4) | (d2 < 5e-4);
+    if (__ballot(mid) == 0ull) entry_terms<0>(d1, d2, w1, w2, wg1, wg2, S_c, S_1, S_2, I_1, I_2, c, g1, g2);
+    else if (__ballot(thin) == 0ull) entry_terms<1>(d1, d2, w1, w2, wg1, wg2, S_c, S_1, S_2, I_1, I_2, c, g1, g2);
+    else entry_terms<2>(d1, d2, w1, w2, wg1, wg2, S_c, S_1, S_2, I_1, I_2, c, g1, g2);
 }
 
 // wavelength pair `idx` of a plane: 32-bit byte offset from a wave-uniform base (planes are < 4 GiB: n < 2^28),
@@ -132,8 +177,13 @@ __device__ __forceinline__ double2 ldpair(const T2 *base, int idx)
 // T: storage type of S, α, I; AM: alpha mode (VRT_ALPHA_SITE, _SITE_LAM, _ANGLE_SITE_LAM); K entries per thread;
 // Q wavelength pairs solved at a time; NT threads.  A workgroup walks `ppw` wavelength pairs with ONE read of its
 // patch's entry table, Q pairs at a time.
+#ifdef VRT_PATCH_WPE            // experiments: force the register budget of that many waves per SIMD
+#define VRT_WPE_ATTR __attribute__((amdgpu_waves_per_eu(VRT_PATCH_WPE, VRT_PATCH_WPE)))
+#else
+#define VRT_WPE_ATTR
+#endif
 template <typename T, int AM, int K, int Q, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT) VRT_WPE_ATTR
 k_patch_solve(PatchArgs pa)
 {
     typedef typename Pair<T>::type T2;
@@ -152,7 +202,8 @@ k_patch_solve(PatchArgs pa)
     const int4 rec = pa.rec[item];
     const int2 rec2 = pa.rec2[item];
     const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
-    const int nlev = rec2.x, a = rec2.y;
+    const int dbg = kDiag ? pa.dbg : 0;
+    const int nlev = (dbg & 1) ? 0 : rec2.x, a = rec2.y;
     const int d = ta.angle_dir[a];
     const int lo = ta.lay[d][pa.layer - 1], hi = ta.lay[d][pa.layer];
     const int64_t n = ta.n;
@@ -190,7 +241,9 @@ k_patch_solve(PatchArgs pa)
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const int i = tid + k * NT;
-            const int p = s_pos[i], v1 = s_u1[i], v2 = s_u2[i];
+            const int p = s_pos[i];
+            int v1 = s_u1[i], v2 = s_u2[i];
+            if (dbg & 2) { v1 = p; v2 = p; }
             // the intensity of an upwind counts when it lies in an EARLIER layer (final); an upwind in this
             // layer enters through the tile, one in a later layer reads 0 (:23): those gather the never-visited
             // site perm[n] at storage position n - 1, whose intensity is 0 in every plane
@@ -218,13 +271,16 @@ k_patch_solve(PatchArgs pa)
                 const double2 I_1 = ldpair(I, i1), I_2 = ldpair(I, i2);
                 const double w1 = s_w1[i], w2 = s_w2[i], r1 = s_r1[i], r2 = s_r2[i];
                 const double wg1 = in1 ? w1 : 0.0, wg2 = in2 ? w2 : 0.0;
-                double t1, t2;
-                upwind_term_sel(r1, w1, wg1, a_c.x, a_1.x, S_c.x, S_1.x, I_1.x, t1, g1[k][qi].x);
-                upwind_term_sel(r2, w2, wg2, a_c.x, a_2.x, S_c.x, S_2.x, I_2.x, t2, g2[k][qi].x);
-                c[k][qi].x = t1 + t2;
-                upwind_term_sel(r1, w1, wg1, a_c.y, a_1.y, S_c.y, S_1.y, I_1.y, t1, g1[k][qi].y);
-                upwind_term_sel(r2, w2, wg2, a_c.y, a_2.y, S_c.y, S_2.y, I_2.y, t2, g2[k][qi].y);
-                c[k][qi].y = t1 + t2;
+                const double rh1 = 0.5 * r1, rh2 = 0.5 * r2;               // exact: r (α_c + α_u) / 2 = (r / 2)(α_c + α_u)
+                if (dbg & 4) {
+                    c[k][qi] = make_double2(a_c.x + S_c.x + I_1.x + a_1.x + S_1.x, a_c.y + S_c.y + I_2.y + a_2.y + S_2.y);
+                    g1[k][qi] = make_double2(w1, w2); g2[k][qi] = make_double2(r1, r2);
+                    continue;
+                }
+                entry_lambda(rh1, rh2, w1, w2, wg1, wg2, a_c.x, a_1.x, a_2.x, S_c.x, S_1.x, S_2.x, I_1.x, I_2.x,
+                             c[k][qi].x, g1[k][qi].x, g2[k][qi].x);
+                entry_lambda(rh1, rh2, w1, w2, wg1, wg2, a_c.y, a_1.y, a_2.y, S_c.y, S_1.y, S_2.y, I_1.y, I_2.y,
+                             c[k][qi].y, g1[k][qi].y, g2[k][qi].y);
             }
         }
         // ---- the patch's Gauss-Seidel levels on the LDS tile: plane qi at ptile + qi * stride ----------------
@@ -250,8 +306,8 @@ k_patch_solve(PatchArgs pa)
                     for (int qi = 0; qi < Q; qi++) {
                         const double2 xv = ptile[qi * stride + l1], yv = ptile[qi * stride + l2];
                         double2 r;
-                        r.x = c[k][qi].x + g1[k][qi].x * xv.x + g2[k][qi].x * yv.x;
-                        r.y = c[k][qi].y + g1[k][qi].y * xv.y + g2[k][qi].y * yv.y;
+                        r.x = fma(g2[k][qi].x, yv.x, fma(g1[k][qi].x, xv.x, c[k][qi].x));
+                        r.y = fma(g2[k][qi].y, yv.y, fma(g1[k][qi].y, xv.y, c[k][qi].y));
                         ptile[qi * stride + tid + k * NT] = r;
                     }
                     vis[k] >>= 8;
@@ -267,7 +323,7 @@ k_patch_solve(PatchArgs pa)
 #pragma unroll
                 for (int qi = 0; qi < Q; qi++) {
                     const int q = q0 + qi;
-                    if (q < qend) {
+                    if (q < qend && !((dbg & 8) && ptile[qi * stride + i].x != 1.2345e300)) {
                         T2 *I = reinterpret_cast<T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)n;
                         const unsigned off = (unsigned)(own_lo + i) * (unsigned)sizeof(T2);
                         *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + off) = from_d2<T>(ptile[qi * stride + i]);
@@ -374,6 +430,7 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     }
     pa.stride = p->patch_cap + 1;
     pa.cap = p->patch_cap;
+    pa.dbg = (kDiag && std::getenv("VRT_DEBUG_FLAGS")) ? std::atoi(std::getenv("VRT_DEBUG_FLAGS")) : 0;
     pa.work = p->d_patch_work + w0;
     pa.rec = p->d_patch_rec;
     pa.rec2 = p->d_patch_rec2;
