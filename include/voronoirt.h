@@ -159,10 +159,22 @@ int vrt_plan_execute_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float 
  * number of sweep-kernel launches it made */
 int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches);
 /* which device path the last execute took: 1 = "levels" (one launch per dependency level),
- * 2 = "tiles" (one persistent launch), 3 = "steps" (two launches per BFS layer); 0 = none yet.
- * The three paths give the same results; the environment variable VRT_PATH=levels|tiles|steps
- * overrides the default choice (performance experiments, the parity tests' cross-checks). */
+ * 2 = "tiles" (one persistent launch), 3 = "steps" (two launches per BFS layer), 4 = "patches" (one
+ * fused launch per BFS layer, layers cut into patches; the default); 0 = none yet.  The paths give the
+ * same results; option VRT_PATH selects one (performance experiments, the parity tests' cross-checks). */
 int vrt_plan_last_path(const vrt_plan *p);
+/* Tuning options (performance experiments and the tests' cross-checks; results never depend on them).
+ * Every option has a default; an environment variable of the option's name presets it and is read ONCE,
+ * when a plan is created -- an execute reads no environment.  vrt_plan_set_option changes an option of a
+ * live plan; vrt_grid_set_option sets it for the plans vrt_delaunay_up / _down cache inside the grid.
+ *   VRT_PATH = auto | levels | tiles | steps | patches
+ *   VRT_PATCH_Q, VRT_PATCH_TARGET              wavelength pairs at a time / workgroups per launch of the patch kernel
+ *   VRT_PATCH_K, VRT_PATCH_NT, VRT_PATCH_OWN   entries per thread, threads, owned sites per patch (creation only)
+ *   VRT_STEP_K, VRT_STEP_SINGLE, VRT_STEP_PAIRS, VRT_STEP_XCD, VRT_STEP_STREAMS, VRT_STEP_LEVEL_MAP,
+ *   VRT_STEP_GROUP_DIR, VRT_TILE_WIDE, VRT_TILE_PRE, VRT_GRAPH     variants of the older paths
+ * VRT_EINVAL for an unknown name, a value out of range, or a creation-only option on a live plan. */
+int vrt_plan_set_option(vrt_plan *p, const char *name, const char *value);
+int vrt_grid_set_option(vrt_grid *g, const char *name, const char *value);
 
 /* ---- schedule introspection (host only, works on a device < 0 grid handle) -----------------
  * The dependency schedule of one direction given an upwind table `up` (2, n), 1-based ids as

@@ -118,7 +118,7 @@ def test_C3_1M_ul9n20_20_wavelengths(grid_1m):
     plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=Jd.data_ptr(),
                      dI0_up=I0d.data_ptr(), dI_out=Iout.data_ptr(), stream=st)
     torch.cuda.synchronize()
-    assert plan.last_path == "steps"
+    assert plan.last_path == "patches"
     # a sample: 2 directions (one up, one down) x 2 wavelengths against the oracle
     ups = [i for i in range(nq) if th[i] > 90]
     downs = [i for i in range(nq) if th[i] < 90]
@@ -171,7 +171,7 @@ def test_C4_1M_per_angle_alpha_51_wavelengths(grid_1m):
     plan.execute_dev(nlam, nlam, S.data_ptr(), alpha.data_ptr(), _lib.ALPHA_ANGLE_SITE_LAM, w,
                      dJ=J.data_ptr(), dI0_up=I0.data_ptr(), stream=st)
     torch.cuda.synchronize()
-    assert plan.last_path == "steps"
+    assert plan.last_path == "patches"
     native = torch.empty(plan.native_alpha_count(nlam), dtype=torch.float64, device=dev)
     plan.alpha_to_native_dev(nlam, nlam, alpha.data_ptr(), native.data_ptr(), stream=st)
     Jn = torch.empty_like(J)

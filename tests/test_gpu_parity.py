@@ -29,20 +29,26 @@ def _valid_line_mask(so):
     return m
 
 
-@pytest.fixture(params=["tiles", "steps", "levels", "patches"])
-def path(request, monkeypatch):
-    """Both device paths: the LDS layer-tile kernel (default when the grid fits) and the
-    one-launch-per-level kernels (general fallback)."""
-    monkeypatch.setenv("VRT_PATH", request.param)
-    return request.param
-
-
 @pytest.fixture(scope="module")
 def grids(bcc_small, voro_small):
     out = {}
     for name, (pos, nbr, bounds) in (("bcc", bcc_small), ("voronoi", voro_small)):
         out[name] = (vrt.VoronoiSites(pos, nbr, bounds, device=0), orc.make_sites(pos, nbr, bounds))
     return out
+
+
+@pytest.fixture(params=["tiles", "steps", "levels", "patches"])
+def path(request, monkeypatch, grids):
+    """Every device path: the fused patch kernel (default), the layer-step kernels, the persistent
+    layer-tile kernel and the one-launch-per-level kernels (general fallback).  The library reads
+    VRT_PATH when a plan is created; plans the module's grids already hold follow set_option."""
+    monkeypatch.setenv("VRT_PATH", request.param)
+    for hs, _ in grids.values():
+        hs.set_option("VRT_PATH", request.param)
+    yield request.param
+    for hs, _ in grids.values():
+        hs.set_option("VRT_PATH", "auto")
+        hs._options.pop("VRT_PATH")          # later plans take the environment's preset again
 
 
 def test_native_library_is_the_compute_path():
@@ -430,32 +436,36 @@ def _large_layer_case(a, nlam, seed):
 
 
 def test_layers_of_8712_sites_run_on_the_single_wavelength_step_kernels(monkeypatch):
-    """Layers above 8192 sites exceed the wavelength-PAIR level kernel (16-byte tile slots, 15
-    registers of coefficients per site); up to 12 288 sites they run on the single-wavelength one
-    (fp64, tile in sorted order).  Same results as the level path, to the last bit of the 1e-10 bar."""
+    """Layers above 8192 sites exceed the wavelength-PAIR level kernel of the layer-step path (16-byte tile
+    slots, 15 registers of coefficients per site); up to 12 288 sites they run on its single-wavelength
+    one (fp64, tile in sorted order).  The default path is the patch kernel, which has no such limit.
+    Same results on every path that holds the grid, to the 1e-10 bar."""
     monkeypatch.delenv("VRT_PATH", raising=False)
     hs, so, S, al, I0 = _large_layer_case(66, 12, 5)           # 8712 sites per layer
     assert int(np.diff(so.layers_up).max()) == 8712
     w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
     plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
     J, _ = plan.execute(S, al, weights=w, I0_up=I0)
-    assert plan.last_path == "steps"                          # 144 problems <= 256, but layers > 4096: not tiles
+    assert plan.last_path == "patches"
     ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
     assert _rel(J, ref) < RTOL
-    monkeypatch.setenv("VRT_PATH", "tiles")                   # the persistent tile kernel cannot hold them
+    plan.set_option("VRT_PATH", "steps")
+    J1, _ = plan.execute(S, al, weights=w, I0_up=I0)
+    assert plan.last_path == "steps" and _rel(J1, ref) < RTOL
+    plan.set_option("VRT_PATH", "tiles")                      # the persistent tile kernel cannot hold them
     with pytest.raises(vrt.VrtError):
         plan.execute(S, al, weights=w, I0_up=I0)
-    monkeypatch.setenv("VRT_PATH", "levels")
+    plan.set_option("VRT_PATH", "levels")
     J2, _ = plan.execute(S, al, weights=w, I0_up=I0)
     assert _rel(J2, ref) < RTOL
     plan.close()
     hs.close()
 
 
-def test_layers_of_17298_sites_fp32_on_steps_fp64_on_patches(monkeypatch):
-    """17 298-site layers (C5's are 17 672): fp32 storage fits the single-wavelength step kernel
-    (float tile and coefficients, 18 sites per thread); fp64 does not (12 288) and runs on the fused
-    patch kernel by itself, refusing VRT_PATH=steps."""
+def test_layers_of_17298_sites_fp32_on_steps_fp64_not(monkeypatch):
+    """17 298-site layers (C5's are 17 672): with fp32 storage the layer-step path's single-wavelength kernel
+    holds them (float tile and coefficients, 18 sites per thread); with fp64 it does not (12 288) and
+    VRT_PATH = steps is refused.  The default (patch kernel) takes both."""
     import torch
     monkeypatch.delenv("VRT_PATH", raising=False)
     hs, so, S, al, I0 = _large_layer_case(93, 6, 6)            # 2 * 93^2 = 17 298 sites per layer
@@ -467,16 +477,19 @@ def test_layers_of_17298_sites_fp32_on_steps_fp64_on_patches(monkeypatch):
                         so, I0_up=I0.astype(np.float32).astype(np.float64), nthreads=8)
     dev = torch.device("cuda", 0)
     Sd, Ad, I0d = (torch.from_numpy(x.astype(np.float32)).to(dev).contiguous() for x in (S, al, I0))
-    Jd = torch.zeros((n, nlam), dtype=torch.float32, device=dev)
-    plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=Jd.data_ptr(),
-                     dI0_up=I0d.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, f32=True)
-    torch.cuda.synchronize()
-    assert plan.last_path == "steps"
-    assert _rel(Jd.cpu().numpy().astype(np.float64), ref) < 5e-6
-    J, _ = plan.execute(S, al, weights=w, I0_up=I0)           # fp64: too large for the step kernels
+    for want in ("patches", "steps"):
+        plan.set_option("VRT_PATH", "auto" if want == "patches" else want)
+        Jd = torch.zeros((n, nlam), dtype=torch.float32, device=dev)
+        plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=Jd.data_ptr(),
+                         dI0_up=I0d.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, f32=True)
+        torch.cuda.synchronize()
+        assert plan.last_path == want
+        assert _rel(Jd.cpu().numpy().astype(np.float64), ref) < 5e-6
+    plan.set_option("VRT_PATH", "auto")
+    J, _ = plan.execute(S, al, weights=w, I0_up=I0)           # fp64
     assert plan.last_path == "patches"
     assert _rel(J, orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)) < RTOL
-    monkeypatch.setenv("VRT_PATH", "steps")
+    plan.set_option("VRT_PATH", "steps")                      # fp64: too large for the step kernels
     with pytest.raises(vrt.VrtError):
         plan.execute(S, al, weights=w, I0_up=I0)
     plan.close()
@@ -501,13 +514,13 @@ def test_layers_of_20000_and_30000_sites_run_on_the_patch_kernel(monkeypatch, a,
     assert plan.last_path == "patches"
     ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
     assert _rel(J, ref) < RTOL
-    monkeypatch.setenv("VRT_PATH", "levels")
+    plan.set_option("VRT_PATH", "levels")
     J2, _ = plan.execute(S, al, weights=w, I0_up=I0)
     assert plan.last_path == "levels" and _rel(J2, J) < 5e-12
-    monkeypatch.setenv("VRT_PATH", "steps")                   # no layer-step kernel holds such a layer
+    plan.set_option("VRT_PATH", "steps")                      # no layer-step kernel holds such a layer
     with pytest.raises(vrt.VrtError):
         plan.execute(S, al, weights=w, I0_up=I0)
-    monkeypatch.delenv("VRT_PATH", raising=False)
+    plan.set_option("VRT_PATH", "auto")
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
     Sd, Ad, I0d = (torch.from_numpy(x.astype(np.float32)).to(dev).contiguous() for x in (S, al, I0))
@@ -535,39 +548,44 @@ def test_layers_of_20000_and_30000_sites_run_on_the_patch_kernel(monkeypatch, a,
     hs.close()
 
 
-def test_default_path_choice(grids):
-    """More (angle, wavelength) problems than CUs -> layer-step kernels; fewer -> the single
-    persistent launch of the tile kernel."""
-    import os
-    old = os.environ.pop("VRT_PATH", None)
-    try:
-        hs, so = grids["voronoi"]
-        n = so.n
-        rng = np.random.default_rng(1)
-        w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
-        plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
-        S = 1 + rng.random((n, 24))
-        al = 5 * 10 ** rng.uniform(-2, 2, (n, 24))
-        plan.execute(S, al, weights=w)
-        assert plan.last_path == "steps"
-        plan.execute(S[:, :2].copy(), al[:, :2].copy(), weights=w)
-        assert plan.last_path == "tiles"
-        plan.close()
-    finally:
-        if old is not None:
-            os.environ["VRT_PATH"] = old
+def test_default_path_choice(grids, monkeypatch):
+    """The fused patch kernel is the default; a lone (angle, wavelength) problem on small layers takes the
+    two launches of the persistent tile kernel.  Options: unknown names and creation-only ones are refused."""
+    monkeypatch.delenv("VRT_PATH", raising=False)
+    hs, so = grids["voronoi"]
+    n = so.n
+    rng = np.random.default_rng(1)
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    S = 1 + rng.random((n, 24))
+    al = 5 * 10 ** rng.uniform(-2, 2, (n, 24))
+    plan.execute(S, al, weights=w)
+    assert plan.last_path == "patches"
+    plan.execute(S[:, :2].copy(), al[:, :2].copy(), weights=w)
+    assert plan.last_path == "patches"
+    with pytest.raises(vrt.VrtError):
+        plan.set_option("VRT_NO_SUCH_OPTION", 1)
+    with pytest.raises(vrt.VrtError):
+        plan.set_option("VRT_PATH", "sideways")
+    with pytest.raises(vrt.VrtError):
+        plan.set_option("VRT_PATCH_NT", 256)                  # shapes what plan creation built
+    plan.close()
+    one = vrt.FormalPlan(hs, [vrt.direction(th[0], ph[0])], 3)
+    one.execute(S[:, :1].copy(), al[:, :1].copy(), weights=[1.0])
+    assert one.last_path == "tiles"
+    one.close()
 
 
-@pytest.mark.parametrize("f32_path", ["steps", "levels"])
+@pytest.mark.parametrize("f32_path", ["patches", "steps", "levels"])
 def test_fp32_value_path_against_fp64_oracle(grids, f32_path, monkeypatch):
     """BASELINE config C5's path: S, α, I_0, J stored as float32, arithmetic in fp64.  Checked
     against the fp64 oracle fed with the same float32-rounded inputs; the remaining difference is
     the float32 rounding of the stored intensities (tolerance 5e-6 relative, fp64 path: 1e-10)."""
     import torch
-    if f32_path == "levels":
-        monkeypatch.setenv("VRT_PATH", "levels")
+    if f32_path == "patches":
+        monkeypatch.delenv("VRT_PATH", raising=False)          # the default
     else:
-        monkeypatch.delenv("VRT_PATH", raising=False)
+        monkeypatch.setenv("VRT_PATH", f32_path)               # read when the plan below is created
     hs, so = grids["voronoi"]
     n = so.n
     nlam = 7
@@ -585,7 +603,7 @@ def test_fp32_value_path_against_fp64_oracle(grids, f32_path, monkeypatch):
                      dI0_up=I0d.data_ptr(), dI_out=Id.data_ptr(),
                      stream=torch.cuda.current_stream().cuda_stream, f32=True)
     torch.cuda.synchronize()
-    assert plan.last_path == f32_path     # fp32 storage runs on the layer-step kernels by default
+    assert plan.last_path == f32_path
     ref = orc.J_voronoi(w, th, ph, S.astype(np.float64), al.astype(np.float64), so,
                         I0_up=I0.astype(np.float64), nthreads=4)
     J = Jd.cpu().numpy().astype(np.float64)
@@ -734,7 +752,7 @@ def test_device_resident_lambda_iteration(grids):
         J_ref = orc.J_voronoi(w, th, ph, S_ref_old, al, so, I0_up=S_ref_old[bottom], nthreads=8)
         S_ref_new = (1 - eps)[:, None] * J_ref + eps[:, None] * B
         hist_ref.append(float(np.abs(1 - S_ref_old / S_ref_new).max()))
-    assert plan.last_path == "steps"
+    assert plan.last_path == "patches"
     assert _rel(S_new.cpu().numpy(), S_ref_new) < RTOL
     assert np.allclose(hist_gpu, hist_ref, rtol=1e-9)
     assert hist_gpu[-1] < hist_gpu[0]                      # the iteration contracts
@@ -894,7 +912,7 @@ def test_every_single_wavelength_level_kernel_instantiation(grids, K, f32, monke
     plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
     if not f32:
         J_pair, _ = plan.execute(S, al, weights=w, I0_up=I0)
-        monkeypatch.setenv("VRT_STEP_SINGLE", "1")
+        plan.set_option("VRT_STEP_SINGLE", 1)
         J, _ = plan.execute(S, al, weights=w, I0_up=I0)
         assert plan.last_path == "steps"
         assert np.array_equal(J, J_pair)
@@ -942,11 +960,12 @@ def test_step_path_thread_assignment_does_not_change_results(grids, monkeypatch)
         assert np.array_equal(J, out[0])
 
 
-def test_diagnostic_environment_variables_cannot_change_results(grids, monkeypatch):
+@pytest.mark.parametrize("dpath", ["steps", "patches"])
+def test_diagnostic_environment_variables_cannot_change_results(grids, monkeypatch, dpath):
     """The timing diagnostics that switch memory traffic off live behind -DVRT_DIAG in a separate
     library (voronoirt_amd/libvrt_hip_diag.so, tools/flags_sweep.sh); the product library ignores
-    their environment variables."""
-    monkeypatch.setenv("VRT_PATH", "steps")
+    their options, whether preset in the environment of a new plan or set on a live one."""
+    monkeypatch.setenv("VRT_PATH", dpath)
     assert _lib.LIB_PATH.endswith("libvrt_hip.so")
     hs, so = grids["bcc"]
     n = so.n
@@ -957,13 +976,19 @@ def test_diagnostic_environment_variables_cannot_change_results(grids, monkeypat
     w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
     plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
     J0, _ = plan.execute(S, al, weights=w)
+    plan.set_option("VRT_DEBUG_FLAGS", 31)
+    plan.set_option("VRT_DEBUG_SKIP_LEVELS", 1)
+    J1, _ = plan.execute(S, al, weights=w)
+    assert plan.last_path == dpath and np.array_equal(J0, J1)
     monkeypatch.setenv("VRT_DEBUG_FLAGS", "31")
     monkeypatch.setenv("VRT_DEBUG_SKIP_LEVELS", "1")
     monkeypatch.setenv("VRT_TILE_DEBUG", "1")
-    J1, _ = plan.execute(S, al, weights=w)
-    assert np.array_equal(J0, J1)
+    plan2 = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    J2, _ = plan2.execute(S, al, weights=w)
+    assert np.array_equal(J0, J2)
     assert _rel(J0, orc.J_voronoi(w, th, ph, S, al, so, nthreads=4)) < RTOL
     plan.close()
+    plan2.close()
 
 
 def test_theta_90_is_skipped_when_the_direction_is_inferred_from_k(grids):

@@ -48,18 +48,19 @@ def test_patches_J_matches_oracle_and_steps(grids, name, own, nlam, monkeypatch)
     of ~40 / ~150 sites (every layer split, halos everywhere); shared and per-angle alpha; up AND down
     boundary intensities.  Equal to the oracle at 1e-10 and to the layer-step path at rounding level."""
     hs, so = grids[name]
+    monkeypatch.delenv("VRT_PATH", raising=False)
     if own:
-        monkeypatch.setenv("VRT_PATCH_OWN", str(own))
+        monkeypatch.setenv("VRT_PATCH_OWN", str(own))          # plan creation reads it
     w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
     plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
     for per_angle in (0, nq):
         S, al, I0u, I0d = _case(so, nlam, 3 + nlam, per_angle)
-        monkeypatch.setenv("VRT_PATH", "patches")
+        plan.set_option("VRT_PATH", "patches")
         J, I = plan.execute(S, al, weights=w, I0_up=I0u, I0_down=I0d, want_I=True)
         assert plan.last_path == "patches"
         ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0u, I0_down=I0d, nthreads=4)
         assert _rel(J, ref) < RTOL
-        monkeypatch.setenv("VRT_PATH", "steps")
+        plan.set_option("VRT_PATH", "steps")
         J2, I2 = plan.execute(S, al, weights=w, I0_up=I0u, I0_down=I0d, want_I=True)
         assert plan.last_path == "steps"
         assert _rel(I, I2) < 5e-12 and _rel(J, J2) < 5e-12       # exp() of the patch kernel: 2e-13 (contract 1e-10)
@@ -83,6 +84,7 @@ def test_every_patch_kernel_instantiation(grids, shape, f32, monkeypatch):
     monkeypatch.setenv("VRT_PATCH_Q", str(Q))
     monkeypatch.setenv("VRT_PATCH_NT", str(NT))
     monkeypatch.setenv("VRT_PATCH_OWN", "90")
+    monkeypatch.setenv("VRT_PATCH_TARGET", str(64 if K == 1 else 4096))      # several pairs per workgroup / one
     monkeypatch.setenv("VRT_PATH", "patches")
     n, nlam = so.n, 9
     w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
@@ -105,7 +107,7 @@ def test_every_patch_kernel_instantiation(grids, shape, f32, monkeypatch):
 
 def test_patches_single_solves_and_sweep_counts(grids, monkeypatch):
     """Delaunay_upII / Delaunay_downII (one problem, one wavelength) and n_sweeps 1, 2, 4 on the patch path."""
-    monkeypatch.setenv("VRT_PATH", "patches")
+    monkeypatch.setenv("VRT_PATH", "patches")      # read when the grid creates the plans of the single solves
     monkeypatch.setenv("VRT_PATCH_OWN", "64")
     hs, so = grids["bcc"]
     n = so.n

@@ -131,8 +131,8 @@ def test_gpu_searchlight_matches_reference_image_statistics(searchlight_grid, na
 @pytest.mark.gpu
 def test_gpu_J_on_true_voronoi_grid_at_reference_resolution(searchlight_grid):
     """J_λ_voronoi on the 51^3-site TRUE Voronoi tessellation (irregular layer sizes, 5-30
-    neighbours per cell, upwind neighbours in later layers): 12 angles x 24 wavelengths (layer-step
-    kernels) and a single wavelength (tile kernel) against the oracle."""
+    neighbours per cell, upwind neighbours in later layers): 12 angles x 24 wavelengths and a single
+    wavelength (the continuum caller) on the default path against the oracle."""
     pos, nbr, bounds, so = searchlight_grid
     hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
     for key in ("layers_up", "layers_down", "perm_up", "perm_down"):
@@ -146,7 +146,7 @@ def test_gpu_J_on_true_voronoi_grid_at_reference_resolution(searchlight_grid):
         gup, gd, gw, gr = plan.upwind(a)
         ok = st == 0
         assert np.array_equal(gup[ok], up[ok]) and np.array_equal(gd[ok], dots[ok])
-    for nlam, expect in ((24, "steps"), (1, "tiles")):
+    for nlam, expect in ((24, "patches"), (1, "patches")):
         S = 1 + rng.random((n, nlam))
         al = 30 * 10 ** rng.uniform(-3, 2, (n, 1)) * (1 + rng.random((n, nlam)))
         I0 = rng.random((so.layers_up[1] - 1, nlam))

@@ -47,7 +47,7 @@ for case in range(cases):
     n_sweeps = int(rng.choice([1, 2, 3, 3, 3, 4]))
     ks = vrt.quadrature_directions(th, ph)
     res = {}
-    for path in ("levels", "steps", "tiles"):
+    for path in ("levels", "steps", "tiles", "patches"):
         os.environ["VRT_PATH"] = path
         plan = vrt.FormalPlan(hs, ks, n_sweeps)
         J, I = plan.execute(S, al, weights=w, I0_up=I0, want_I=True)
@@ -70,10 +70,12 @@ for case in range(cases):
                np.abs(res["steps"][1] - res["levels"][1]).max() / max(np.abs(res["levels"][1]).max(), 1e-300))
     e_ti = max(np.abs(res["tiles"][0] - res["levels"][0]).max() / scale,
                np.abs(res["tiles"][1] - res["levels"][1]).max() / max(np.abs(res["levels"][1]).max(), 1e-300))
-    worst = max(worst, e_or, e_st, e_ti)
-    ok = e_or < 1e-10 and e_st < 1e-12 and e_ti < 1e-12
+    e_pa = max(np.abs(res["patches"][0] - res["levels"][0]).max() / scale,
+               np.abs(res["patches"][1] - res["levels"][1]).max() / max(np.abs(res["levels"][1]).max(), 1e-300))
+    worst = max(worst, e_or, e_st, e_ti, e_pa)
+    ok = e_or < 1e-10 and e_st < 1e-12 and e_ti < 1e-12 and e_pa < 5e-12
     print(f"case {case:3d} {desc:18s} n={n:6d} quad={nq:2d} nlam={nlam:2d} alpha_mode={mode} sweeps={n_sweeps} "
-          f"oracle {e_or:.1e} steps {e_st:.1e} tiles {e_ti:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
+          f"oracle {e_or:.1e} steps {e_st:.1e} tiles {e_ti:.1e} patches {e_pa:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok:
         sys.exit(1)
     hs.close()

@@ -47,9 +47,8 @@ n1 = int(hs.layers_up[1] - 1)
 I0 = torch.rand((n1, nlam), generator=g, device=dev, dtype=torch.float64)
 J = torch.zeros((n, nlam), device=dev, dtype=torch.float64)
 stream = torch.cuda.current_stream().cuda_stream
-for path in (None, "levels", "steps", "tiles"):
-    if path:
-        os.environ["VRT_PATH"] = path
+for path in (None, "levels", "steps", "tiles", "patches"):
+    plan.set_option("VRT_PATH", path or "auto")
     if (path == "tiles" and max(lu.max(), ld_.max()) > 8192) or (path == "steps" and max(lu.max(), ld_.max()) > 12288):
         continue
     for _ in range(2):
@@ -61,7 +60,10 @@ for path in (None, "levels", "steps", "tiles"):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     print(f"path {plan.last_path}: {dt * 1e3:.2f} ms per J ({n * nq * nlam / dt / 1e9:.1f} G cell-updates/s)", flush=True)
-os.environ.pop("VRT_PATH", None)
+plan.set_option("VRT_PATH", "auto")
+for _ in range(2):      # J of the default path for the parity check
+    plan.execute_dev(nlam, nlam, S.data_ptr(), al.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=J.data_ptr(), dI0_up=I0.data_ptr(), stream=stream)
+torch.cuda.synchronize()
 so = orc.make_sites(pos, nbr, bounds)
 ls = min(nlam, 4)
 ref = orc.J_voronoi(w, th, ph, S[:, :ls].cpu().numpy(), al[:, :ls].cpu().numpy(), so, I0_up=I0[:, :ls].cpu().numpy(), nthreads=8)

@@ -65,6 +65,8 @@ PROTOTYPES = {
                                                  vp, vp]),
     "vrt_plan_last_sweep_timing": (ctypes.c_int, [vp, p_dbl, p_i64]),
     "vrt_plan_last_path": (ctypes.c_int, [vp]),
+    "vrt_plan_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_char_p]),
+    "vrt_grid_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_char_p]),
     "vrt_schedule_build": (ctypes.c_int, [vp, ctypes.c_int, p_i64, ctypes.c_int,
                                           ctypes.POINTER(vp)]),
     "vrt_schedule_num_nodes": (c_i64, [vp]),

@@ -108,6 +108,7 @@ class VoronoiSites:
         self.perm_down = self._perm(-1)
         self._plans = {}
         self._live_plans = weakref.WeakSet()    # every FormalPlan built on this grid (closed with it)
+        self._options = {}                      # tuning options set on this grid (set_option)
 
     # -- introspection ------------------------------------------------------------------------
     def _layers(self, d):
@@ -120,6 +121,16 @@ class VoronoiSites:
         out = np.zeros(self.n, dtype=np.int64)
         check(_lib.load().vrt_grid_get_perm(self._h, d, _i(out)))
         return out
+
+    def set_option(self, name: str, value) -> None:
+        """Tuning option (`vrt_grid_set_option` / `vrt_plan_set_option`, e.g. VRT_PATH = auto | levels | tiles |
+        steps | patches) for every plan of this grid: the single-solve plans cached inside the handle, the
+        live FormalPlans and those created later.  Environment variables of the same names are read once, at
+        plan creation."""
+        check(_lib.load().vrt_grid_set_option(self._h, name.encode(), str(value).encode()))
+        self._options[name] = str(value)
+        for p in list(self._live_plans):
+            p.set_option(name, value)
 
     def storage_order(self, d: int) -> np.ndarray:
         """1-based site id at every storage position of direction d (> 0 up, < 0 down): the site
@@ -205,6 +216,11 @@ class FormalPlan:
                                        d.ctypes.data_as(_lib.p_int), self.n_sweeps, ctypes.byref(h)))
         self._h = h
         sites._live_plans.add(self)
+        for name, value in sites._options.items():      # options set on the grid follow into its plans
+            try:
+                self.set_option(name, value)
+            except VrtError:
+                pass                                     # a creation-only option: the environment presets those
 
     @property
     def num_levels(self) -> int:
@@ -290,6 +306,11 @@ class FormalPlan:
         check(_lib.load().vrt_line_opacity_dev(self._h, lam.size, _d(lam), float(lambda0), float(c0), d_velocity,
                                                d_doppler, d_gamma, d_line_strength, d_alpha_cont, d_alpha_native,
                                                stream or None))
+
+    def set_option(self, name: str, value) -> None:
+        """Tuning option of this plan (`vrt_plan_set_option`); results never depend on it."""
+        if getattr(self, "_h", None):
+            check(_lib.load().vrt_plan_set_option(self._h, name.encode(), str(value).encode()))
 
     def last_sweep_timing(self):
         ms = ctypes.c_double()

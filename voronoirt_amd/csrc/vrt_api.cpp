@@ -20,6 +20,55 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
+void tuning_from_env(Tuning &t)
+{
+    static const char *names[] = {"VRT_PATH", "VRT_STEP_K", "VRT_STEP_SINGLE", "VRT_STEP_PAIRS", "VRT_STEP_XCD",
+                                  "VRT_STEP_STREAMS", "VRT_STEP_LEVEL_MAP", "VRT_STEP_GROUP_DIR", "VRT_TILE_WIDE",
+                                  "VRT_TILE_PRE", "VRT_GRAPH", "VRT_PATCH_K", "VRT_PATCH_NT", "VRT_PATCH_OWN",
+                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
+                                  "VRT_TILE_DEBUG"};
+    for (const char *nm : names) {
+        const char *e = std::getenv(nm);
+        if (e && *e) (void)tuning_set(t, nm, e, /*created=*/false);     // a bad value keeps the default
+    }
+}
+
+int tuning_set(Tuning &t, const char *name, const char *value, bool created)
+{
+    if (!name || !value) return fail(VRT_EINVAL, "NULL option name or value");
+    const std::string nm(name), v(value);
+    if (nm == "VRT_PATH") {
+        static const char *paths[] = {"auto", "levels", "tiles", "steps", "patches"};
+        for (int i = 0; i < 5; i++)
+            if (v == paths[i]) { t.path = i; return VRT_OK; }
+        if (v.empty()) { t.path = 0; return VRT_OK; }
+        return fail(VRT_EINVAL, "VRT_PATH must be auto, levels, tiles, steps or patches");
+    }
+    char *end = nullptr;
+    const long x = std::strtol(value, &end, 10);
+    if (end == value || *end != 0) return fail(VRT_EINVAL, "option " + nm + " needs an integer value");
+    struct { const char *name; int *field; long lo, hi; bool creation_only; } tab[] = {
+        {"VRT_STEP_K", &t.step_K, 0, 18, false}, {"VRT_STEP_SINGLE", &t.step_single, 0, 1, false},
+        {"VRT_STEP_PAIRS", &t.step_pairs, 0, 64, false}, {"VRT_STEP_XCD", &t.step_xcd, 0, 2, false},
+        {"VRT_STEP_STREAMS", &t.step_streams, 1, 4, false}, {"VRT_STEP_LEVEL_MAP", &t.step_level_map, 0, 1, false},
+        {"VRT_STEP_GROUP_DIR", &t.step_group_dir, 0, 1, false}, {"VRT_TILE_WIDE", &t.tile_wide, 0, 1, false},
+        {"VRT_TILE_PRE", &t.tile_pre, 0, 1, false}, {"VRT_GRAPH", &t.graph, 0, 1, false},
+        {"VRT_PATCH_K", &t.patch_K, 1, 8, true}, {"VRT_PATCH_NT", &t.patch_NT, 64, 1024, true},
+        {"VRT_PATCH_OWN", &t.patch_own, 0, 65535, true}, {"VRT_PATCH_Q", &t.patch_Q, 1, 4, false},
+        {"VRT_PATCH_TARGET", &t.patch_target, 1, 1 << 20, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
+        {"VRT_DEBUG_SKIP_LEVELS", &t.debug_skip_levels, 0, 1, false}, {"VRT_TILE_DEBUG", &t.tile_debug, 0, 1, false},
+    };
+    for (auto &o : tab)
+        if (nm == o.name) {
+            if (o.creation_only && created)
+                return fail(VRT_EINVAL, "option " + nm + " shapes what plan creation builds: preset it in the environment");
+            if (x < o.lo || x > o.hi) return fail(VRT_EINVAL, "option " + nm + " out of range");
+            *o.field = (int)x;
+            return VRT_OK;
+        }
+    return fail(VRT_EINVAL, "unknown option " + nm);
+}
+
 template <typename T>
 static int dev_alloc(T **p, size_t count)
 {
@@ -294,7 +343,8 @@ static int ensure_level_schedule(vrt_plan *p)
 }
 
 static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, const int *dirs,
-                            int n_sweeps, vrt_plan **out)
+                            int n_sweeps, vrt_plan **out,
+                            const std::vector<std::pair<std::string, std::string>> *options = nullptr)
 {
     if (!out) return fail(VRT_EINVAL, "out is NULL");
     *out = nullptr;
@@ -308,6 +358,9 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
     p->g = g;
     p->n_sweeps = n_sweeps;
     p->n_angles_user = n_angles;
+    tuning_from_env(p->tune);             // the ONLY place the library reads its tuning environment variables
+    if (options)
+        for (const auto &o : *options) (void)tuning_set(p->tune, o.first.c_str(), o.second.c_str(), /*created=*/false);
     for (int64_t a = 0; a < n_angles; a++) {
         const double *ka = k + 3 * a;
         const double nrm = std::sqrt(ka[0] * ka[0] + ka[1] * ka[1] + ka[2] * ka[2]);
@@ -375,25 +428,16 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
     std::vector<std::vector<int32_t>> sorted_self((size_t)A);   // thread assignment of k_step_levels
     std::vector<PatchSchedule> psched((size_t)A);                // fused patch path (vrt_patch.cpp)
     {
-        // shape of the patch kernel: K entries per thread x NT threads = largest dependency cone of a
-        // patch, Q wavelength pairs per workgroup; tuning knobs read ONCE, here
-        auto env_int = [](const char *name, int dflt) {
-            const char *e = std::getenv(name);
-            return e && *e ? std::atoi(e) : dflt;
-        };
-        p->patch_K = env_int("VRT_PATCH_K", 1);
-        p->patch_NT = env_int("VRT_PATCH_NT", 1024);
-        p->patch_Q = env_int("VRT_PATCH_Q", 2);
-        if (!patch_shape_exists(p->patch_K, p->patch_Q, p->patch_NT)) {
-            p->patch_K = 1; p->patch_NT = 1024; p->patch_Q = 2;
+        // shape of the patch kernel: K entries per thread x NT threads = largest dependency cone of a patch
+        if (!patch_shape_exists(p->tune.patch_K, p->tune.patch_Q, p->tune.patch_NT)) {
+            p->tune.patch_K = 1; p->tune.patch_NT = 512; p->tune.patch_Q = 1;
         }
+        p->patch_K = p->tune.patch_K;
+        p->patch_NT = p->tune.patch_NT;
         p->patch_cap = p->patch_K * p->patch_NT;
     }
     // a patch owns as many consecutive sites as its dependency cone leaves room for (VRT_PATCH_OWN: at most that many)
-    const int patch_own = std::max(1, std::min(p->patch_cap, [&]() {
-        const char *e = std::getenv("VRT_PATCH_OWN");
-        return e && *e ? std::atoi(e) : p->patch_cap;
-    }()));
+    const int patch_own = p->tune.patch_own > 0 ? std::min(p->tune.patch_own, p->patch_cap) : p->patch_cap;
     {
         unsigned hw = std::thread::hardware_concurrency();
         int nthr = (int)std::min<unsigned>(hw ? hw : 4, 16);
@@ -628,23 +672,21 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         // coefficient kernel wins once a layer holds more than a few sites per thread -- 1M sites x
         // 12 angles x 1 λ: 5.1 vs 7.8 ms; C4: 11.8 vs 20.5 ms); levels when the grid does not fit.
         // VRT_PATH selects one explicitly.
-        const char *force = std::getenv("VRT_PATH");
         const bool tiles_ok = steps_ok && !f32 && p->tile_max_layer_size <= 8192;
         int path = 1;
-        if (steps_ok)
-            path = (tiles_ok && (int64_t)p->A * nlam <= 256 && p->tile_max_layer_size <= 4096) ? 2 : 3;
+        if (tiles_ok && (int64_t)p->A * nlam <= 2 && p->tile_max_layer_size <= 4096)
+            path = 2;                 // a single solve on small layers: two launches in all
         else if (p->patch_ok)
             path = 4;
-        if (force && std::strcmp(force, "levels") == 0) path = 1;
-        if (force && std::strcmp(force, "tiles") == 0) path = 2;
-        if (force && std::strcmp(force, "steps") == 0) path = 3;
-        if (force && std::strcmp(force, "patches") == 0) path = 4;
+        else if (steps_ok)
+            path = 3;
+        if (p->tune.path) path = p->tune.path;
         // the native layout IS the storage order of the layer paths
         if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && path != 3 && path != 4) path = (steps_ok && !f32) ? 3 : 4;
         if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && path == 3 && (f32 || !steps_ok)) path = 4;
         if (p->A == 0) path = 1;      // nothing to solve (every direction skipped): J = 0 via the level path
         if ((path == 3 && !steps_ok) || (path == 2 && !tiles_ok) || (path == 4 && !p->patch_ok))
-            return fail(VRT_EINVAL, "VRT_PATH=tiles/steps/patches but the grid (or the fp32 storage type) does not fit those kernels");
+            return fail(VRT_EINVAL, "VRT_PATH = tiles / steps / patches but the grid (or the fp32 storage type) does not fit those kernels");
         if (path != 1) {
             p->last_path = path;
             return execute_tiles(p, nlam, ld, dS_, dalpha_, alpha_mode, dI0_up_, dI0_down_, weights, dJ_,
@@ -675,8 +717,7 @@ static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void 
         // Measured on MI355X it changes nothing (C2: 7.57 vs 7.56 ms, C4: 24.87 vs 24.91 ms --
         // the launches are bound by the dependent-load latency inside each level, not by the
         // host), so eager launches stay the default.
-        const char *genv = std::getenv("VRT_GRAPH");
-        const bool use_graph = genv && genv[0] == '1';
+        const bool use_graph = p->tune.graph == 1;
         SweepKey key;
         key.nlam = sa.nlam; key.ldS = sa.ldS; key.ldA = sa.ldA; key.ldI = sa.ldI;
         key.S = sa.S; key.alpha = sa.alpha; key.I = sa.I; key.alpha_mode = sa.alpha_mode; key.f32 = sa.f32;
@@ -1253,6 +1294,31 @@ int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches)
 
 int vrt_plan_last_path(const vrt_plan *p) { return p ? p->last_path : 0; }
 
+int vrt_plan_set_option(vrt_plan *p, const char *name, const char *value)
+{
+    if (!p) return fail(VRT_EINVAL, "NULL plan");
+    std::lock_guard<std::mutex> lock(p->mu);
+    return tuning_set(p->tune, name, value, /*created=*/true);
+}
+
+int vrt_grid_set_option(vrt_grid *g, const char *name, const char *value)
+{
+    if (!g) return fail(VRT_EINVAL, "NULL grid");
+    Tuning probe;
+    int rc = tuning_set(probe, name, value, /*created=*/false);      // validates name and value
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(g->mu);
+    bool found = false;
+    for (auto &o : g->options)
+        if (o.first == name) { o.second = value; found = true; }
+    if (!found) g->options.emplace_back(name, value);
+    for (PlanCacheEntry *c : g->cache) {                             // cached single-solve plans follow where they can
+        std::lock_guard<std::mutex> plock(c->plan->mu);
+        (void)tuning_set(c->plan->tune, name, value, /*created=*/true);
+    }
+    return VRT_OK;
+}
+
 int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *dJ, const double *dB,
                           const double *deps, const double *dS_old, double *dS_new, double *max_rel_change,
                           void *stream)
@@ -1406,7 +1472,7 @@ static int single_solve(vrt_grid *g, int dir, const double k[3], const double *S
             if (!entry) {
                 int dirs[1] = {dir};
                 vrt_plan *plan = nullptr;
-                int rc = plan_create_impl(g, 1, k, dirs, n_sweeps, &plan);
+                int rc = plan_create_impl(g, 1, k, dirs, n_sweeps, &plan, &g->options);
                 if (rc) return rc;
                 if (g->cache.size() >= 64)      // drop the oldest entry nobody is using
                     for (size_t i = 0; i < g->cache.size(); i++)

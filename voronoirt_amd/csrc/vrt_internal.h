@@ -60,6 +60,31 @@ struct Direction {
 
 struct PlanCacheEntry;
 
+// Tuning options of a plan (vrt_plan_set_option / vrt_grid_set_option).  Defaults; an environment variable of the
+// option's name presets it, read ONCE when the plan is created (never during an execute).  Results do not
+// depend on any of them (the parity tests run the paths and shapes against each other).
+struct Tuning {
+    int path = 0;                 // VRT_PATH: 0 auto, 1 levels, 2 tiles, 3 steps, 4 patches
+    int step_K = 0;               // VRT_STEP_K: sites per thread of the layer-step level kernels (0: fewest that fit)
+    int step_single = 0;          // VRT_STEP_SINGLE: 1 = the single-wavelength level kernel on any grid
+    int step_pairs = 0;           // VRT_STEP_PAIRS: wavelength pairs per coefficient thread (0: 4 to 6)
+    int step_xcd = 2;             // VRT_STEP_XCD: block -> XCD map of the coefficient kernel
+    int step_streams = 2;         // VRT_STEP_STREAMS: internal streams of the layer paths (1..4)
+    int step_level_map = 1;       // VRT_STEP_LEVEL_MAP: level workgroups of an angle on one XCD
+    int step_group_dir = 1;       // VRT_STEP_GROUP_DIR: one direction per stream when balanced
+    int tile_wide = 1;            // VRT_TILE_WIDE, VRT_TILE_PRE: variants of the persistent tile path
+    int tile_pre = 1;
+    int graph = 0;                // VRT_GRAPH: replay the level launches as a hipGraph
+    int patch_K = 1, patch_NT = 512;   // VRT_PATCH_K, VRT_PATCH_NT: entries per thread, threads (plan creation only)
+    int patch_own = 0;            // VRT_PATCH_OWN: owned sites per patch at most (0: as many as fit; creation only)
+    int patch_Q = 1;              // VRT_PATCH_Q: wavelength pairs a patch workgroup solves at a time
+    int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
+    int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)
+};
+void tuning_from_env(Tuning &t);
+// VRT_OK, or VRT_EINVAL for an unknown name / bad value; `created`: the plan exists already (creation-only options fail)
+int tuning_set(Tuning &t, const char *name, const char *value, bool created);
+
 // arguments a captured level-launch graph was recorded with
 struct SweepKey {
     int64_t nlam = -1, ldS = 0, ldA = 0, ldI = 0;
@@ -98,6 +123,8 @@ struct vrt_grid {
     bool small_ev_valid = false;
     hipEvent_t small_copy_ev = nullptr;        // last copy out of h_small
     bool small_copy_valid = false;
+    // options applied to the single-solve plans cached below (vrt_grid_set_option)
+    std::vector<std::pair<std::string, std::string>> options;
     // cache of single-angle plans for vrt_delaunay_up/down
     std::mutex mu;
     std::vector<vrt::PlanCacheEntry *> cache;
@@ -105,6 +132,7 @@ struct vrt_grid {
 
 struct vrt_plan {
     vrt_grid *g = nullptr;
+    vrt::Tuning tune;
     int n_sweeps = 3;
     int64_t n_angles_user = 0;
     int A = 0;                          // active angles (k[0] != 0)
@@ -173,7 +201,7 @@ struct vrt_plan {
     std::vector<int32_t> h_step_angles;  // host copy of d_step_angles
     // fused patch path (vrt_patch.hip): per-angle patch schedules, concatenated over the active angles
     bool patch_ok = false;
-    int patch_cap = 0, patch_K = 0, patch_NT = 0, patch_Q = 0;   // entries per patch <= cap = K * NT; pairs per workgroup
+    int patch_cap = 0, patch_K = 0, patch_NT = 0;   // entries per patch <= cap = K * NT (fixed at creation)
     int64_t n_patches = 0, n_patch_entries = 0, n_patch_visits = 0;
     std::vector<int32_t> h_patch_first;  // [A][tile_max_layers + 2]: index of the first patch of (angle, layer)
     std::vector<int4> h_patch_rec;       // per patch: first entry, entries, first owned position, owned sites

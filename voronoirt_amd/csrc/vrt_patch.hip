@@ -411,8 +411,8 @@ int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angl
 int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, int group, int Q, hipStream_t st,
                        bool f32)
 {
-    // workgroups per launch: enough to fill the chip twice over with both direction streams running
-    static const int target_wgs = std::getenv("VRT_PATCH_TARGET") ? std::max(1, std::atoi(std::getenv("VRT_PATCH_TARGET"))) : 512;
+    // workgroups per launch: enough to fill the chip a few times over with both direction streams running
+    const int target_wgs = std::max(1, p->tune.patch_target);
     const int maxL = p->tile_max_layers;
     const size_t wo = (size_t)group * (size_t)(maxL + 2) + (size_t)layer;
     const int64_t w0 = p->patch_work_off[wo], w1 = p->patch_work_off[wo + 1];
@@ -430,7 +430,7 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     }
     pa.stride = p->patch_cap + 1;
     pa.cap = p->patch_cap;
-    pa.dbg = (kDiag && std::getenv("VRT_DEBUG_FLAGS")) ? std::atoi(std::getenv("VRT_DEBUG_FLAGS")) : 0;
+    pa.dbg = kDiag ? p->tune.debug_flags : 0;
     pa.work = p->d_patch_work + w0;
     pa.rec = p->d_patch_rec;
     pa.rec2 = p->d_patch_rec2;

@@ -435,6 +435,7 @@ struct vrt_regular {
     int64_t cap_S = 0, cap_A = 0, cap_I = 0, cap_k = 0, cap_coef = 0;      // in solves
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timed = false;
+    int force_threads = 0;                 // VRT_REG_THREADS, read once at creation (tests: forces the launch shape)
 };
 
 static void regular_free(vrt_regular *r)
@@ -461,6 +462,7 @@ extern "C" int vrt_regular_create(int64_t nz, int64_t nx, int64_t ny, const doub
     if (device < 0 || device >= cnt) return fail(VRT_EINVAL, "device ordinal out of range");
     VRT_HIP_TRY(hipSetDevice(device));
     vrt_regular *r = new vrt_regular;
+    if (const char *e = std::getenv("VRT_REG_THREADS")) r->force_threads = std::max(64, std::min(1024, std::atoi(e) / 64 * 64));
     r->device = device;
     r->nz = nz; r->nx = nx; r->ny = ny;
     r->h_g.assign(z, z + nz);
@@ -572,7 +574,7 @@ extern "C" int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const do
             while (threads < 1024 && n_solve * threads * 2 <= 256 * 1024 && (int64_t)threads * 2 <= (nx - 2) * (ny - 2))
                 threads *= 2;
     }
-    if (const char *e = std::getenv("VRT_REG_THREADS")) threads = std::max(64, std::min(1024, std::atoi(e) / 64 * 64));
+    if (r->force_threads) threads = r->force_threads;
     if (threads <= 256)
         hipLaunchKernelGGL(k_regular_solve<256>, dim3((unsigned)n_solve), dim3((unsigned)threads), lds, st, ra);
     else

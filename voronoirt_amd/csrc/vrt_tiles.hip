@@ -1146,7 +1146,7 @@ static int ensure_step_streams(vrt_plan *p, int G)
     // two streams and as many up as down angles: one direction per stream, whose angles share the
     // S planes and the storage order (C4 11.85 -> 11.70 ms); otherwise dealt heaviest first
     const bool by_dir = G == 2 && p->n_up > 0 && std::abs(p->n_up - p->n_down) <= 1 &&
-                        !(std::getenv("VRT_STEP_GROUP_DIR") && std::atoi(std::getenv("VRT_STEP_GROUP_DIR")) == 0);
+                        p->tune.step_group_dir != 0;
     for (int gi = 0; gi < G; gi++) {
         p->step_group_off[(size_t)gi] = (int)list.size();
         if (by_dir) {                              // one direction per stream: its angles share the S planes
@@ -1266,7 +1266,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     // the pair level kernel (fp64 storage, layers <= 8192 sites) or the single-wavelength one
     // (VRT_STEP_SINGLE=1 selects the single-wavelength kernel on any grid: same results, for the tests)
     const bool single = steps && !patches && (kF32 || p->tile_max_layer_size > 8192 ||
-                                  (std::getenv("VRT_STEP_SINGLE") && std::atoi(std::getenv("VRT_STEP_SINGLE")) == 1));
+                                  p->tune.step_single == 1);
     // storage layout: wavelength pairs side by side on the layer-step path, plain planes on the
     // persistent tile path (sw_index); planes are padded to a whole number of blocks
     const int lb = steps ? 2 : 1;
@@ -1348,7 +1348,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     }
     VRT_HIP_TRY(hipGetLastError());
 
-    const bool debug = kDiag && std::getenv("VRT_TILE_DEBUG") != nullptr;
+    const bool debug = kDiag && p->tune.tile_debug;
     long long *d_dbg = nullptr;
     int64_t launches = 1;
     if (steps && A > 0) {
@@ -1377,30 +1377,28 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         for (int c = kStepPairs + 1; c <= kStepPairs + 2; c++)
             if ((npair + c - 1) / c * c - npair < (npair + sa.pairs_per_thread - 1) / sa.pairs_per_thread * sa.pairs_per_thread - npair)
                 sa.pairs_per_thread = c;
-        if (std::getenv("VRT_STEP_PAIRS")) sa.pairs_per_thread = std::max(1, std::atoi(std::getenv("VRT_STEP_PAIRS")));
+        if (p->tune.step_pairs > 0) sa.pairs_per_thread = p->tune.step_pairs;
         sa.chunks = (int)((p->tile_max_layer_size + 255) / 256);
-        sa.xcd_map = std::getenv("VRT_STEP_XCD") ? std::atoi(std::getenv("VRT_STEP_XCD")) : 2;
-        sa.debug_skip_levels = kDiag && std::getenv("VRT_DEBUG_SKIP_LEVELS") != nullptr;
+        sa.xcd_map = p->tune.step_xcd;
+        sa.debug_skip_levels = kDiag && p->tune.debug_skip_levels;
         // 1: S/alpha gathers off, 2: I gathers off, 4: coefficient stores off, 8: coefficient loads off,
         // 16: I stores off, 32: no linear_weights arithmetic, 64: level kernel keeps the storage-order thread assignment
-        sa.debug_flags = (kDiag && std::getenv("VRT_DEBUG_FLAGS")) ? std::atoi(std::getenv("VRT_DEBUG_FLAGS")) : 0;
+        sa.debug_flags = kDiag ? p->tune.debug_flags : 0;
         if ((sa.debug_flags & ~(64 | 128)) || sa.debug_skip_levels) {   // (256, 512, 1024: single-wavelength level kernel)
             static bool warned = false;
             if (!warned) std::fprintf(stderr, "[vrt] VRT_DEBUG_FLAGS / VRT_DEBUG_SKIP_LEVELS set: timing diagnostics, the results are WRONG\n");
             warned = true;
         }
         const int Lmax = std::max(ta.nlayers[0] * (use_dir[0] ? 1 : 0), ta.nlayers[1] * (use_dir[1] ? 1 : 0));
-        const int force_K = std::getenv("VRT_STEP_K") ? std::atoi(std::getenv("VRT_STEP_K")) : 0;
+        const int force_K = p->tune.step_K;
         // The angles are dealt (heaviest first) to a few internal streams that advance through
         // the layers independently: the (angle, wavelength) problems of different streams share
         // nothing, so one stream's launches fill the tail of the other's (612 level workgroups
         // are 2.4 rounds of the 256 CUs: a lone launch idles a fifth of the chip in its last round).
-        int G = 2;
-        if (const char *e = std::getenv("VRT_STEP_STREAMS")) G = std::atoi(e);
-        G = std::max(1, std::min({G, 4, A}));
+        const int G = std::max(1, std::min({p->tune.step_streams, 4, A}));
         if ((rc = ensure_step_streams(p, G))) return rc;
         // level workgroups -> XCDs: contiguous cost-balanced runs (VRT_STEP_LEVEL_MAP=0: round-robin)
-        const bool use_map = !patches && !(std::getenv("VRT_STEP_LEVEL_MAP") && std::atoi(std::getenv("VRT_STEP_LEVEL_MAP")) == 0);
+        const bool use_map = !patches && p->tune.step_level_map != 0;
         if (use_map && (rc = build_level_map(p, G, single ? (int)nlam : npair))) return rc;
         if (patches && (rc = ensure_patch_work(p, G, p->h_step_angles, p->step_group_off))) return rc;
         sa.level_map = nullptr;
@@ -1435,7 +1433,8 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                 if (n_list == 0) continue;
                 if (patches) {               // ONE fused launch per layer and stream
                     // pairs per workgroup: the plan's Q, or 1 when that would leave half of every group empty
-                    const int Q = (npair % p->patch_Q != 0 && npair < 2 * p->patch_Q && patch_shape_exists(p->patch_K, 1, p->patch_NT)) ? 1 : p->patch_Q;
+                    int Q = p->tune.patch_Q;
+                    if (!patch_shape_exists(p->patch_K, Q, p->patch_NT) || (npair % Q != 0 && npair < 2 * Q)) Q = 1;
                     if ((rc = launch_patch_layer(p, sa.ta, npair, layer, gi, Q, sg, kF32))) return rc;
                     launches += 1;
                     continue;
@@ -1495,11 +1494,11 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                 const dim3 grid((unsigned)((size_t)A * (size_t)nlam));
                 // layers of up to 3072 sites: 768 threads x 4 sites in ONE phase-1 batch (the 168 VGPRs of
                 // 3 waves per SIMD hold its 48 loads); larger layers: 1024 threads, batches of two
-                const bool wide = p->tile_max_layer_size <= 3072 && !(std::getenv("VRT_TILE_WIDE") && std::atoi(std::getenv("VRT_TILE_WIDE")) == 0);
+                const bool wide = p->tile_max_layer_size <= 3072 && p->tune.tile_wide != 0;
                 // layers of at most 4096 sites: the two-launch form (chip-wide I-independent
                 // coefficients, then persistent level workgroups; VRT_TILE_PRE=0: the one-launch kernel)
                 const bool pre = p->tile_max_layer_size <= kPreMaxLayer && p->t_code_ss &&
-                                 !(std::getenv("VRT_TILE_PRE") && std::atoi(std::getenv("VRT_TILE_PRE")) == 0);
+                                 p->tune.tile_pre != 0;
                 if (pre) {
                     const size_t ntask = (size_t)A * (size_t)nlam;
                     if ((rc = ensure_dev(p->ws_cg[0], p->ws_cg_cap[0], 3 * ntask * (size_t)n))) return rc;
