@@ -4,8 +4,9 @@
   C2  ~250k-site Voronoi (246 420), ul7n12 x 1 λ -- the whole J against the oracle
   C3  ~1M sites, ul9n20 x 20 λ, shared α -- a sample of directions x wavelengths + properties
   C4  ~1M sites, ul7n12 x 51 λ, PER-ANGLE α (caller layout and the native layout)
-  C5  4M sites (4 011 544), ul9n20, fp32 storage -- properties + one up / one down single solve
-      against the fp64 oracle at 5e-6
+  C5  4M sites (4 011 544), ul9n20 x 100 λ, fp32 storage -- properties + up / down single solves at
+      wavelengths 1 and 97 against the fp64 oracle at 5e-6
+  +   the in-process tessellation at 250 000 and 1 000 000 density-stratified sites
 
 Full-size parity uses the same seeded inputs on both sides; where the oracle would take minutes
 the comparison is on a sample of (direction, wavelength) problems -- every problem is independent
@@ -192,7 +193,11 @@ def test_C4_1M_per_angle_alpha_51_wavelengths(grid_1m):
 
 
 # ---- C5 ---------------------------------------------------------------------------------------------
-def test_C5_4M_sites_fp32_storage():
+def test_C5_4M_sites_fp32_storage_100_wavelengths():
+    """BASELINE configs[4] at its full size: 4 011 544 sites x ul9n20 x 100 wavelengths, fp32 storage (S, α, J
+    1.6 GB each, the per-angle intensities 32 GB).  Fields are generated on the device; the oracle solves one up
+    and one down ray at wavelength indices either side of the 64-wavelength knee (1 and 97) on the float32-
+    rounded inputs; determinism, bounds and linearity at full size."""
     import torch
     a, c = synth.BCC_CONFIGS["C5"]
     pos, nbr, bounds = synth.bcc_grid(a, c, seed=1998)
@@ -200,16 +205,21 @@ def test_C5_4M_sites_fp32_storage():
     n = hs.n
     assert n == 4011544
     w, th, ph, nq = vrt.read_quadrature("ul9n20.dat")
-    nlam = 4
-    S, al = _fields(pos, bounds, nlam, 17)
+    nlam = 100
     so = orc.make_sites(pos, nbr, bounds)
     for key in ("layers_up", "layers_down", "perm_up", "perm_down"):
         assert np.array_equal(getattr(hs, key), getattr(so, key)), key
-    n1 = int(so.layers_up[1] - 1)
-    I0 = S[so.perm_up[:n1] - 1].copy()
-    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
     dev = torch.device("cuda", 0)
-    Sd, Ad, I0d = (torch.from_numpy(x.astype(np.float32)).to(dev) for x in (S, al, I0))
+    g = torch.Generator(device=dev)
+    g.manual_seed(17)
+    z = torch.as_tensor(pos[:, 0], device=dev, dtype=torch.float32)
+    Sd = (1.0 + 0.5 * torch.sin(2 * np.pi * (z - bounds[0]) / (bounds[1] - bounds[0]))[:, None]
+          + 0.1 * torch.rand((n, nlam), generator=g, device=dev, dtype=torch.float32)).contiguous()
+    Ad = ((1e-2 * torch.exp(-(z - bounds[0]) / 0.7e6))[:, None]
+          * (1.0 + 0.1 * torch.rand((n, nlam), generator=g, device=dev, dtype=torch.float32))).contiguous()
+    n1 = int(so.layers_up[1] - 1)
+    I0d = Sd[torch.as_tensor(so.perm_up[:n1] - 1, device=dev)].contiguous()
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
     st = torch.cuda.current_stream().cuda_stream
 
     def solve(Sx, I0x, want_I=False):
@@ -221,22 +231,111 @@ def test_C5_4M_sites_fp32_storage():
         return J, Io
 
     J1, Io = solve(Sd, I0d, want_I=True)
+    assert plan.last_path == "patches"
     up_i = next(i for i in range(nq) if th[i] > 90 and th[i] < 130)
     dn_i = next(i for i in range(nq) if th[i] < 90 and th[i] > 50)
-    S64, al64, I064 = (x.astype(np.float32).astype(np.float64) for x in (S, al, I0))   # what the device was given
-    ref = orc.Delaunay_upII(orc.direction(th[up_i], ph[up_i]), S64[:, 1].copy(), I064[:, 1].copy(),
-                            al64[:, 1].copy(), so, 3)
-    assert _rel(Io[up_i, :, 1].cpu().numpy().astype(np.float64), ref) < RTOL_F32
-    ref = orc.Delaunay_downII(orc.direction(th[dn_i], ph[dn_i]), S64[:, 2].copy(),
-                              np.zeros(so.layers_down[1] - 1), al64[:, 2].copy(), so, 3)
-    assert _rel(Io[dn_i, :, 2].cpu().numpy().astype(np.float64), ref) < RTOL_F32
+    for l, a_i in ((1, up_i), (97, dn_i), (97, up_i)):
+        S64, al64 = (x[:, l].cpu().numpy().astype(np.float64) for x in (Sd, Ad))      # what the device was given
+        k = orc.direction(th[a_i], ph[a_i])
+        if th[a_i] > 90:
+            ref = orc.Delaunay_upII(k, S64, I0d[:, l].cpu().numpy().astype(np.float64), al64, so, 3)
+        else:
+            ref = orc.Delaunay_downII(k, S64, np.zeros(so.layers_down[1] - 1), al64, so, 3)
+        assert _rel(Io[a_i, :, l].cpu().numpy().astype(np.float64), ref) < RTOL_F32, (l, a_i)
     del Io
+    torch.cuda.empty_cache()
     # properties at full size: determinism, bounds (convex combinations of S and I_0), linearity
     J2, _ = solve(Sd, I0d)
     assert torch.equal(J1, J2)
-    assert J1.min().item() >= 0.0 and J1.max().item() <= float(S.max()) * (1 + 1e-5)
+    assert J1.min().item() >= 0.0 and J1.max().item() <= float(Sd.max().item()) * (1 + 1e-5)
     J3, _ = solve(Sd * 2.0, I0d * 2.0)
     assert ((J3 - 2.0 * J1).abs().max() / J3.abs().max()).item() < 1e-5
+    plan.close()
+    hs.close()
+
+
+# ---- in-process tessellation -> device path --------------------------------------------
+def _stratified_sites(n, seed, H=2.0e6):
+    """density ~ exp(-z / H) like sample_from_invNH_invT (src/sample_grids.jl:223-230) in the Bifrost-sized box"""
+    bounds = (-0.5e6, 14.0e6, 0.0, 6.0e6, 0.0, 6.0e6)
+    rng = np.random.default_rng(seed)
+    u = rng.random(n)
+    Lz = bounds[1] - bounds[0]
+    pos = np.stack([bounds[0] - H * np.log(1.0 - u * (1.0 - np.exp(-Lz / H))),
+                    bounds[2] + rng.random(n) * (bounds[3] - bounds[2]),
+                    bounds[4] + rng.random(n) * (bounds[5] - bounds[4])], axis=1)
+    return pos, bounds
+
+
+def test_tessellated_250k_stratified_sites_full_J():
+    """`voro` (rt_preprocessing/output_sites.cc:35-49, here vrt_tessellate) -> VoronoiSites -> J_λ_voronoi on
+    250 000 density-stratified sites (layers of up to ~11 000 sites): ul7n12 x 4 wavelengths, the whole J
+    against the oracle on the default device path."""
+    pos, bounds = _stratified_sites(250000, 11)
+    nbr = vrt.voro(pos, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    for key in ("layers_up", "layers_down", "perm_up", "perm_down"):
+        assert np.array_equal(getattr(hs, key), getattr(so, key)), key
+    assert max(np.diff(hs.layers_up).max(), np.diff(hs.layers_down).max()) > 8192      # beyond the pair-tile kernels
+    S, al = _fields(pos, bounds, 4, 21)
+    I0 = S[so.perm_up[: so.layers_up[1] - 1] - 1]
+    J = vrt.J_lambda_voronoi(S, al, hs, "ul7n12.dat", I0_up=I0)
+    assert list(hs._plans.values())[0].last_path == "patches"
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
+    assert _rel(J, ref) < RTOL
+    hs.close()
+
+
+def test_tessellated_1M_stratified_sites_sample_of_directions():
+    """The reference's production shape (compare_line.jl:64-68: 1 050 232 sites sampled ~ N_H / T): 1 000 000
+    density-stratified sites tessellated in-process, BFS layers of ~30 000 sites -- beyond every
+    whole-layer kernel, so the layers are cut into patches.  One up and one down direction x 2 wavelengths
+    against the oracle; J = Σ w I; per-angle alpha in the native layout is accepted."""
+    import torch
+    pos, bounds = _stratified_sites(1000000, 12)
+    nbr = vrt.voro(pos, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    assert max(np.diff(hs.layers_up).max(), np.diff(hs.layers_down).max()) > 18432
+    n, nlam = hs.n, 6
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    S, al = _fields(pos, bounds, nlam, 5)
+    n1 = int(so.layers_up[1] - 1)
+    I0 = S[so.perm_up[:n1] - 1].copy()
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
+    dev = torch.device("cuda", 0)
+    Sd, Ad, I0d = (torch.from_numpy(x).to(dev) for x in (S, al, I0))
+    Iout = torch.empty((nq, n, nlam), dtype=torch.float64, device=dev)
+    Jd = torch.empty((n, nlam), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=Jd.data_ptr(),
+                     dI0_up=I0d.data_ptr(), dI_out=Iout.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert plan.last_path == "patches"
+    ups = [i for i in range(nq) if th[i] > 90]
+    downs = [i for i in range(nq) if th[i] < 90]
+    for a_i, l in ((ups[1], 0), (downs[4], 5)):
+        k = orc.direction(th[a_i], ph[a_i])
+        if th[a_i] > 90:
+            ref = orc.Delaunay_upII(k, S[:, l].copy(), I0[:, l].copy(), al[:, l].copy(), so, 3)
+        else:
+            ref = orc.Delaunay_downII(k, S[:, l].copy(), np.zeros(so.layers_down[1] - 1), al[:, l].copy(), so, 3)
+        assert _rel(Iout[a_i, :, l].cpu().numpy(), ref) < RTOL, (a_i, l)
+    Jsum = torch.zeros_like(Jd)
+    for i in range(nq):
+        Jsum += w[i] * Iout[i]
+    assert (Jsum - Jd).abs().max().item() <= 1e-13 * Jd.abs().max().item()
+    # the native per-angle alpha layout works on such a grid (the device-resident Λ-iteration's input)
+    native = torch.empty(plan.native_alpha_count(nlam), dtype=torch.float64, device=dev)
+    A3 = Ad[None].expand(nq, n, nlam).contiguous()
+    plan.alpha_to_native_dev(nlam, nlam, A3.data_ptr(), native.data_ptr(), stream=st)
+    Jn = torch.empty_like(Jd)
+    plan.execute_dev(nlam, nlam, Sd.data_ptr(), native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE, w, dJ=Jn.data_ptr(),
+                     dI0_up=I0d.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert torch.equal(Jn, Jd)
     plan.close()
     hs.close()
 
