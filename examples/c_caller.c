@@ -7,6 +7,12 @@
  *                           batched: ul7n12's 12 angles, 5 wavelengths, alpha_tot per (λ, site,
  *                           angle), I_0 of the bottom layer for the up rays, ONE
  *                           vrt_plan_execute, prints J (nλ, n)
+ *   scenario 3 (argv[1]=3, argv[2]=inputs file): the caller julia/VoronoiRT_hip.jl's Λ_voronoi is -- the
+ *                           reference's Λ_voronoi loop (src/lambda_iteration.jl:205-300) over vrt_lambda_create /
+ *                           _iterate / _get with HOST arrays: per iteration only the criterion's scalar
+ *                           comes back; prints the history, J, S_new and the populations.  The per-site
+ *                           inputs (what Λ_voronoi derives before its loop) are read from a binary file
+ *                           the test writes, as the Julia driver would hand over its arrays.
  * Build:
  *   gcc -std=c99 -I include examples/c_caller.c -o c_caller -L voronoirt_amd -lvrt_hip \
  *       -Wl,-rpath,$PWD/voronoirt_amd -lm
@@ -72,6 +78,88 @@ static int scenario_J(vrt_grid *g, int n)
     return rc ? 1 : 0;
 }
 
+/* the Λ_voronoi caller: library-owned device state, one call per iteration */
+static double *rd(FILE *f, size_t count)
+{
+    double *a = malloc(sizeof(double) * (count ? count : 1));
+    if (fread(a, sizeof(double), count, f) != count) { fprintf(stderr, "short inputs file\n"); exit(3); }
+    return a;
+}
+
+static int scenario_lambda(vrt_grid *g, int n, const char *path)
+{
+    enum { NA = 12 };
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "cannot read %s\n", path); return 3; }
+    int64_t head[4], blocks[6];
+    double sc[9];
+    if (fread(head, sizeof(int64_t), 4, f) != 4 || fread(blocks, sizeof(int64_t), 6, f) != 6 ||
+        fread(sc, sizeof(double), 9, f) != 9 || head[0] != n) {
+        fprintf(stderr, "bad inputs file\n");
+        return 3;
+    }
+    const int64_t nlam = head[1], maxiter = head[2];
+    const double eps_conv = 0.0;
+    vrt_line_case lc;
+    lc.nlam = nlam;
+    for (int q = 0; q < 6; q++) lc.blocks[q] = blocks[q];
+    lc.lambda0 = sc[0]; lc.c0 = sc[1]; lc.strength_const = sc[2]; lc.Bij = sc[3]; lc.Bji = sc[4];
+    lc.sigma_bb_const = sc[5]; lc.hc_over_kB = sc[6]; lc.pref_ij = sc[7]; lc.pref_ji = sc[8];
+    lc.lambda = rd(f, (size_t)nlam);
+    lc.velocity = rd(f, 3 * (size_t)n);
+    lc.doppler_width = rd(f, (size_t)n);
+    lc.gamma_static = rd(f, (size_t)n);
+    lc.gamma_unsold = rd(f, (size_t)n);
+    lc.alpha_cont = rd(f, (size_t)n);
+    lc.eps = rd(f, (size_t)n);
+    lc.temperature = rd(f, (size_t)n);
+    lc.atom_density = rd(f, (size_t)n);
+    lc.B0 = rd(f, (size_t)nlam * (size_t)n);
+    lc.lte_populations = rd(f, 3 * (size_t)n);
+    lc.C = rd(f, 9 * (size_t)n);
+    lc.planck2 = rd(f, (size_t)nlam);
+    lc.sigma_bf1 = rd(f, (size_t)(blocks[3] - blocks[2]));
+    lc.sigma_bf2 = rd(f, (size_t)(blocks[5] - blocks[4]));
+    fclose(f);
+    double k[3 * NA], w[NA];
+    int dirs[NA];
+    for (int a = 0; a < NA; a++) {
+        w[a] = UL7N12[a][0];
+        vrt_direction(UL7N12[a][1], UL7N12[a][2], k + 3 * a);
+        dirs[a] = UL7N12[a][1] > 90 ? 1 : (UL7N12[a][1] < 90 ? -1 : 0);
+    }
+    vrt_plan *plan = NULL;
+    vrt_lambda *ses = NULL;
+    if (vrt_plan_create_ex(g, NA, k, dirs, 3, &plan) || vrt_lambda_create(plan, &lc, w, &ses)) {
+        fprintf(stderr, "vrt_lambda_create: %s\n", vrt_last_error());
+        return 1;
+    }
+    /* Λ_voronoi: while criterion(S_new, S_old, ϵ, i, maxiter) ... (lambda_iteration.jl:253); the criterion starts at 1 */
+    double diff = 1.0;
+    int64_t i = 0;
+    while (diff > eps_conv && i < maxiter) {
+        if (vrt_lambda_iterate(ses, &diff)) {
+            fprintf(stderr, "vrt_lambda_iterate: %s\n", vrt_last_error());
+            return 1;
+        }
+        printf("hist %lld %.17g\n", (long long)(i + 1), diff);
+        i++;
+    }
+    double *J = malloc(sizeof(double) * (size_t)nlam * (size_t)n), *S = malloc(sizeof(double) * (size_t)nlam * (size_t)n);
+    double *P = malloc(sizeof(double) * 3 * (size_t)n);
+    if (vrt_lambda_get(ses, J, S, P, NULL, NULL)) {
+        fprintf(stderr, "vrt_lambda_get: %s\n", vrt_last_error());
+        return 1;
+    }
+    for (int s = 0; s < n; s++)
+        for (int64_t l = 0; l < nlam; l++)
+            printf("JS %d %lld %.17g %.17g\n", s + 1, (long long)(l + 1), J[l + nlam * s], S[l + nlam * s]);
+    for (int s = 0; s < n; s++) printf("P %d %.17g %.17g %.17g\n", s + 1, P[s], P[s + n], P[s + 2 * n]);
+    vrt_lambda_destroy(ses);
+    vrt_plan_destroy(plan);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     /* 4 x 5 x 6 simple-cubic lattice in the unit cube, 6 neighbours per site, x/y periodic,
@@ -105,6 +193,11 @@ int main(int argc, char **argv)
     }
     if (argc > 1 && atoi(argv[1]) == 2) {
         int rc = scenario_J(g, N);
+        vrt_grid_destroy(g);
+        return rc;
+    }
+    if (argc > 2 && atoi(argv[1]) == 3) {
+        int rc = scenario_lambda(g, N, argv[2]);
         vrt_grid_destroy(g);
         return rc;
     }

@@ -251,6 +251,67 @@ int vrt_line_opacity_dev(vrt_plan *p, int64_t nlam, const double *lambda, double
                          const double *d_line_strength, const double *d_alpha_cont, double *d_alpha_native,
                          void *stream);
 
+/* ---- the same from HOST arrays: the whole body of J_λ_voronoi, line case, in one call --------------------
+ * src/lambda_iteration.jl:72-111 for a host without device arrays of its own (the reference's Julia driver):
+ * uploads the seven per-site line vectors, λ and S (about (nλ + 7) n doubles -- NOT α_tot (nλ, n, n_angles),
+ * which is nλ n_angles n), makes α_tot of every angle on the device in the native layout, solves every
+ * angle x wavelength and returns J.  Arguments as vrt_line_opacity_dev / vrt_plan_execute, all host pointers;
+ * gamma[n] is γ_constant of the current populations (or vrt_lambda_* below keeps the whole loop on the device). */
+int vrt_plan_execute_line(vrt_plan *p, int64_t nlam, int64_t ld, const double *lambda, double lambda0, double c0,
+                          const double *velocity, const double *doppler_width, const double *gamma,
+                          const double *line_strength, const double *alpha_cont, const double *S, const double *I0_up,
+                          const double *I0_down, const double *weights, double *J);
+
+/* ---- population-dependent line terms on the device ------------------------------------------------------
+ *   gamma[i]         = gamma_static[i] + gamma_unsold[i] (n_1 + n_2)     γ_constant, src/broadening.jl:63-82, which
+ *                      J_λ_voronoi evaluates with populations[:,1] .+ populations[:,2] in EVERY iteration
+ *                      (lambda_iteration.jl:72-75).  gamma_static = natural width + linear + quadratic Stark
+ *                      (electron density and temperature only: fixed), gamma_unsold = γ_unsold per unit
+ *                      neutral-hydrogen density (van der Waals; linear in the density) -- both come from the
+ *                      caller, whose Transparency.jl holds the constants
+ *   line_strength[i] = strength_const (n_1 B_ij - n_2 B_ji)              αline_λ, src/line.jl:219-225
+ * populations (n, 3) as Julia's; gamma or line_strength may be NULL.  Device pointers. */
+int vrt_line_terms_dev(vrt_grid *g, const double *d_gamma_static, const double *d_gamma_unsold,
+                       const double *d_populations, double strength_const, double Bij, double Bji, double *d_gamma,
+                       double *d_line_strength, void *stream);
+
+/* ---- Λ_voronoi's loop with library-owned device state (src/lambda_iteration.jl:205-300) -----------------
+ * For a single-process host with HOST arrays: create uploads the per-site inputs Λ_voronoi derives before its
+ * loop, starts in LTE with S = B_0 (:232-240); every vrt_lambda_iterate is one pass of the loop body --
+ *   γ, line strength of the current populations -> α_tot of every angle (:72-96) -> J_λ (:84-111) ->
+ *   S_new = (1 - ε) J + ε B_0 and max |1 - S_old/S_new| (:261-263, :325-349) -> R, populations (:269, :274)
+ * -- and returns that maximum (NaN like Julia's); vrt_lambda_get downloads what the caller wants to keep
+ * (the reference checkpoints populations and S_new each iteration, :280-281).  All arrays host, (…) = Julia
+ * dims; plain numbers in one unit system, unit factors folded into the constants as in
+ * vrt_rates_populations_dev.  weights[n_angles] of the plan's quadrature. */
+typedef struct vrt_lambda vrt_lambda;
+typedef struct vrt_line_case {
+    int64_t nlam;
+    const double *lambda;            /* [nlam]: bound-bound block first, then the two bound-free blocks */
+    int64_t blocks[6];               /* their [lo, hi) offsets, 0-based (line.λidx) */
+    double lambda0, c0;
+    const double *velocity;          /* (3, n) rows z, x, y */
+    const double *doppler_width;     /* [n] ΔλD */
+    const double *gamma_static;      /* [n] see vrt_line_terms_dev */
+    const double *gamma_unsold;      /* [n] */
+    const double *alpha_cont;        /* [n] */
+    const double *eps;               /* [n] destruction probability ε */
+    const double *temperature;       /* [n] */
+    const double *atom_density;      /* [n] */
+    const double *B0;                /* (nlam, n) Planck function */
+    const double *lte_populations;   /* (n, 3) */
+    const double *C;                 /* (3, 3, n) collisional rates */
+    const double *planck2;           /* [nlam] 2 h c0² / λ⁵ in J's unit */
+    const double *sigma_bf1, *sigma_bf2;   /* σic per wavelength of the two bound-free blocks */
+    double strength_const, Bij, Bji;       /* αline_λ = strength_const (n_1 B_ij - n_2 B_ji) φ */
+    double sigma_bb_const, hc_over_kB, pref_ij, pref_ji;
+} vrt_line_case;
+int vrt_lambda_create(vrt_plan *p, const vrt_line_case *lc, const double *weights, vrt_lambda **out);
+int vrt_lambda_iterate(vrt_lambda *s, double *max_rel_change);
+/* J, S (nlam, n), populations (n, 3), R (3, 3, n), gamma [n] of the last iteration; any pointer may be NULL */
+int vrt_lambda_get(vrt_lambda *s, double *J, double *S, double *populations, double *R, double *gamma);
+void vrt_lambda_destroy(vrt_lambda *s);
+
 /* ---- rates + populations of the Λ-iteration epilogue on the device --------
  * calculate_R (src/rates.jl:154-201: Rij / Rji λ-trapezoids :226-364, σij with the site's static
  * Voigt profile :374-416, Gij :459-476) and get_revised_populations (src/populations.jl:191-221,

@@ -94,6 +94,8 @@ def lib():
         L.orc_calculate_R.restype = None
         L.orc_revised_populations.argtypes = [_c_i64, _p_dbl, _p_dbl, _p_dbl, _p_dbl]
         L.orc_revised_populations.restype = None
+        L.orc_line_terms.argtypes = [_c_i64, _p_dbl, _p_dbl, _p_dbl, _c_dbl, _c_dbl, _c_dbl, _p_dbl, _p_dbl]
+        L.orc_line_terms.restype = None
         L.orc_max_threads.argtypes = []
         L.orc_max_threads.restype = ctypes.c_int
         _lib = L
@@ -375,3 +377,13 @@ def revised_populations(R, C, atom_density):
     out = np.zeros((3, n))
     lib().orc_revised_populations(n, _d(R), _d(C), _d(atom_density), _d(out))
     return out
+
+
+def line_terms(gamma_static, gamma_unsold, populations, strength_const, Bij, Bji):
+    """(γ_constant of the populations (3, n), src/broadening.jl:63-82 as called at lambda_iteration.jl:72-75;
+    αline_λ's population factor, src/line.jl:219-225)"""
+    gs, gu, pops = _f64(gamma_static), _f64(gamma_unsold), _f64(populations)
+    n = gs.size
+    gamma, strength = np.zeros(n), np.zeros(n)
+    lib().orc_line_terms(n, _d(gs), _d(gu), _d(pops), strength_const, Bij, Bji, _d(gamma), _d(strength))
+    return gamma, strength

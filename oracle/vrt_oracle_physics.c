@@ -252,3 +252,26 @@ void orc_revised_populations(i64 n, const double *R, const double *C, const doub
         populations[i] = atom_density[i] - (x[0] + x[1]);        /* :219 */
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * γ of the current populations and the λ-independent factor of αline_λ:
+ *   γ_constant, src/broadening.jl:63-82:  γ = γ_unsold(const, T, n_HI) + 4.702e8 + γ_linear_stark(n_e, 2, 1)
+ *   + γ_quadratic_stark(n_e, T), which J_λ_voronoi evaluates every iteration with
+ *   n_HI = populations[:, 1] .+ populations[:, 2] (src/lambda_iteration.jl:72-75).  The three broadening
+ *   functions live in Transparency.jl (absent, unpinned); what the loop needs of them is their dependence on
+ *   the populations: only the van der Waals term has one, and it is linear in the neutral density.  So
+ *     γ[i] = gamma_static[i] + gamma_unsold[i] (n_1[i] + n_2[i])
+ *   with gamma_static = natural + Stark widths and gamma_unsold = γ_unsold per unit density, both per site
+ *   from the caller.
+ *   αline_λ, src/line.jl:219-225:  strength[i] = strength_const (n_1 B_ij - n_2 B_ji)
+ * populations (n, 3) column-major.
+ * ------------------------------------------------------------------------------------------ */
+void orc_line_terms(i64 n, const double *gamma_static, const double *gamma_unsold, const double *populations,
+                    double strength_const, double Bij, double Bji, double *gamma, double *strength)
+{
+    for (i64 i = 0; i < n; i++) {
+        const double n1 = populations[i], n2 = populations[i + n];
+        gamma[i] = gamma_static[i] + gamma_unsold[i] * (n1 + n2);
+        strength[i] = strength_const * (n1 * Bij - n2 * Bji);
+    }
+}

@@ -683,6 +683,44 @@ def test_plain_c_caller_plays_J_lambda_voronoi(tmp_path):
     assert _rel(got, ref) < RTOL
 
 
+def test_plain_c_caller_plays_Lambda_voronoi(tmp_path):
+    """Scenario 3 of examples/c_caller.c is the caller julia/VoronoiRT_hip.jl's Λ_voronoi is: the reference's loop
+    (src/lambda_iteration.jl:205-300) over vrt_lambda_create / _iterate / _get with host arrays -- library-owned
+    device state, one call per iteration, γ following the populations.  Against the same loop driven by the oracle."""
+    import subprocess
+    from test_physics import _lambda_case, _oracle_lambda_iteration
+    exe = _build_c_caller(tmp_path)
+    n, so = _c_caller_lattice()
+    case = _lambda_case(so.positions, (0.0, 1.0, 0.0, 1.0, 0.0, 1.0), 3)
+    maxiter = 3
+    nlam = case.lam.size
+    blob = tmp_path / "lambda_inputs.bin"
+    with open(blob, "wb") as f:
+        np.array([n, nlam, maxiter, 0], dtype=np.int64).tofile(f)
+        np.asarray(case.blocks, dtype=np.int64).tofile(f)
+        np.array([case.lambda0, case.c0, case.strength_const, case.Bij, case.Bji, case.sigma_bb_const, case.hc_over_kB,
+                  case.pref_ij, case.pref_ji]).tofile(f)
+        for a in (case.lam, case.velocity, case.doppler, case.gamma_static, case.gamma_unsold, case.alpha_cont, case.eps,
+                  case.temperature, case.atom_density, case.B0, case.lte, case.C, case.planck2, case.sigma_bf1,
+                  case.sigma_bf2):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+    out = subprocess.run([str(exe), "3", str(blob)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    hist, J, S, P = [], np.zeros((n, nlam)), np.zeros((n, nlam)), np.zeros((3, n))
+    for ln in out.stdout.strip().splitlines():
+        t = ln.split()
+        if t[0] == "hist":
+            hist.append(float(t[2]))
+        elif t[0] == "JS":
+            J[int(t[1]) - 1, int(t[2]) - 1], S[int(t[1]) - 1, int(t[2]) - 1] = float(t[3]), float(t[4])
+        else:
+            P[:, int(t[1]) - 1] = [float(x) for x in t[2:5]]
+    J_ref, S_ref, pops_ref, hist_ref = _oracle_lambda_iteration(case, so, "ul7n12.dat", maxiter)
+    assert len(hist) == maxiter and np.allclose(hist, hist_ref, rtol=1e-8)
+    assert np.abs(J - J_ref).max() < 1e-9 * np.abs(J_ref).max() and np.abs(S / S_ref - 1).max() < 1e-9
+    assert np.abs(P / pops_ref - 1).max() < 1e-9
+
+
 def test_degenerate_grids_and_plans(path):
     """Edge cases on every device path: a single-layer grid (every cell touches the wall: no sweep
     at all, I = I_0 except the never-visited last site), a two-layer grid, one angle / one

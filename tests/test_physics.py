@@ -237,7 +237,7 @@ def _lambda_case(pos, bounds, seed):
     strength_const = 60.0 / box * doppler.mean() / n1.mean()       # line-centre τ of order 100 across the box
     return vrt.LineCase(
         lam=lam, blocks=c["blocks"], lambda0=c["lambda0"], c0=C0, velocity=rng.normal(0, 3e3, (n, 3)), doppler=doppler,
-        gamma=4.7e8 + 10 ** rng.uniform(7, 9, n), alpha_cont=0.05 / box * np.exp(-2 * z), eps=10 ** rng.uniform(-2.5, -0.5, n),
+        gamma_static=4.702e8 + 10 ** rng.uniform(7, 8.7, n), gamma_unsold=10 ** rng.uniform(-8.5, -7.5, n), alpha_cont=0.05 / box * np.exp(-2 * z), eps=10 ** rng.uniform(-2.5, -0.5, n),
         temperature=T, atom_density=lte.sum(axis=0), B0=B0, lte=lte, C=Cm, planck2=2.0 * (c["lambda0"] / lam) ** 5,
         sigma_bf1=1e-21 * (lam[21:27] / lam[26]) ** 3, sigma_bf2=2e-21 * (lam[27:33] / lam[32]) ** 3,
         strength_const=strength_const, Bij=Bij, Bji=0.25 * Bij, sigma_bb_const=2e-32,
@@ -253,13 +253,14 @@ def _oracle_lambda_iteration(case, so, quadrature, maxiter, eps_conv=0.0):
     hist, diff, i = [], np.inf, 0
     while diff > eps_conv and i < maxiter:
         S_old = S_new.copy()
-        strength = case.strength_const * (pops[0] * case.Bij - pops[1] * case.Bji)
+        # γ_constant of the current populations (lambda_iteration.jl:72-75) and αline_λ's population factor
+        gamma, strength = orc.line_terms(case.gamma_static, case.gamma_unsold, pops, case.strength_const, case.Bij, case.Bji)
         alpha = np.stack([orc.line_opacity(orc.direction(th[a], ph[a]), case.lam, case.lambda0, case.c0, case.velocity,
-                                           case.doppler, case.gamma, strength, case.alpha_cont) for a in range(nq)])
+                                           case.doppler, gamma, strength, case.alpha_cont) for a in range(nq)])
         J = orc.J_voronoi(w, th, ph, S_old, alpha, so, I0_up=case.B0[bottom], nthreads=8)
         S_new = (1 - case.eps)[:, None] * J + case.eps[:, None] * case.B0
         diff = float(np.abs(1 - S_old / S_new).max())
-        R = orc.calculate_R(case.lam, case.blocks, J, case.planck2, case.lambda0, case.c0, case.doppler, case.gamma,
+        R = orc.calculate_R(case.lam, case.blocks, J, case.planck2, case.lambda0, case.c0, case.doppler, gamma,
                             case.sigma_bb_const, case.sigma_bf1, case.sigma_bf2, case.temperature, case.lte,
                             case.hc_over_kB, case.pref_ij, case.pref_ji)
         pops = orc.revised_populations(R, case.C, case.atom_density)
@@ -282,7 +283,11 @@ def test_oracle_lambda_iteration_is_well_posed(voro_small):
     assert np.abs(pops[1] / case.lte[1] - 1).max() > 1e-3          # the radiation field moved the populations
     strength = case.strength_const * (case.lte[0] * case.Bij - case.lte[1] * case.Bji)
     al = orc.line_opacity(orc.direction(180.0, 0.0), case.lam, case.lambda0, case.c0, case.velocity, case.doppler,
-                          case.gamma, strength, case.alpha_cont)
+                          case.gamma(case.lte), strength, case.alpha_cont)
+    g0, g3 = case.gamma(case.lte), case.gamma(pops)
+    assert np.abs(g3 / g0 - 1).max() > 1e-4                        # γ did follow the populations
+    assert np.array_equal(orc.line_terms(case.gamma_static, case.gamma_unsold, pops, case.strength_const, case.Bij,
+                                         case.Bji)[0], g3)
     tau = al.mean(axis=0) * (bounds[1] - bounds[0])
     assert tau[10] > 10 and tau[0] < 1 and tau[20] < 1
 
@@ -311,4 +316,31 @@ def test_gpu_lambda_voronoi_device_resident_loop(voro_small):
         J2, S2, pops2, hist2 = vrt.Lambda_voronoi(eps, 10, hs, case, "ul7n12.dat")
         assert len(hist2) == expect
         assert np.abs(S2 / _oracle_lambda_iteration(case, so, "ul7n12.dat", expect)[1] - 1).max() < 1e-9
+    # the same loop for a host without device arrays: library-owned device state, one call per iteration
+    Jh, Sh, ph_, hh = vrt.Lambda_voronoi_host(0.0, 4, hs, case, "ul7n12.dat")
+    assert np.array_equal(Jh, J) and np.array_equal(Sh, S) and np.array_equal(ph_, pops) and hh == hist
+    assert vrt.Lambda_voronoi_host(1.0, 10, hs, case, "ul7n12.dat")[3] == []
+    hs.close()
+
+
+@pytest.mark.gpu
+def test_gpu_J_line_from_host_arrays(voro_small):
+    """vrt_plan_execute_line: the body of J_λ_voronoi's line method (src/lambda_iteration.jl:72-111) from HOST arrays in
+    one call -- seven per-site vectors + S in, J out, α_tot (nλ, n, n_angles) made on the device -- against the
+    oracle's α_tot + J_λ_voronoi; γ from the given populations."""
+    pos, nbr, bounds = voro_small
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    case = _lambda_case(pos, bounds, 12)
+    rng = np.random.default_rng(2)
+    pops = case.lte * (1 + 0.2 * rng.random(case.lte.shape))
+    S = case.B0 * (1 + 0.3 * rng.random(case.B0.shape))
+    J = vrt.J_lambda_voronoi_line(S, pops, hs, case, "ul7n12.dat")
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    gamma, strength = orc.line_terms(case.gamma_static, case.gamma_unsold, pops, case.strength_const, case.Bij, case.Bji)
+    alpha = np.stack([orc.line_opacity(orc.direction(th[a], ph[a]), case.lam, case.lambda0, case.c0, case.velocity,
+                                       case.doppler, gamma, strength, case.alpha_cont) for a in range(nq)])
+    bottom = so.perm_up[: so.layers_up[1] - 1] - 1
+    ref = orc.J_voronoi(w, th, ph, S, alpha, so, I0_up=case.B0[bottom], nthreads=8)
+    assert np.abs(J - ref).max() < 1e-10 * np.abs(ref).max()
     hs.close()

@@ -24,6 +24,16 @@ vp = ctypes.c_void_p
 VRT_OK, VRT_EINVAL, VRT_EGRID, VRT_ENODEVICE, VRT_ENOMEM, VRT_EIO = 0, -1, -2, -3, -4, -5
 ALPHA_SITE, ALPHA_SITE_LAM, ALPHA_ANGLE_SITE_LAM, ALPHA_ANGLE_NATIVE = 0, 1, 2, 3
 
+class LineCaseStruct(ctypes.Structure):
+    """vrt_line_case of include/voronoirt.h"""
+    _fields_ = [("nlam", c_i64), ("lambda_", p_dbl), ("blocks", c_i64 * 6), ("lambda0", c_dbl), ("c0", c_dbl),
+                ("velocity", p_dbl), ("doppler_width", p_dbl), ("gamma_static", p_dbl), ("gamma_unsold", p_dbl),
+                ("alpha_cont", p_dbl), ("eps", p_dbl), ("temperature", p_dbl), ("atom_density", p_dbl), ("B0", p_dbl),
+                ("lte_populations", p_dbl), ("C", p_dbl), ("planck2", p_dbl), ("sigma_bf1", p_dbl), ("sigma_bf2", p_dbl),
+                ("strength_const", c_dbl), ("Bij", c_dbl), ("Bji", c_dbl), ("sigma_bb_const", c_dbl),
+                ("hc_over_kB", c_dbl), ("pref_ij", c_dbl), ("pref_ji", c_dbl)]
+
+
 # name -> (restype, argtypes): every symbol include/voronoirt.h declares
 PROTOTYPES = {
     "vrt_last_error": (ctypes.c_char_p, []),
@@ -60,6 +70,13 @@ PROTOTYPES = {
     "vrt_plan_native_alpha_count": (c_i64, [vp, c_i64]),
     "vrt_plan_alpha_to_native_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp]),
     "vrt_line_opacity_dev": (ctypes.c_int, [vp, c_i64, p_dbl, c_dbl, c_dbl, vp, vp, vp, vp, vp, vp, vp]),
+    "vrt_plan_execute_line": (ctypes.c_int, [vp, c_i64, c_i64, p_dbl, c_dbl, c_dbl, p_dbl, p_dbl, p_dbl, p_dbl, p_dbl,
+                                             p_dbl, p_dbl, p_dbl, p_dbl, p_dbl]),
+    "vrt_line_terms_dev": (ctypes.c_int, [vp, vp, vp, vp, c_dbl, c_dbl, c_dbl, vp, vp, vp]),
+    "vrt_lambda_create": (ctypes.c_int, [vp, ctypes.POINTER(LineCaseStruct), p_dbl, ctypes.POINTER(vp)]),
+    "vrt_lambda_iterate": (ctypes.c_int, [vp, p_dbl]),
+    "vrt_lambda_get": (ctypes.c_int, [vp, p_dbl, p_dbl, p_dbl, p_dbl, p_dbl]),
+    "vrt_lambda_destroy": (None, [vp]),
     "vrt_rates_populations_dev": (ctypes.c_int, [vp, c_i64, c_i64, p_dbl, p_i64, vp, p_dbl, c_dbl, c_dbl, vp, vp,
                                                  c_dbl, p_dbl, p_dbl, vp, vp, c_dbl, c_dbl, c_dbl, vp, vp, vp,
                                                  vp, vp]),

@@ -568,31 +568,136 @@ def rates_populations_dev(sites: VoronoiSites, lam, blocks, ld: int, dJ: int, pl
                                                 d_populations, stream or None))
 
 
+def line_terms_dev(sites: VoronoiSites, d_gamma_static: int, d_gamma_unsold: int, d_populations: int,
+                   strength_const: float, Bij: float, Bji: float, d_gamma: int = 0, d_line_strength: int = 0,
+                   stream: int = 0) -> None:
+    """γ of the current populations (γ_constant, src/broadening.jl:63-82, as J_λ_voronoi evaluates it every
+    iteration, lambda_iteration.jl:72-75) and the λ-independent factor of αline_λ (src/line.jl:219-225), on the
+    device (`vrt_line_terms_dev`; device pointers)."""
+    check(_lib.load().vrt_line_terms_dev(sites.handle, d_gamma_static or None, d_gamma_unsold or None, d_populations,
+                                         float(strength_const), float(Bij), float(Bji), d_gamma or None,
+                                         d_line_strength or None, stream or None))
+
+
 # ---- the Λ-iteration driver, device-resident (src/lambda_iteration.jl:205-300, Λ_voronoi) -------------
 class LineCase:
     """The per-site inputs Λ_voronoi derives before its loop (LTE populations, α_cont, B_0, ε, C; through
     Transparency.jl, which is outside this path) plus the line's constants, as plain numbers in ONE unit
     system.  Arrays: `lam` (nλ,) all wavelengths (bound-bound block first, then the two bound-free
-    blocks; `blocks` = their six [lo, hi) offsets), `velocity` (n, 3) [z, x, y], `doppler`, `gamma`,
-    `alpha_cont`, `eps`, `temperature`, `atom_density` (n,), `B0` (n, nλ), `lte` (3, n), `C` (n, 3, 3),
-    `planck2` (nλ,), `sigma_bf1`, `sigma_bf2` (one per wavelength of their block)."""
+    blocks; `blocks` = their six [lo, hi) offsets), `velocity` (n, 3) [z, x, y], `doppler`, `alpha_cont`,
+    `eps`, `temperature`, `atom_density` (n,), `B0` (n, nλ), `lte` (3, n), `C` (n, 3, 3), `planck2` (nλ,),
+    `sigma_bf1`, `sigma_bf2` (one per wavelength of their block).  γ_constant (src/broadening.jl:63-82) is
+    `gamma_static` + `gamma_unsold` (n_1 + n_2): the natural + Stark widths, fixed per site, and the van der
+    Waals width per unit neutral-hydrogen density, which follows the populations every iteration."""
+    FIELDS = ("lam", "blocks", "lambda0", "c0", "velocity", "doppler", "gamma_static", "gamma_unsold", "alpha_cont", "eps",
+              "temperature", "atom_density", "B0", "lte", "C", "planck2", "sigma_bf1", "sigma_bf2", "strength_const", "Bij",
+              "Bji", "sigma_bb_const", "hc_over_kB", "pref_ij", "pref_ji")
 
     def __init__(self, **kw):
-        for k in ("lam", "blocks", "lambda0", "c0", "velocity", "doppler", "gamma", "alpha_cont", "eps", "temperature",
-                  "atom_density", "B0", "lte", "C", "planck2", "sigma_bf1", "sigma_bf2", "strength_const", "Bij", "Bji",
-                  "sigma_bb_const", "hc_over_kB", "pref_ij", "pref_ji"):
+        for k in self.FIELDS:
             setattr(self, k, kw.pop(k))
         if kw:
             raise TypeError(f"unexpected fields {sorted(kw)}")
+
+    def gamma(self, populations) -> np.ndarray:
+        """γ_constant for populations (3, n)"""
+        pops = np.asarray(populations)
+        return np.asarray(self.gamma_static) + np.asarray(self.gamma_unsold) * (pops[0] + pops[1])
+
+    def c_struct(self):
+        """(vrt_line_case, the arrays it points into) for the host-pointer entry points"""
+        keep = {k: _f64(getattr(self, k)) for k in ("lam", "velocity", "doppler", "gamma_static", "gamma_unsold", "alpha_cont",
+                                                   "eps", "temperature", "atom_density", "B0", "lte", "C", "planck2",
+                                                   "sigma_bf1", "sigma_bf2")}
+        lc = _lib.LineCaseStruct()
+        lc.nlam = keep["lam"].size
+        lc.lambda_ = _d(keep["lam"])
+        for q, v in enumerate(np.asarray(self.blocks, dtype=np.int64).reshape(6)):
+            lc.blocks[q] = int(v)
+        lc.lambda0, lc.c0 = float(self.lambda0), float(self.c0)
+        for cname, k in (("velocity", "velocity"), ("doppler_width", "doppler"), ("gamma_static", "gamma_static"),
+                         ("gamma_unsold", "gamma_unsold"), ("alpha_cont", "alpha_cont"), ("eps", "eps"),
+                         ("temperature", "temperature"), ("atom_density", "atom_density"), ("B0", "B0"),
+                         ("lte_populations", "lte"), ("C", "C"), ("planck2", "planck2"), ("sigma_bf1", "sigma_bf1"),
+                         ("sigma_bf2", "sigma_bf2")):
+            setattr(lc, cname, _d(keep[k]))
+        for k in ("strength_const", "Bij", "Bji", "sigma_bb_const", "hc_over_kB", "pref_ij", "pref_ji"):
+            setattr(lc, k, float(getattr(self, k)))
+        return lc, keep
+
+
+def _quadrature_plan(sites: VoronoiSites, quadrature: str, n_sweeps: int):
+    w, th, ph, _ = read_quadrature(quadrature)
+    key = (os.path.basename(quadrature), int(n_sweeps))
+    plan = sites._plans.get(key)
+    if plan is None:
+        dirs = [1 if t > 90 else (-1 if t < 90 else 0) for t in th]
+        plan = FormalPlan(sites, quadrature_directions(th, ph), n_sweeps, dirs=dirs)
+        sites._plans[key] = plan
+    return plan, w
+
+
+def J_lambda_voronoi_line(S_lambda, populations, sites: VoronoiSites, case: LineCase, quadrature: str,
+                          n_sweeps: int = 3) -> np.ndarray:
+    """J_λ_voronoi, line method (src/lambda_iteration.jl:60-113), from HOST arrays through ONE call
+    (`vrt_plan_execute_line`): γ and the line strength of `populations` (3, n), α_tot of every angle made on the
+    device, I_0 = B_0 of the bottom layer for the up rays (:99-101), zeros for the down rays (:105-106)."""
+    plan, w = _quadrature_plan(sites, quadrature, n_sweeps)
+    S = _f64(S_lambda)
+    n, nlam = S.shape
+    pops = np.asarray(populations)
+    gamma = _f64(case.gamma(pops))
+    strength = _f64(case.strength_const * (pops[0] * case.Bij - pops[1] * case.Bji))
+    lam, vel, dop, ac = _f64(case.lam), _f64(case.velocity), _f64(case.doppler), _f64(case.alpha_cont)
+    n1 = int(sites.layers_up[1] - 1)
+    I0 = _f64(np.asarray(case.B0)[sites.perm_up[:n1] - 1])
+    J = np.zeros((n, nlam))
+    check(_lib.load().vrt_plan_execute_line(plan._h, nlam, nlam, _d(lam), float(case.lambda0), float(case.c0), _d(vel),
+                                            _d(dop), _d(gamma), _d(strength), _d(ac), _d(S), _d(I0), None, _d(_f64(w)),
+                                            _d(J)))
+    return J
+
+
+def Lambda_voronoi_host(eps_conv: float, maxiter: int, sites: VoronoiSites, case: LineCase, quadrature: str,
+                        n_sweeps: int = 3):
+    """Λ_voronoi (src/lambda_iteration.jl:205-300) for a host WITHOUT device arrays: the library owns the device
+    state (`vrt_lambda_create` / `_iterate` / `_get`), one call per iteration, only the criterion's scalar
+    comes back inside the loop.  Returns (J, S_new, populations (3, n), history)."""
+    L = _lib.load()
+    plan, w = _quadrature_plan(sites, quadrature, n_sweeps)
+    lc, keep = case.c_struct()
+    h = ctypes.c_void_p()
+    check(L.vrt_lambda_create(plan._h, ctypes.byref(lc), _d(_f64(w)), ctypes.byref(h)))
+    n, nlam = sites.n, int(keep["lam"].size)
+    history, diff, i = [], 1.0, 0                              # criterion(S_new = B, S_old = 0) = 1
+    try:
+        while diff > eps_conv and i < maxiter:
+            d = ctypes.c_double()
+            check(L.vrt_lambda_iterate(h, ctypes.byref(d)))
+            diff = d.value
+            history.append(diff)
+            i += 1
+            if diff != diff:
+                import warnings
+                warnings.warn(f"Lambda_voronoi_host: NaN DIFF! at iteration {i} -- stopping, results are not converged")
+        J, S, pops = np.zeros((n, nlam)), np.zeros((n, nlam)), np.zeros((3, n))
+        check(L.vrt_lambda_get(h, _d(J), _d(S), _d(pops), None, None))
+        if i == 0:
+            S[:] = keep["B0"]
+            pops[:] = keep["lte"]
+        return J, S, pops, history
+    finally:
+        L.vrt_lambda_destroy(h)
 
 
 def Lambda_voronoi(eps_conv: float, maxiter: int, sites: VoronoiSites, case: LineCase, quadrature: str,
                    n_sweeps: int = 3):
     """Λ_voronoi (src/lambda_iteration.jl:205-300) with everything between two convergence checks on
-    the device: per iteration `vrt_line_opacity_dev` (α_tot of every angle from the current
-    populations, :72-96), `vrt_plan_execute_dev` (J_λ, :84-111), `vrt_lambda_update_dev` (S_new and
-    the criterion's scalar, :261-263, :325-349) and `vrt_rates_populations_dev` (:269, :274); only that
-    scalar crosses PCIe inside the loop.  Starts in LTE with S = B_0 like the reference.
+    the device, over the device-pointer entry points: per iteration `vrt_line_terms_dev` (γ and the line
+    strength of the current populations, :72-75), `vrt_line_opacity_dev` (α_tot of every angle, :72-96),
+    `vrt_plan_execute_dev` (J_λ, :84-111), `vrt_lambda_update_dev` (S_new and the criterion's scalar, :261-263,
+    :325-349) and `vrt_rates_populations_dev` (:269, :274); only that scalar crosses PCIe inside the loop.
+    Starts in LTE with S = B_0 like the reference.
     Returns (J, S_new, populations (3, n), history of the criterion's differences) as numpy arrays."""
     import torch
     w, th, ph, nq = read_quadrature(quadrature)
@@ -600,13 +705,15 @@ def Lambda_voronoi(eps_conv: float, maxiter: int, sites: VoronoiSites, case: Lin
     n, nlam = sites.n, int(np.asarray(case.lam).size)
     plan = FormalPlan(sites, quadrature_directions(th, ph), n_sweeps, dirs=[1 if t > 90 else (-1 if t < 90 else 0) for t in th])
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
-    d_vel, d_dop, d_gam, d_ac, d_eps, d_T = (t(getattr(case, k)) for k in
-                                             ("velocity", "doppler", "gamma", "alpha_cont", "eps", "temperature"))
+    d_vel, d_dop, d_gs, d_gu, d_ac, d_eps, d_T = (t(getattr(case, k)) for k in
+                                                  ("velocity", "doppler", "gamma_static", "gamma_unsold", "alpha_cont", "eps",
+                                                   "temperature"))
     d_B, d_lte, d_C, d_atom = t(case.B0), t(case.lte), t(case.C), t(case.atom_density)
     pops = d_lte.clone()                                       # populations = copy(LTE_pops)
     S_new, S_old, J = d_B.clone(), torch.zeros_like(d_B), torch.zeros_like(d_B)
     native = torch.empty(plan.native_alpha_count(nlam), dtype=torch.float64, device=dev)
     d_R = torch.empty((n, 3, 3), dtype=torch.float64, device=dev)
+    d_gam, strength = torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
     n1 = int(sites.layers_up[1] - 1)
     bottom = torch.as_tensor(sites.perm_up[:n1] - 1, device=dev)
     I0_up = d_B[bottom].contiguous()                           # B_λ(λ_l, T) of the bottom layer, :99-101
@@ -616,8 +723,9 @@ def Lambda_voronoi(eps_conv: float, maxiter: int, sites: VoronoiSites, case: Lin
     try:
         while diff > eps_conv and i < maxiter:                 # criterion, :325-349
             S_old.copy_(S_new)
-            # αline_λ's population factor (src/line.jl:219-225); the profile is the kernel's
-            strength = case.strength_const * (pops[0] * case.Bij - pops[1] * case.Bji)
+            # γ_constant of the current populations (:72-75) and αline_λ's population factor (src/line.jl:219-225)
+            line_terms_dev(sites, d_gs.data_ptr(), d_gu.data_ptr(), pops.data_ptr(), case.strength_const, case.Bij, case.Bji,
+                           d_gam.data_ptr(), strength.data_ptr(), stream=st)
             plan.line_opacity_dev(case.lam, case.lambda0, case.c0, d_vel.data_ptr(), d_dop.data_ptr(), d_gam.data_ptr(),
                                   strength.data_ptr(), d_ac.data_ptr(), native.data_ptr(), stream=st)
             plan.execute_dev(nlam, nlam, S_old.data_ptr(), native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE, w,

@@ -90,7 +90,7 @@ static void dev_free(T *&p)
     p = nullptr;
 }
 
-static int use_device(int device)
+int use_device(int device)
 {
     if (device < 0)
         return fail(VRT_ENODEVICE, "host-only grid handle (device < 0): no compute without a HIP device");
@@ -636,10 +636,9 @@ static int ensure(double *&buf, size_t &cap, size_t count)
     return VRT_OK;
 }
 
-static int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_,
-                              const void *dalpha_, int alpha_mode, const void *dI0_up_,
-                              const void *dI0_down_, const double *weights, void *dJ_,
-                              void *dI_out_, hipStream_t st, bool f32 = false)
+int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_, const void *dalpha_, int alpha_mode,
+                       const void *dI0_up_, const void *dI0_down_, const double *weights, void *dJ_, void *dI_out_,
+                       hipStream_t st, bool f32)
 {
     const void *dS = dS_, *dalpha = dalpha_;
     void *dJ = dJ_, *dI_out = dI_out_;

@@ -301,6 +301,8 @@ int launch_reduce_J(vrt_plan *p, const SweepArgs &sa, const double *weights_acti
                     int64_t ldJ, hipStream_t st);
 int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, void *dI_out, int64_t ldO, hipStream_t st);
 
+int launch_gather_rows(int64_t rows, int64_t nlam, int64_t ld, const int32_t *d_order, const double *d_src, double *d_dst,
+                       hipStream_t st);
 int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, const double *dB,
                          const double *deps, const double *dS_old, double *dS_new,
                          unsigned long long *d_result, hipStream_t st);
@@ -309,12 +311,20 @@ int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, 
 int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, double lambda0, double c0,
                         const double *d_velocity, const double *d_doppler, const double *d_gamma,
                         const double *d_strength, const double *d_alpha_cont, double *d_out, hipStream_t st);
+int launch_line_terms(int64_t n, const double *d_gamma_static, const double *d_gamma_unsold, const double *d_pops,
+                      double strength_const, double Bij, double Bji, double *d_gamma, double *d_strength, hipStream_t st);
 int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_t blocks[6],
                              const double *d_small, const double *dJ, double lambda0, double c0,
                              const double *d_doppler, const double *d_gamma, double sigma_bb_const,
                              const double *d_temperature, const double *d_lte, double hc_over_kB,
                              double pref_ij, double pref_ji, const double *d_C, const double *d_atom_density,
                              double *d_R, double *d_populations, hipStream_t st);
+
+// ---- entry-point internals shared with vrt_lambda.cpp (vrt_api.cpp) ---------------------------------
+int use_device(int device);
+int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, const void *dalpha, int alpha_mode,
+                       const void *dI0_up, const void *dI0_down, const double *weights, void *dJ, void *dI_out,
+                       hipStream_t st, bool f32 = false);
 
 // ---- layer-tile path (vrt_tiles.hip) ----------------------------------------------------------
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);

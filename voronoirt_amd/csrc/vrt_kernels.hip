@@ -480,6 +480,28 @@ k_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *__restrict__ 
     }
 }
 
+// dst[j][l] = src[order[j]][l]: rows of a caller-layout (nlam, n) array picked by a site list (the boundary
+// intensity B_λ(T) of the bottom layer in perm_up order, lambda_iteration.jl:99-101)
+__global__ void __launch_bounds__(256)
+k_gather_rows(int64_t rows, int64_t nlam, int64_t ld, const int32_t *__restrict__ order, const double *__restrict__ src,
+              double *__restrict__ dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * nlam) return;
+    const int64_t j = t / nlam, l = t % nlam;
+    dst[t] = src[(size_t)order[j] * (size_t)ld + (size_t)l];
+}
+
+int launch_gather_rows(int64_t rows, int64_t nlam, int64_t ld, const int32_t *d_order, const double *d_src, double *d_dst,
+                       hipStream_t st)
+{
+    if (rows * nlam <= 0) return VRT_OK;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((rows * nlam + 255) / 256)), dim3(256), 0, st, rows, nlam, ld, d_order,
+                       d_src, d_dst);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, const double *dB,
                          const double *deps, const double *dS_old, double *dS_new,
                          unsigned long long *d_result, hipStream_t st)

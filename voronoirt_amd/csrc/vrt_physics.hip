@@ -141,6 +141,35 @@ int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, doubl
     return VRT_OK;
 }
 
+// ---- population-dependent line terms -----------------------------------------------------------------
+// γ of the CURRENT populations and the λ-independent factor of αline_λ, per site:
+//   γ = γ_static + γ_unsold (n_1 + n_2)     γ_constant, src/broadening.jl:63-82, called with
+//                                            populations[:,1] .+ populations[:,2] each iteration (lambda_iteration.jl:72-75);
+//                                            γ_static = natural width + the two Stark terms (electron density and
+//                                            temperature only), γ_unsold = the van der Waals width per unit neutral density
+//   strength = strength_const (n_1 B_ij - n_2 B_ji)      αline_λ, src/line.jl:219-225
+// populations (n, 3) column-major as Julia's
+__global__ void __launch_bounds__(256)
+k_line_terms(int64_t n, const double *__restrict__ gamma_static, const double *__restrict__ gamma_unsold,
+             const double *__restrict__ pops, double strength_const, double Bij, double Bji,
+             double *__restrict__ gamma, double *__restrict__ strength)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double n1 = pops[i], n2 = pops[i + n];
+    if (gamma) gamma[i] = gamma_static[i] + gamma_unsold[i] * (n1 + n2);
+    if (strength) strength[i] = strength_const * (n1 * Bij - n2 * Bji);
+}
+
+int launch_line_terms(int64_t n, const double *d_gamma_static, const double *d_gamma_unsold, const double *d_pops,
+                      double strength_const, double Bij, double Bji, double *d_gamma, double *d_strength, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_line_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, d_gamma_static,
+                       d_gamma_unsold, d_pops, strength_const, Bij, Bji, d_gamma, d_strength);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 // ---- rates + populations epilogue ------------------------------------------------------------------
 struct RatesArgs {
     int64_t n, nlam, ld;
