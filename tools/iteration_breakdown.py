@@ -128,4 +128,43 @@ for name, fn, nbytes in steps:
 print(f"{'one iteration':28s} {total:8.3f} ms   (path {plan.last_path})")
 assert torch.isfinite(Jline).all() and torch.isfinite(d_pop).all()
 plan.close()
+
+# ---- the same from HOST arrays (what the Julia shim calls): PCIe-inclusive wall times ------------------
+import time  # noqa: E402
+case = vrt.LineCase(lam=lam, blocks=blocks, lambda0=lambda0, c0=C0, velocity=velocity, doppler=doppler,
+                    gamma_static=gamma, gamma_unsold=1e-9 * np.ones(n), alpha_cont=alpha_cont,
+                    eps=10 ** rng.uniform(-2.5, -0.5, n), temperature=T, atom_density=atom,
+                    B0=(1.0 + (z - bounds[0]) / (bounds[1] - bounds[0]))[:, None] * np.ones((1, nlam_all)), lte=lte, C=Cmat,
+                    planck2=planck2, sigma_bf1=sig1, sigma_bf2=sig2,
+                    strength_const=float(np.median(strength / lte[0])), Bij=1.0, Bji=0.25,
+                    sigma_bb_const=H_PLANCK * C0 / (4 * np.pi * lambda0) * 4.5e20, hc_over_kB=H_PLANCK * C0 / K_B,
+                    pref_ij=2 * np.pi / (H_PLANCK * C0) / 1000.0, pref_ji=2 * np.pi / (H_PLANCK * C0))
+S_h = np.ascontiguousarray(case.B0[:, :nbb])
+line_only = vrt.LineCase(**{**{k: getattr(case, k) for k in vrt.LineCase.FIELDS}, "lam": lam[:nbb], "B0": S_h})
+vrt.J_lambda_voronoi_line(S_h, lte, sites, line_only, "ul7n12.dat")            # warm-up: plan, staging buffers
+t0 = time.perf_counter()
+for _ in range(3):
+    Jh = vrt.J_lambda_voronoi_line(S_h, lte, sites, line_only, "ul7n12.dat")
+dt = (time.perf_counter() - t0) / 3
+up = 8.0 * (n * nbb + 7 * n) / 1e9
+print(f"vrt_plan_execute_line, host arrays in -> J out ({nbb} wavelengths): {dt * 1e3:.1f} ms per J "
+      f"(uploads {up:.2f} GB + downloads {8.0 * n * nbb / 1e9:.2f} GB; alpha_tot (nlam, n, n_angles) would be {8.0 * n * nbb * A / 1e9:.1f} GB)")
+assert np.isfinite(Jh).all()
+t0 = time.perf_counter()
+Jl, Sl, pl, hist = vrt.Lambda_voronoi_host(0.0, 4, sites, case, "ul7n12.dat")
+dt = time.perf_counter() - t0
+print(f"vrt_lambda_create + 4 x vrt_lambda_iterate + vrt_lambda_get ({nlam_all} wavelengths): {dt * 1e3:.0f} ms in all; history {hist}")
+L = _lib.load()
+import ctypes  # noqa: E402
+plan_h, wq = api._quadrature_plan(sites, "ul7n12.dat", 3)
+lc, keep = case.c_struct()
+h = ctypes.c_void_p()
+api.check(L.vrt_lambda_create(plan_h._h, ctypes.byref(lc), api._d(api._f64(wq)), ctypes.byref(h)))
+d = ctypes.c_double()
+api.check(L.vrt_lambda_iterate(h, ctypes.byref(d)))
+t0 = time.perf_counter()
+for _ in range(3):
+    api.check(L.vrt_lambda_iterate(h, ctypes.byref(d)))
+print(f"vrt_lambda_iterate: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per Λ-iteration at {nlam_all} wavelengths (only the criterion's scalar crosses PCIe)")
+L.vrt_lambda_destroy(h)
 sites.close()
