@@ -14,14 +14,15 @@ depend on the grid and the quadrature only; their one-time cost is reported sepa
 N > 1: one rank per GPU over RCCL.  Launched by `python -m torch.distributed.run ...` (RANK /
 WORLD_SIZE in the environment) the script joins that job; launched bare (`python bench.py --gpus 8`)
 it starts its own N ranks through torch.distributed.run BEFORE anything touches a GPU and relays
-rank 0's JSON line.  Sharding:
-  lambda         weak scaling, the default: every rank owns a block of `nlam` wavelengths of a global
-                 N x nlam problem and all angles for it, i.e. whole rows of J: no data-path collective
+rank 0's JSON line.  Sharding; the default for N > 1 is the FIXED workload
+(`auto`: lambda-strong when the workload has at least N wavelengths, angle otherwise):
   lambda-strong  the FIXED problem of the workload: its nlam wavelengths are split into contiguous
                  blocks (51 over 8 ranks -> 7,7,7,6,6,6,6,6), every rank solves all angles for its
-                 block, J is all-gathered over RCCL each step
+                 block, J is all-gathered over RCCL inside every timed step
   angle          strong scaling over the angles (needed when nlam < N): partial J's summed with one
                  RCCL all-reduce per step -- the scheme BASELINE.json's north star names
+  lambda         weak scaling, opt-in: every rank owns a block of `nlam` wavelengths of a global
+                 N x nlam problem and all angles for it, i.e. whole rows of J: no data-path collective
 
 Prints ONE JSON line on rank 0.
 """
@@ -61,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--nlam", type=int, default=0, help="override the workload's wavelength count")
-    ap.add_argument("--shard", default="lambda", choices=["lambda", "lambda-strong", "angle"])
+    ap.add_argument("--shard", default="auto", choices=["auto", "lambda", "lambda-strong", "angle"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary C2 measurement")
     ap.add_argument("--no-critical-path", action="store_true",
@@ -137,6 +138,8 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     if args.nlam > 0 and workload == args.workload:
         nlam_total = args.nlam
     shard = args.shard if world > 1 else "lambda"
+    if shard == "auto":                     # N > 1: the fixed workload, RCCL on J inside the timed step
+        shard = "lambda-strong" if nlam_total >= world else "angle"
     weights, theta, phi, n_angles = vrt.read_quadrature(quad)
 
     # wavelengths this rank solves: its own block of `nlam_total` (weak), or its part of the fixed set
@@ -229,6 +232,19 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
             groups.append((gp, ga, w_mine[ch], torch.zeros_like(J)))
 
     gathered = {}     # lambda-strong: the gathered (n, nlam_total) J of the last step
+    coll = {"op": None, "bytes_per_step": 0, "ms": 0.0, "calls": 0}
+    coll_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def timed_collective(fn, op, nbytes):
+        """the data-path collective of a step, between two events on the launch stream"""
+        coll_ev[0].record()
+        out_ = fn()
+        coll_ev[1].record()
+        coll_ev[1].synchronize()
+        coll["op"], coll["bytes_per_step"] = op, int(nbytes)
+        coll["ms"] += coll_ev[0].elapsed_time(coll_ev[1])
+        coll["calls"] += 1
+        return out_
 
     def step():
         if groups is not None:
@@ -243,14 +259,18 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
             plan.execute_dev(nlam, nlam, S.data_ptr(), alpha.data_ptr(), alpha_mode, w_mine,
                              dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
         if world > 1 and shard == "angle":
-            if rehearse:       # gloo reduces host tensors
-                Jh = J.cpu()
-                distributed.allreduce_J(Jh)
-                J.copy_(Jh)
-            else:
-                distributed.allreduce_J(J)
+            def reduce_():
+                if rehearse:       # gloo reduces host tensors
+                    Jh = J.cpu()
+                    distributed.allreduce_J(Jh)
+                    J.copy_(Jh)
+                else:
+                    distributed.allreduce_J(J)
+            timed_collective(reduce_, "all_reduce(sum) of J (n, nlam) over the angle shards", J.numel() * J.element_size())
         elif world > 1 and shard == "lambda-strong":
-            gathered["J"] = distributed.allgather_J_lambda(J.cpu() if rehearse else J, nlam_total)
+            gathered["buf"], gathered["sizes"] = timed_collective(
+                lambda: distributed.allgather_J_blocks(J.cpu() if rehearse else J, nlam_total, out=gathered.get("buf")),
+                "all_gather of the wavelength blocks of J (n, nlam_total)", n * nlam_total * J.element_size())
 
     def barrier():
         if world > 1:
@@ -260,6 +280,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         step()
     torch.cuda.synchronize()
     barrier()
+    coll["ms"], coll["calls"] = 0.0, 0
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()              # on the stream the library launches on (its internal streams fork from and
@@ -304,6 +325,12 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         },
         "setup_s": {"grid_generate": t_gen, "grid_create": t_grid, "plan_create": t_plan},
     }
+    if world > 1:
+        out["collective"] = {"op": coll["op"] or "none (every rank owns whole rows of J)",
+                             "bytes_per_step": coll["bytes_per_step"],
+                             "ms": coll["ms"] / max(coll["calls"], 1),
+                             "backend": "gloo (rehearsal on one GPU)" if rehearse else "nccl (RCCL)",
+                             "note": "rank 0's time of the collective inside every timed step (HIP events on the launch stream)"}
     # secondary bound: the dependency critical path of the sweep -- the same plan with
     # ONE wavelength pair, where bandwidth plays no role and only the per-layer launch + Gauss-Seidel
     # level chain of the most inclined angle is left
@@ -413,7 +440,8 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         }
         out["parity_vs_oracle_max_rel_err"] = parity
     if args.dump_J and rank == 0:
-        np.save(args.dump_J, (gathered["J"] if "J" in gathered else J).cpu().numpy())
+        Jout = distributed.assemble_J_blocks(gathered["buf"], gathered["sizes"]) if "buf" in gathered else J
+        np.save(args.dump_J, Jout.cpu().numpy())
     return out
 
 

@@ -312,6 +312,27 @@ int vrt_lambda_iterate(vrt_lambda *s, double *max_rel_change);
 int vrt_lambda_get(vrt_lambda *s, double *J, double *S, double *populations, double *R, double *gamma);
 void vrt_lambda_destroy(vrt_lambda *s);
 
+/* ---- several GPUs of a node from ONE host process -------------------------------------
+ * The object owns a grid + plan per device and -- when the devices are distinct -- an in-process RCCL
+ * communicator (ncclCommInitAll; librccl is dlopen'ed on first use).  vrt_multi_execute is vrt_plan_execute for
+ * the node: the angle x wavelength loop of J_λ_voronoi (src/lambda_iteration.jl:84-111) sharded
+ *   by wavelength blocks when nlam >= devices (51 over 8 -> 7,7,7,6,6,6,6,6; every device owns whole rows of J,
+ *   which go home by strided copies: no exchange), or
+ *   by angles otherwise (ups and downs dealt separately), the partial J's summed by ONE RCCL all-reduce.
+ * Arguments as vrt_grid_create + vrt_plan_create_ex / vrt_plan_execute (host pointers; alpha_mode 0..2).
+ * The same device listed twice is a rehearsal on a one-GPU box: no RCCL, the partial sums are added by a
+ * kernel.  vrt_multi_set_shard: "auto" | "lambda" | "angle"; vrt_multi_last_shard: 1 lambda, 2 angle. */
+typedef struct vrt_multi vrt_multi;
+int vrt_multi_create(int n_devices, const int *devices, int64_t n, const double *pos_zxy, const int64_t *nbr, int64_t D1,
+                     const double bounds[6], int64_t n_angles, const double *k, const int *dirs, int n_sweeps,
+                     vrt_multi **out);
+int vrt_multi_execute(vrt_multi *m, int64_t nlam, int64_t ld, const double *S, const double *alpha, int alpha_mode,
+                      const double *I0_up, const double *I0_down, const double *weights, double *J);
+int vrt_multi_set_shard(vrt_multi *m, const char *mode);
+int vrt_multi_last_shard(const vrt_multi *m);
+int vrt_multi_uses_rccl(const vrt_multi *m);
+void vrt_multi_destroy(vrt_multi *m);
+
 /* ---- rates + populations of the Λ-iteration epilogue on the device --------
  * calculate_R (src/rates.jl:154-201: Rij / Rji λ-trapezoids :226-364, σij with the site's static
  * Voigt profile :374-416, Gij :459-476) and get_revised_populations (src/populations.jl:191-221,

@@ -369,6 +369,8 @@ def test_bench_two_ranks_reproduce_the_one_rank_J(tmp_path, shard):
     (j1, J1), (j2, J2) = outs[1], outs[2]
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
     assert j2["config"]["shard"] == shard and J1.shape == J2.shape
+    c = j2["collective"]                                      # the collective is inside the timed step, and visible
+    assert c["bytes_per_step"] == J1.size * 8 and c["ms"] > 0 and ("all_gather" if shard == "lambda-strong" else "all_reduce") in c["op"]
     # same cell-update count for the fixed job at either rank count
     assert abs(j2["value"] * j2["ms_per_step"] - j1["value"] * j1["ms_per_step"]) < 1e-6 * j1["value"] * j1["ms_per_step"]
     if shard == "lambda-strong":
@@ -378,10 +380,11 @@ def test_bench_two_ranks_reproduce_the_one_rank_J(tmp_path, shard):
 
 
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])
-def test_bench_two_ranks_weak_default(launcher):
-    """The driver's scaling run: `bench.py --gpus 2` with the default (weak, wavelength-block) sharding,
-    started by bench.py itself or — as the driver does — under `python -m torch.distributed.run`.
-    One JSON line from rank 0, n_gpus 2, scaling "weak", twice the one-rank cell-update count per step."""
+def test_bench_two_ranks_default_is_the_fixed_workload(launcher):
+    """The driver's scaling run: `bench.py --gpus 2` with the DEFAULT sharding -- the fixed workload split by
+    wavelength blocks, J all-gathered inside the timed step (north star: RCCL on J each step) -- started by
+    bench.py itself or, as the driver does, under `python -m torch.distributed.run`.  One JSON line from rank 0,
+    n_gpus 2, scaling "strong", the one-rank cell-update count per step; `--shard lambda` is the opt-in weak mode."""
     import json
     import os
     import subprocess
@@ -411,6 +414,14 @@ def test_bench_two_ranks_weak_default(launcher):
     assert len(lines) == 1                                    # rank 0 only
     j1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
     j2 = json.loads(lines[0])
-    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["steps"] == 2 and j2["warmup"] == 1
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["steps"] == 2 and j2["warmup"] == 1
+    assert j2["config"]["shard"] == "lambda-strong" and "all_gather" in j2["collective"]["op"]
     u1, u2 = j1["value"] * j1["ms_per_step"], j2["value"] * j2["ms_per_step"]
-    assert abs(u2 - 2 * u1) < 1e-6 * u2                       # whole-job aggregate: both ranks' updates
+    assert abs(u2 - u1) < 1e-6 * u2                           # the same fixed job at either rank count
+    if launcher == "self":
+        r3 = subprocess.run([sys.executable, bench, "--gpus", "2", "--shard", "lambda"] + args, env=env, capture_output=True,
+                            text=True, timeout=600)
+        assert r3.returncode == 0, r3.stderr[-2000:]
+        j3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.startswith("{")][-1])
+        assert j3["scaling"] == "weak" and "none" in j3["collective"]["op"]
+        assert abs(j3["value"] * j3["ms_per_step"] - 2 * u1) < 1e-6 * u2      # weak: both ranks' updates

@@ -721,6 +721,48 @@ def test_plain_c_caller_plays_Lambda_voronoi(tmp_path):
     assert np.abs(P / pops_ref - 1).max() < 1e-9
 
 
+@pytest.mark.parametrize("devices", [(0,), (0, 0), (0, 0, 0)])
+def test_multi_device_object_of_the_c_abi(voro_small, devices):
+    """vrt_multi_*: one process, several device handles.  On a one-GPU box the same device is
+    listed two or three times: the wavelength-block sharding must reproduce the one-handle J bit for bit (every
+    wavelength is solved by exactly one handle), the angle sharding to summation order (its all-reduce is
+    replaced by kernel adds here; with distinct devices it is ONE RCCL all-reduce)."""
+    pos, nbr, bounds = voro_small
+    so = orc.make_sites(pos, nbr, bounds)
+    n = so.n
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    dirs = [1 if t > 90 else -1 for t in th]
+    mp = vrt.MultiDevicePlan(pos, nbr, bounds, vrt.quadrature_directions(th, ph), dirs=dirs, devices=devices)
+    assert not mp.uses_rccl or len(set(devices)) == len(devices) > 1
+    rng = np.random.default_rng(len(devices))
+    for nlam, per_angle in ((5, False), (7, True), (1, False)):
+        S = 1 + rng.random((n, nlam))
+        al = 5 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+        if per_angle:
+            al = np.stack([al * (1 + 0.1 * rng.random((n, nlam))) for _ in range(nq)])
+        I0u, I0d = rng.random((so.layers_up[1] - 1, nlam)), rng.random((so.layers_down[1] - 1, nlam))
+        ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0u, I0_down=I0d, nthreads=4)
+        mp.set_shard("auto")
+        J = mp.execute(S, al, w, I0_up=I0u, I0_down=I0d)
+        assert mp.last_shard == ("lambda" if nlam >= len(devices) else "angle")
+        assert _rel(J, ref) < RTOL
+        mp.set_shard("lambda")
+        Jl = mp.execute(S, al, w, I0_up=I0u, I0_down=I0d)
+        mp.set_shard("angle")
+        Ja = mp.execute(S, al, w, I0_up=I0u, I0_down=I0d)
+        assert mp.last_shard == "angle" and _rel(Ja, ref) < RTOL and _rel(Ja, Jl) < 1e-13
+        if len(devices) == 1:
+            hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+            plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=dirs)
+            J1, _ = plan.execute(S, al, weights=w, I0_up=I0u, I0_down=I0d)
+            assert np.array_equal(J1, Jl)
+            plan.close()
+            hs.close()
+    mp.close()
+    with pytest.raises(vrt.VrtError):
+        vrt.MultiDevicePlan(pos, nbr, bounds, vrt.quadrature_directions(th, ph), dirs=dirs, devices=(0, 97))
+
+
 def test_degenerate_grids_and_plans(path):
     """Edge cases on every device path: a single-layer grid (every cell touches the wall: no sweep
     at all, I = I_0 except the never-visited last site), a two-layer grid, one angle / one

@@ -524,6 +524,11 @@ a, b = distributed.partition(nlam, world, rank)
 Jb = torch.from_numpy(J_full[:, a:b].copy())
 Jg = distributed.allgather_J_lambda(Jb, nlam)
 assert np.array_equal(Jg.numpy(), J_full)
+# the same as ONE collective into a preallocated (world, n, width) buffer (what bench.py times)
+buf, sizes = distributed.allgather_J_blocks(Jb, nlam)
+assert np.array_equal(distributed.assemble_J_blocks(buf, sizes).numpy(), J_full)
+buf2, _ = distributed.allgather_J_blocks(Jb, nlam, out=buf)
+assert buf2 is buf
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

@@ -77,6 +77,13 @@ PROTOTYPES = {
     "vrt_lambda_iterate": (ctypes.c_int, [vp, p_dbl]),
     "vrt_lambda_get": (ctypes.c_int, [vp, p_dbl, p_dbl, p_dbl, p_dbl, p_dbl]),
     "vrt_lambda_destroy": (None, [vp]),
+    "vrt_multi_create": (ctypes.c_int, [ctypes.c_int, p_int, c_i64, p_dbl, p_i64, c_i64, p_dbl, c_i64, p_dbl, p_int,
+                                        ctypes.c_int, ctypes.POINTER(vp)]),
+    "vrt_multi_execute": (ctypes.c_int, [vp, c_i64, c_i64, p_dbl, p_dbl, ctypes.c_int, p_dbl, p_dbl, p_dbl, p_dbl]),
+    "vrt_multi_set_shard": (ctypes.c_int, [vp, ctypes.c_char_p]),
+    "vrt_multi_last_shard": (ctypes.c_int, [vp]),
+    "vrt_multi_uses_rccl": (ctypes.c_int, [vp]),
+    "vrt_multi_destroy": (None, [vp]),
     "vrt_rates_populations_dev": (ctypes.c_int, [vp, c_i64, c_i64, p_dbl, p_i64, vp, p_dbl, c_dbl, c_dbl, vp, vp,
                                                  c_dbl, p_dbl, p_dbl, vp, vp, c_dbl, c_dbl, c_dbl, vp, vp, vp,
                                                  vp, vp]),

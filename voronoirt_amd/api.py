@@ -336,6 +336,68 @@ class FormalPlan:
             pass
 
 
+class MultiDevicePlan:
+    """Several GPUs of a node from ONE process (`vrt_multi_*`): a grid + plan per device and an in-process RCCL
+    communicator; `execute` is `FormalPlan.execute` for the node (host arrays in, J out), sharded by
+    wavelength blocks when nλ >= devices, by angles (one RCCL all-reduce of J) otherwise.  Listing a device
+    twice rehearses the sharding on a one-GPU box (no RCCL, partial sums added by a kernel)."""
+
+    def __init__(self, positions, neighbours, bounds, k, dirs=None, n_sweeps: int = 3, devices=(0,)):
+        L = _lib.load()
+        pos = _f64(positions)
+        nbr = np.ascontiguousarray(neighbours, dtype=np.int64)
+        b = np.array([float(v) for v in bounds], dtype=np.float64)
+        self.k = _f64(np.atleast_2d(k))
+        self.n, self.n_angles = pos.shape[0], self.k.shape[0]
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        d = np.ascontiguousarray(dirs, dtype=np.int32) if dirs is not None else None
+        h = ctypes.c_void_p()
+        check(L.vrt_multi_create(dev.size, dev.ctypes.data_as(_lib.p_int), self.n, _d(pos), _i(nbr), nbr.shape[0], _d(b),
+                                 self.n_angles, _d(self.k), d.ctypes.data_as(_lib.p_int) if d is not None else None,
+                                 int(n_sweeps), ctypes.byref(h)))
+        self._h = h
+
+    def set_shard(self, mode: str) -> None:
+        check(_lib.load().vrt_multi_set_shard(self._h, mode.encode()))
+
+    @property
+    def last_shard(self) -> str:
+        return {0: "", 1: "lambda", 2: "angle"}[int(_lib.load().vrt_multi_last_shard(self._h))]
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(_lib.load().vrt_multi_uses_rccl(self._h))
+
+    def execute(self, S, alpha, weights, I0_up=None, I0_down=None, alpha_mode=None) -> np.ndarray:
+        S = _f64(S)
+        if S.ndim == 1:
+            S = S.reshape(-1, 1)
+        n, nlam = S.shape
+        alpha = _f64(alpha)
+        if alpha_mode is None:
+            alpha_mode = {1: _lib.ALPHA_SITE, 2: _lib.ALPHA_SITE_LAM, 3: _lib.ALPHA_ANGLE_SITE_LAM}[alpha.ndim]
+        if I0_up is not None:
+            I0_up = _f64(I0_up).reshape(-1, nlam)
+        if I0_down is not None:
+            I0_down = _f64(I0_down).reshape(-1, nlam)
+        w = _f64(weights)
+        J = np.zeros((n, nlam))
+        check(_lib.load().vrt_multi_execute(self._h, nlam, nlam, _d(S), _d(alpha), alpha_mode, _d(I0_up), _d(I0_down),
+                                            _d(w), _d(J)))
+        return J
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.load().vrt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _single(fn_name, k, S, I_0, alpha, sites: VoronoiSites, n_sweeps: int):
     L = _lib.load()
     k = _f64(k)

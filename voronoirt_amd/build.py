@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvrt_hip.so")
-SOURCES = ["vrt_api.cpp", "vrt_grid.cpp", "vrt_schedule.cpp", "vrt_patch.cpp", "vrt_lambda.cpp", "vrt_tessellate.cpp", "vrt_kernels.hip", "vrt_tiles.hip", "vrt_patch.hip", "vrt_regular.hip", "vrt_physics.hip"]
+SOURCES = ["vrt_api.cpp", "vrt_grid.cpp", "vrt_schedule.cpp", "vrt_patch.cpp", "vrt_lambda.cpp", "vrt_multi.cpp", "vrt_tessellate.cpp", "vrt_kernels.hip", "vrt_tiles.hip", "vrt_patch.hip", "vrt_regular.hip", "vrt_physics.hip"]
 HEADERS = [os.path.join(CSRC, "vrt_internal.h"), os.path.join(CSRC, "vrt_device.h"), os.path.join(ROOT, "include", "voronoirt.h")]
 
 
@@ -55,7 +55,7 @@ def _build(out: str, extra, verbose: bool) -> str:
         "-Wall", "-Wno-unused-result",
         "-I", os.path.join(ROOT, "include"), "-I", CSRC,
         "-o", out,
-    ] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
+    ] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

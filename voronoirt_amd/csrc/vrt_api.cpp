@@ -100,6 +100,9 @@ int use_device(int device)
         return fail(VRT_ENODEVICE, "no HIP device available (libvrt_hip has no CPU fallback)");
     if (device < 0 || device >= cnt) return fail(VRT_EINVAL, "device ordinal out of range");
     VRT_HIP_TRY(hipSetDevice(device));
+    // an error some EARLIER call of this thread left behind (the host application's, or a refused argument of
+    // ours) must not be reported by the hipGetLastError() checks behind this entry point's own launches
+    (void)hipGetLastError();
     return VRT_OK;
 }
 

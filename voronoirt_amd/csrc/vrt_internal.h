@@ -301,6 +301,7 @@ int launch_reduce_J(vrt_plan *p, const SweepArgs &sa, const double *weights_acti
                     int64_t ldJ, hipStream_t st);
 int launch_copy_I_out(vrt_plan *p, const SweepArgs &sa, void *dI_out, int64_t ldO, hipStream_t st);
 
+int launch_axpy(size_t count, const double *d_src, double *d_dst, hipStream_t st);
 int launch_gather_rows(int64_t rows, int64_t nlam, int64_t ld, const int32_t *d_order, const double *d_src, double *d_dst,
                        hipStream_t st);
 int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, const double *dB,

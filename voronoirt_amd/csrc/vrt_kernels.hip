@@ -480,6 +480,22 @@ k_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *__restrict__ 
     }
 }
 
+// dst += src (partial J's of two handles on one device: vrt_multi's same-device rehearsal)
+__global__ void __launch_bounds__(256)
+k_axpy(size_t count, const double *__restrict__ src, double *__restrict__ dst)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) dst[t] += src[t];
+}
+
+int launch_axpy(size_t count, const double *d_src, double *d_dst, hipStream_t st)
+{
+    if (!count) return VRT_OK;
+    hipLaunchKernelGGL(k_axpy, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, count, d_src, d_dst);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 // dst[j][l] = src[order[j]][l]: rows of a caller-layout (nlam, n) array picked by a site list (the boundary
 // intensity B_λ(T) of the bottom layer in perm_up order, lambda_iteration.jl:99-101)
 __global__ void __launch_bounds__(256)

@@ -97,3 +97,34 @@ def allgather_J_lambda(J_block, nlam_total: int):
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded.contiguous())
     return torch.cat([parts[r][:, : sizes[r][1] - sizes[r][0]] for r in range(world)], dim=1)
+
+
+def allgather_J_blocks(J_block, nlam_total: int, out=None):
+    """The J all-gather of the "lambda-strong" mode as ONE collective into a preallocated
+    (world, n, width) buffer (width = the largest wavelength block; narrower blocks are padded): no list of
+    tensors, no concatenation inside the step.  Returns (buffer, [(start, stop)] per rank);
+    `assemble_J_blocks` builds the (n, nlam_total) array when a caller wants it."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    n = J_block.shape[0]
+    sizes = [partition(nlam_total, world, r) for r in range(world)]
+    width = max(b - a for a, b in sizes)
+    if out is None or tuple(out.shape) != (world, n, width) or out.dtype != J_block.dtype or out.device != J_block.device:
+        out = torch.zeros((world, n, width), dtype=J_block.dtype, device=J_block.device)
+    if world == 1:
+        out[0, :, : J_block.shape[1]] = J_block
+        return out, sizes
+    if J_block.shape[1] == width and J_block.is_contiguous():
+        mine = J_block
+    else:
+        mine = torch.zeros((n, width), dtype=J_block.dtype, device=J_block.device)
+        mine[:, : J_block.shape[1]] = J_block
+    dist.all_gather_into_tensor(out.view(world * n, width), mine)     # concatenation along dim 0 = the (world, n, width) buffer
+    return out, sizes
+
+
+def assemble_J_blocks(buf, sizes):
+    import torch
+    return torch.cat([buf[r][:, : b - a] for r, (a, b) in enumerate(sizes)], dim=1)
