@@ -185,4 +185,17 @@ __device__ __forceinline__ void upwind_term(double r, double w, double a_c, doub
     g = inl ? ce * w : 0.0;
 }
 
+// J reduction riding along the fused patch launches (vrt_patch.hip), lagged by one layer
+struct PatchReduce {
+    int nred = 0;                    // blocks in the reduction role (a multiple of 8: the XCD dealing of the rest stays aligned)
+    int nblk[2] = {0, 0};            // of which for range 0 / 1
+    int lo[2] = {0, 0}, hi[2] = {0, 0};   // storage position ranges
+    int count[2] = {0, 0};           // angles of the range's direction
+    int ppb = 4;                     // wavelength pairs per block
+    void *Jd[2] = {nullptr, nullptr};     // J_dir planes [npair][n] (pairs of T)
+    double w[kMaxAngles];            // quadrature weight per ACTIVE angle
+    int32_t angles[2][kMaxAngles];   // active angles of the range's direction, in the reference's order
+};
+
+
 }  // namespace vrt

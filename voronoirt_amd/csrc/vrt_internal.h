@@ -339,10 +339,11 @@ int64_t steps_max_layer(bool f32);   // largest layer the layer-step level kerne
 
 // ---- fused patch path (vrt_patch.hip) ----------------------------------------------------------------
 struct TileArgs;
+struct PatchReduce;
 bool patch_shape_exists(int K, int Q, int NT);
 int launch_patch_entries(vrt_plan *p, int a, int64_t first, int64_t count);
 int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angles, const std::vector<int> &group_off);
 int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, int group, int Q, hipStream_t st,
-                       bool f32);
+                       bool f32, const PatchReduce *reduce);
 
 }  // namespace vrt

@@ -34,6 +34,10 @@ struct PatchArgs {
     int cap;                  // entries per patch at most (K * NT): length of the LDS table arrays
     int dbg;                  // timing diagnostics (-DVRT_DIAG build only, WRONG results): 1 no levels, 2 gathers ->
                               //   coalesced centre reads, 4 no weights arithmetic, 8 no stores
+    // J reduction riding along (lagged by one layer): the first nred blocks of the launch do not solve a patch
+    // but form J_dir = Σ_a w_a I_a (reference's angle order inside the direction) over storage positions
+    // [red_lo, red_hi) of up to two directions -- layers the stream's previous launch has made final
+    PatchReduce red;
     const int32_t *work;      // this launch's work list: patch index per (slot, XCD), -1 = padding
     const int4 *rec;          // per patch: first entry, entries, first owned storage position, owned sites
     const int2 *rec2;         // per patch: in-layer levels, active angle
@@ -193,7 +197,32 @@ k_patch_solve(PatchArgs pa)
     // block -> (work item, pair group): blocks b, b + 8, ... share an XCD (MI355X_MICROARCH.md, speed
     // only); the pair groups of an item follow each other on ONE XCD and read its entry tables
     // through that L2, and consecutive items of an XCD are neighbouring patches / angles of a patch
-    const int x = blockIdx.x & 7, rr = blockIdx.x >> 3;
+    if ((int)blockIdx.x < pa.red.nred) {
+        // ---- reduction role: J_dir of a finished layer (512 positions x ppb pairs per block) -----------------
+        int b = blockIdx.x, r = 0;
+        if (b >= pa.red.nblk[0]) { b -= pa.red.nblk[0]; r = 1; }
+        if (b >= pa.red.nblk[r]) return;                         // padding to a multiple of 8
+        const int chunks = (pa.red.hi[r] - pa.red.lo[r] + NT - 1) / NT;
+        const int pos = pa.red.lo[r] + (b % chunks) * NT + tid;
+        const int q0r = (b / chunks) * pa.red.ppb, q1r = min(pa.npair, q0r + pa.red.ppb);
+        if (pos >= pa.red.hi[r]) return;
+        const int64_t nn = ta.n;
+        T2 *Jd = reinterpret_cast<T2 *>(pa.red.Jd[r]);
+        for (int q = q0r; q < q1r; q++) {
+            double ax = 0.0, ay = 0.0;
+            for (int j = 0; j < pa.red.count[r]; j++) {          // the reference's angle order (lambda_iteration.jl:84,102,107)
+                const int a = pa.red.angles[r][j];
+                const double2 v = ldpair(reinterpret_cast<const T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)nn, pos);
+                ax += pa.red.w[a] * v.x;
+                ay += pa.red.w[a] * v.y;
+            }
+            const unsigned off = (unsigned)pos * (unsigned)sizeof(T2);
+            *reinterpret_cast<T2 *>(reinterpret_cast<char *>(Jd + (size_t)q * (size_t)nn) + off) = from_d2<T>(make_double2(ax, ay));
+        }
+        return;
+    }
+    const int bid = (int)blockIdx.x - pa.red.nred;
+    const int x = bid & 7, rr = bid >> 3;
     const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
     const int item = pa.work[sj * 8 + x];
     if (item < 0) return;
@@ -408,20 +437,38 @@ int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angl
 }
 
 // one layer of one stream group
+// fills the block counts of a reduction request for NT-thread blocks
+static void size_reduce(PatchReduce &red, int npair, int NT)
+{
+    red.nred = 0;
+    for (int r = 0; r < 2; r++) {
+        const int len = red.hi[r] - red.lo[r];
+        red.nblk[r] = (len > 0 && red.count[r] > 0 && red.Jd[r]) ? (len + NT - 1) / NT * ((npair + red.ppb - 1) / red.ppb) : 0;
+        red.nred += red.nblk[r];
+    }
+    red.nred = (red.nred + 7) / 8 * 8;
+}
+
 int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, int group, int Q, hipStream_t st,
-                       bool f32)
+                       bool f32, const PatchReduce *reduce)
 {
     // workgroups per launch: enough to fill the chip a few times over with both direction streams running
     const int target_wgs = std::max(1, p->tune.patch_target);
     const int maxL = p->tile_max_layers;
     const size_t wo = (size_t)group * (size_t)(maxL + 2) + (size_t)layer;
-    const int64_t w0 = p->patch_work_off[wo], w1 = p->patch_work_off[wo + 1];
-    if (w1 <= w0) return VRT_OK;
+    const int64_t w0 = (layer >= 2 && layer <= maxL) ? p->patch_work_off[wo] : 0, w1 = (layer >= 2 && layer <= maxL) ? p->patch_work_off[wo + 1] : 0;
     PatchArgs pa;
+    if (reduce) {
+        pa.red = *reduce;
+        size_reduce(pa.red, npair, p->patch_NT);
+    }
+    if (w1 <= w0 && pa.red.nred == 0) return VRT_OK;
     pa.ta = ta;
     pa.npair = npair;
     pa.layer = layer;
-    {
+    pa.ppw = Q;
+    pa.ngrp = 1;
+    if (w1 > w0) {
         const int64_t items = w1 - w0;                         // work-list slots (a few of them padding)
         const int steps_all = (npair + Q - 1) / Q;             // Q pairs at a time
         const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(steps_all, (target_wgs + items - 1) / items));
@@ -437,7 +484,7 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     pa.e_pos = p->e_pos; pa.e_u1 = p->e_u1; pa.e_u2 = p->e_u2;
     pa.e_vis = p->e_vis; pa.e_loc = p->e_loc;
     pa.e_w1 = p->e_w1; pa.e_w2 = p->e_w2; pa.e_r1 = p->e_r1; pa.e_r2 = p->e_r2;
-    const dim3 grid((unsigned)((w1 - w0) * pa.ngrp));
+    const dim3 grid((unsigned)(pa.red.nred + (w1 - w0) * pa.ngrp));
     const size_t lds = (size_t)Q * (size_t)pa.stride * sizeof(double2) + (size_t)pa.cap * (4 * sizeof(double) + 5 * sizeof(int32_t));
     const int rc = f32 ? launch_mode<float>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa)
                        : launch_mode<double>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa);

@@ -1349,6 +1349,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     VRT_HIP_TRY(hipGetLastError());
 
     const bool debug = kDiag && p->tune.tile_debug;
+    bool fused_dir[2] = {false, false};     // J_dir of the direction was reduced inside the sweep (patch path)
     long long *d_dbg = nullptr;
     int64_t launches = 1;
     if (steps && A > 0) {
@@ -1401,6 +1402,49 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         const bool use_map = !patches && p->tune.step_level_map != 0;
         if (use_map && (rc = build_level_map(p, G, single ? (int)nlam : npair))) return rc;
         if (patches && (rc = ensure_patch_work(p, G, p->h_step_angles, p->step_group_off))) return rc;
+        // J reduction riding along the patch launches: a stream that holds ALL angles of a direction forms
+        // J_dir of layer l - 1 in its launch of layer l (the layer is final, its lines still cache-resident)
+        PatchReduce red_tmpl;
+        int owner_of_dir[2] = {-1, -1};
+        int64_t reduced_upto[2] = {0, 0};
+        if (patches && dJ) {
+            for (int a = 0; a < A; a++) red_tmpl.w[a] = weights_user[p->user_of_active[(size_t)a]];
+            for (int d = 0; d < 2; d++) {
+                if (!use_dir[d]) continue;
+                if ((rc = ensure_dev(p->ws_J[d], p->ws_J_cap[d], dcount(plane)))) return rc;
+                for (int gi = 0; gi < G; gi++) {
+                    int have = 0;
+                    for (int j = p->step_group_off[(size_t)gi]; j < p->step_group_off[(size_t)gi + 1]; j++)
+                        have += (p->dir_of_active[(size_t)p->h_step_angles[(size_t)j]] > 0) == (d == 0);
+                    if (have == (d == 0 ? p->n_up : p->n_down)) owner_of_dir[d] = gi;
+                }
+            }
+        }
+        fused_dir[0] = owner_of_dir[0] >= 0;
+        fused_dir[1] = owner_of_dir[1] >= 0;
+        auto make_reduce = [&](int gi, int layer_done, bool final, PatchReduce &red) -> bool {
+            // ranges of the directions this group owns that became final with layer `layer_done`
+            red = red_tmpl;
+            int r = 0;
+            for (int d = 0; d < 2; d++) {
+                if (owner_of_dir[d] != gi) continue;
+                const Direction &dir = d == 0 ? g->up : g->down;
+                const int Ld = (int)dir.reduced.size() - 1;
+                int64_t upto = reduced_upto[d];
+                if (final) upto = n;
+                else if (layer_done >= 1 && layer_done <= Ld) upto = dir.reduced[(size_t)layer_done] - 1;
+                if (upto <= reduced_upto[d]) continue;
+                red.lo[r] = (int)reduced_upto[d];
+                red.hi[r] = (int)upto;
+                red.Jd[r] = p->ws_J[d];
+                red.count[r] = 0;
+                for (int a = 0; a < A; a++)
+                    if ((p->dir_of_active[(size_t)a] > 0) == (d == 0)) red.angles[r][red.count[r]++] = a;
+                reduced_upto[d] = upto;
+                r++;
+            }
+            return r > 0;
+        };
         sa.level_map = nullptr;
         VRT_HIP_TRY(hipEventRecord(p->ev0, st));
         VRT_HIP_TRY(hipEventRecord(p->step_fork, st));
@@ -1435,7 +1479,9 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                     // pairs per workgroup: the plan's Q, or 1 when that would leave half of every group empty
                     int Q = p->tune.patch_Q;
                     if (!patch_shape_exists(p->patch_K, Q, p->patch_NT) || (npair % Q != 0 && npair < 2 * Q)) Q = 1;
-                    if ((rc = launch_patch_layer(p, sa.ta, npair, layer, gi, Q, sg, kF32))) return rc;
+                    PatchReduce red;
+                    const bool have_red = make_reduce(gi, layer - 1, false, red);
+                    if ((rc = launch_patch_layer(p, sa.ta, npair, layer, gi, Q, sg, kF32, have_red ? &red : nullptr))) return rc;
                     launches += 1;
                     continue;
                 }
@@ -1478,6 +1524,14 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                 launches += 2;
             }
         }
+        if (patches)       // the last layers (and the never-visited site n - 1, whose intensity is 0)
+            for (int gi = 0; gi < G; gi++) {
+                PatchReduce red;
+                if (!make_reduce(gi, 0, true, red)) continue;
+                if ((rc = launch_patch_layer(p, sa.ta, npair, p->tile_max_layers + 1, gi, 1, G == 1 ? st : p->step_stream[gi], kF32, &red)))
+                    return rc;
+                launches += 1;
+            }
         if (G > 1)
             for (int gi = 0; gi < G; gi++) {
                 VRT_HIP_TRY(hipEventRecord(p->step_join[gi], p->step_stream[gi]));
@@ -1557,6 +1611,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                     dw.count++;
                 }
             Jd[d] = reinterpret_cast<T *>(p->ws_J[d]);
+            if (fused_dir[d]) continue;                  // formed layer by layer inside the sweep's launches
             hipLaunchKernelGGL(k_reduce_dir<T>, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st,
                                (int64_t)plane, (int64_t)plane, dw, wI, Jd[d]);
         }
