@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E vendor peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r2"
+PROFILE_ROUND = "r3"
 
 WORKLOADS = {
     # name: (a, c, quadrature, nlam, alpha per angle, seed)   -- SURVEY.md 8d, BASELINE.md sec. 3
@@ -95,7 +95,8 @@ def source_digest() -> str:
     return h.hexdigest()[:16]
 
 
-ONE_TIME_KERNELS = ("k_upwind_table", "k_permute_table", "k_delaunay_lines", "k_sorted_tables", "k_gpos")
+ONE_TIME_KERNELS = ("k_upwind_table", "k_permute_table", "k_delaunay_lines", "k_sorted_tables", "k_sorted_loc", "k_sorted_code",
+                    "k_gpos", "k_patch_entries")
 
 
 def pmc_traffic_per_step(workload, path, nlam, world, alpha_layout):
@@ -373,7 +374,10 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
                                         "native" if alpha_native is not None else "caller"),
         "kernel": {"levels": "k_sweep_level (one launch per dependency level)",
                    "steps": "k_step_coeffs + k_step_levels (two launches per BFS layer)",
-                   "tiles": "k_sweep_tiles (one persistent launch)"}.get(plan.last_path, plan.last_path),
+                   "tiles": "k_sweep_tiles (one persistent launch)",
+                   "patches": "k_patch_solve (one fused launch per BFS layer and direction: coefficients + "
+                              "Gauss-Seidel levels of every patch, J reduction of the previous layer riding along)"
+                   }.get(plan.last_path, plan.last_path),
         "path": plan.last_path, "launches_per_step": launches,
         "step_event_ms": step_event_ms,
         "algorithmic_bytes_per_step": alg_bytes,

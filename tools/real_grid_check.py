@@ -47,7 +47,7 @@ n1 = int(hs.layers_up[1] - 1)
 I0 = torch.rand((n1, nlam), generator=g, device=dev, dtype=torch.float64)
 J = torch.zeros((n, nlam), device=dev, dtype=torch.float64)
 stream = torch.cuda.current_stream().cuda_stream
-for path in (None, "levels", "steps", "tiles", "patches"):
+for path in ((None,) if os.environ.get("REAL_GRID_DEFAULT_ONLY") else (None, "levels", "steps", "tiles", "patches")):
     plan.set_option("VRT_PATH", path or "auto")
     if (path == "tiles" and max(lu.max(), ld_.max()) > 8192) or (path == "steps" and max(lu.max(), ld_.max()) > 12288):
         continue

@@ -25,7 +25,7 @@ go, out = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles", rnd)
 os.makedirs(out, exist_ok=True)
 
 stats_csv = glob.glob(os.path.join(go, f"prof_{tag}_default", "**", "*kernel_stats.csv"), recursive=True)[0]
-shutil.copy(stats_csv, os.path.join(out, "c4_steps_default_kernel_stats.csv"))
+shutil.copy(stats_csv, os.path.join(out, "c4_default_kernel_stats.csv"))
 steps_total = 4    # tools/prof_kernels.sh: 1 warm-up + 3 timed steps under the profiler
 ks = {}
 for r in csv.DictReader(open(stats_csv)):
@@ -35,7 +35,7 @@ for r in csv.DictReader(open(stats_csv)):
         ks[name] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                     "ms_per_step": float(r["TotalDurationNs"]) / 1e6 / (1 if once else steps_total)}
 pmc = collections.defaultdict(lambda: collections.defaultdict(float))
-for ctr in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
+for ctr in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_EA0_RDREQ_DRAM_sum"):
     for f in glob.glob(os.path.join(go, f"pmc_{tag}_default_{ctr}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Kernel_Name"].startswith(("vrt::", "void vrt::")):
@@ -82,5 +82,13 @@ for src, dst in ((f"{tag}_bench_default.json", "bench_default.json"), (f"{tag}_b
         lines = [ln for ln in open(path).read().splitlines() if ln.startswith("{")]
         if lines:
             open(os.path.join(out, dst), "w").write(lines[-1] + "\n")
+for src, dst in ((f"prof_{tag}_real1m", "real_grid_1m_kernel_stats.csv"), (f"prof_{tag}_C3", "c3_default_kernel_stats.csv"),
+                 (f"prof_{tag}_C5", "c5_f32_kernel_stats.csv")):
+    found = glob.glob(os.path.join(go, src, "**", "*kernel_stats.csv"), recursive=True)
+    if found:
+        shutil.copy(found[0], os.path.join(out, dst))
+for src, dst in ((f"{tag}_real_grid_1m.txt", "real_grid_1m.txt"), (f"{tag}_pmc.txt", "c4_pmc_table.txt")):
+    if os.path.exists(os.path.join(go, src)):
+        shutil.copy(os.path.join(go, src), os.path.join(out, dst))
 print(json.dumps(ks, indent=1)[:1500])
 print("traffic per step %.1f GB, algorithmic %.1f GB" % (total / 1e9, b["roofline"]["algorithmic_bytes_per_step"] / 1e9))
