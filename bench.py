@@ -502,10 +502,8 @@ def main():
     args = parse_args()
     # the host driver supports dmabuf IPC only: RCCL and cross-process tensor sharing need this
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # the sweep runs on two internal streams beside the caller's and the grid's own: with the default of
-    # four hardware queues any further stream of the process (RCCL's, torch side streams) is multiplexed
-    # onto one of theirs and can stall a sweep chain; eight leave room
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # (the sweep advances on the caller's stream and ONE internal stream: the default of four hardware queues
+    # per process leaves room for RCCL's -- no GPU_MAX_HW_QUEUES override is needed any more)
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_own_ranks(args))
 

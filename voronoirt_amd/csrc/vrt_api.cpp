@@ -362,6 +362,18 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
     p->n_sweeps = n_sweeps;
     p->n_angles_user = n_angles;
     tuning_from_env(p->tune);             // the ONLY place the library reads its tuning environment variables
+    {
+        // The layer paths advance the two sweep directions on two streams: the caller's and ONE of the library's.
+        // A process gets four hardware queues by default (GPU_MAX_HW_QUEUES); streams beyond them share queues
+        // and serialise.  The library cannot see the host's other streams, but it can see a lowered limit.
+        static bool warned = false;
+        const char *q = std::getenv("GPU_MAX_HW_QUEUES");
+        if (!warned && q && *q && std::atoi(q) < 2) {
+            warned = true;
+            std::fprintf(stderr, "[libvrt_hip] GPU_MAX_HW_QUEUES=%s: the sweep's two direction streams will share one "
+                                 "hardware queue and run one after the other (set it to 2 or more)\n", q);
+        }
+    }
     if (options)
         for (const auto &o : *options) (void)tuning_set(p->tune, o.first.c_str(), o.second.c_str(), /*created=*/false);
     for (int64_t a = 0; a < n_angles; a++) {

@@ -1162,7 +1162,7 @@ static int ensure_step_streams(vrt_plan *p, int G)
     if (p->d_patch_work) { (void)hipFree(p->d_patch_work); p->d_patch_work = nullptr; }   // work lists follow the groups
     if (!p->step_fork) VRT_HIP_TRY(hipEventCreateWithFlags(&p->step_fork, hipEventDisableTiming));
     for (int gi = 0; gi < 4; gi++) {
-        if (gi < G && !p->step_stream[gi]) {
+        if (gi >= 1 && gi < G && !p->step_stream[gi]) {      // group 0 advances on the caller's stream
             VRT_HIP_TRY(hipStreamCreateWithFlags(&p->step_stream[gi], hipStreamNonBlocking));
             VRT_HIP_TRY(hipEventCreateWithFlags(&p->step_join[gi], hipEventDisableTiming));
         }
@@ -1454,7 +1454,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         // another stream's would start a millisecond late and finish alone.
         const int ngrp = (npair + sa.pairs_per_thread - 1) / sa.pairs_per_thread;
         if (G > 1)
-            for (int gi = 0; gi < G; gi++) VRT_HIP_TRY(hipStreamWaitEvent(p->step_stream[gi], p->step_fork, 0));
+            for (int gi = 1; gi < G; gi++) VRT_HIP_TRY(hipStreamWaitEvent(p->step_stream[gi], p->step_fork, 0));
         for (int layer = 2; layer <= Lmax; layer++) {
             sa.layer = layer;
             // launch geometry from THIS layer's size (the larger of the two directions'): layers
@@ -1472,7 +1472,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             const int need_K = (int)((cnt_l + 1023) / 1024);
             const int step_K = std::max(1, std::min(8, std::max(force_K, need_K)));
             for (int gi = 0; gi < G; gi++) {
-                hipStream_t sg = G == 1 ? st : p->step_stream[gi];
+                hipStream_t sg = gi == 0 ? st : p->step_stream[gi];     // group 0 on the caller's stream: one hardware queue less
                 const int n_list = p->step_group_off[gi + 1] - p->step_group_off[gi];
                 if (n_list == 0) continue;
                 if (patches) {               // ONE fused launch per layer and stream
@@ -1528,12 +1528,12 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             for (int gi = 0; gi < G; gi++) {
                 PatchReduce red;
                 if (!make_reduce(gi, 0, true, red)) continue;
-                if ((rc = launch_patch_layer(p, sa.ta, npair, p->tile_max_layers + 1, gi, 1, G == 1 ? st : p->step_stream[gi], kF32, &red)))
+                if ((rc = launch_patch_layer(p, sa.ta, npair, p->tile_max_layers + 1, gi, 1, gi == 0 ? st : p->step_stream[gi], kF32, &red)))
                     return rc;
                 launches += 1;
             }
         if (G > 1)
-            for (int gi = 0; gi < G; gi++) {
+            for (int gi = 1; gi < G; gi++) {
                 VRT_HIP_TRY(hipEventRecord(p->step_join[gi], p->step_stream[gi]));
                 VRT_HIP_TRY(hipStreamWaitEvent(st, p->step_join[gi], 0));
             }
