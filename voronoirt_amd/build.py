@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvrt_hip.so")
-SOURCES = ["vrt_api.cpp", "vrt_grid.cpp", "vrt_schedule.cpp", "vrt_patch.cpp", "vrt_lambda.cpp", "vrt_multi.cpp", "vrt_tessellate.cpp", "vrt_kernels.hip", "vrt_tiles.hip", "vrt_patch.hip", "vrt_regular.hip", "vrt_physics.hip"]
-HEADERS = [os.path.join(CSRC, "vrt_internal.h"), os.path.join(CSRC, "vrt_device.h"), os.path.join(ROOT, "include", "voronoirt.h")]
+SOURCES = ["vrt_api.cpp", "vrt_grid.cpp", "vrt_schedule.cpp", "vrt_patch.cpp", "vrt_lambda.cpp", "vrt_multi.cpp", "vrt_tessellate.cpp", "vrt_kernels.hip", "vrt_tables.hip", "vrt_layers.hip", "vrt_patch.hip", "vrt_regular.hip", "vrt_physics.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("vrt_internal.h", "vrt_device.h", "vrt_layout_kernels.h", "vrt_tile_kernels.h", "vrt_step_kernels.h")] + [os.path.join(ROOT, "include", "voronoirt.h")]
 
 
 def _hipcc() -> str:

@@ -509,7 +509,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         if (p->n_down > 0) max_layer = std::max(max_layer, g->down.n1);
         if (n >= ((int64_t)1 << 28)) ok = false;  // the layer kernels index 16-byte pair planes with 32-bit byte offsets
         // the layer-step level kernels hold a whole layer per workgroup: 8192 sites as fp64 wavelength
-        // pairs, 12 288 as fp64 single wavelengths, 18 432 as fp32 ones (vrt_tiles.hip); the fused
+        // pairs, 12 288 as fp64 single wavelengths, 18 432 as fp32 ones (vrt_step_kernels.h); the fused
         // patch kernel (vrt_patch.hip) has no such limit
         const bool tile_ok = ok && max_layer <= steps_max_layer(/*f32=*/true);
         bool patch_ok = ok;

@@ -1,5 +1,5 @@
 // Device helpers and kernel-argument records shared by the HIP translation units of the layer
-// solvers (vrt_tiles.hip: persistent tile + layer-step kernels, vrt_patch.hip: fused patch kernel).
+// solvers (vrt_layers.hip with vrt_tile_kernels.h / vrt_step_kernels.h / vrt_layout_kernels.h, vrt_patch.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>

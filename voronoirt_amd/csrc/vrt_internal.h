@@ -162,7 +162,7 @@ struct vrt_plan {
     int64_t I_ld = 0;
     double *d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // S, alpha, I0up, I0down, J, I_out
     size_t stage_cap[6] = {0, 0, 0, 0, 0, 0};
-    // layer-tile path (vrt_tiles.hip): tables in sweep order, per-layer level counts
+    // layer paths (vrt_layers.hip, vrt_tables.hip): tables in storage order, per-layer level counts
     bool tile_ok = false;
     int tile_K = 8;                      // sites per thread of the 1024-thread workgroup
     int tile_max_layers = 0;
@@ -327,7 +327,7 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, co
                        const void *dI0_up, const void *dI0_down, const double *weights, void *dJ, void *dI_out,
                        hipStream_t st, bool f32 = false);
 
-// ---- layer-tile path (vrt_tiles.hip) ----------------------------------------------------------
+// ---- layer paths (vrt_tables.hip, vrt_layers.hip) ----------------------------------------------------------
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
 int launch_sorted_tables(vrt_plan *p, int a);
 int launch_gpos(vrt_plan *p, int a);

@@ -1,0 +1,164 @@
+// Layout changes between the caller's (nλ, n) site-major arrays and the storage order of the layer paths
+// (LDS-tiled transposes), the boundary intensities, and the J reduction / combination.  Kernel templates,
+// included by the translation unit that launches them (vrt_layers.hip).
+#pragma once
+
+#include "vrt_device.h"
+
+namespace vrt {
+
+// out[l][p] = in[order[p]][l]   (caller's (nλ, n) site-major rows -> wavelength-major sweep order)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_to_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__restrict__ order,
+                 const T *__restrict__ in, T *__restrict__ out)
+{
+    __shared__ T tile[64][65];
+    __shared__ int32_t rows[64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int l0 = blockIdx.y * 64;
+    if (threadIdx.x < 64) rows[threadIdx.x] = p0 + threadIdx.x < n ? order[p0 + threadIdx.x] : -1;
+    __syncthreads();
+    T v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {          // 16 independent row reads in flight per thread
+        const int32_t site = rows[ty + 4 * j];
+        v[j] = (site >= 0 && l0 + tx < nlam) ? in[(size_t)site * ld + l0 + tx] : (T)0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) tile[ty + 4 * j][tx] = v[j];
+    __syncthreads();
+    if (lb == 1) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int l = l0 + ty + 4 * j;
+            if (l < nlam && p0 + tx < n) out[(size_t)l * n + p0 + tx] = tile[tx][ty + 4 * j];
+        }
+    } else {                                   // one 16-byte store per (site, wavelength pair)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = 2 * (ty + 4 * j), l = l0 + c;
+            if (l < nlam && p0 + tx < n) {
+                typename Pair<T>::type v2;
+                v2.x = tile[tx][c];
+                v2.y = l + 1 < nlam ? tile[tx][c + 1] : (T)0;
+                reinterpret_cast<typename Pair<T>::type *>(out)[(size_t)(l >> 1) * (size_t)n + (size_t)(p0 + tx)] = v2;
+            }
+        }
+    }
+}
+
+// out[p] = in[order[p]]   (per-site vector, e.g. wavelength-independent α)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_gather_vec(int64_t n, const int32_t *__restrict__ order, const T *__restrict__ in,
+             T *__restrict__ out)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) out[p] = in[order[p]];
+}
+
+// I[a][l][p] = I0[p][l] for p < n1 (boundary layer, already in sweep order), blockIdx.z = angle slot
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_boundary_sweep_order(int64_t n, int nlam, int lb, int64_t n1, const int32_t *__restrict__ angles,
+                       const int32_t *__restrict__ order, const int32_t *__restrict__ srank,
+                       const T *__restrict__ I0, T *__restrict__ I)
+{
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int l0 = blockIdx.y * 64;
+    const int a = angles[blockIdx.z];
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t p = p0 + r;
+        if (p < n1 && l0 + tx < nlam) tile[r][tx] = I0 ? I0[(size_t)p * nlam + l0 + tx] : (T)0;
+    }
+    __syncthreads();
+    const int nl_pad = (nlam + lb - 1) / lb * lb;
+    T *Ia = I + (size_t)a * (size_t)nl_pad * (size_t)n;
+    for (int c = ty; c < 64; c += 4) {
+        const int l = l0 + c;
+        // I_0 is ordered like perm[1:n1] (irregular_ray_tracing.jl:33); storage is Morton order
+        if (l < nlam && p0 + tx < n1) {
+            const int32_t pos = srank[order[p0 + tx]];
+            Ia[sw_index(l, pos, n, lb)] = tile[tx][c];
+            if (l == nlam - 1 && nl_pad > nlam) Ia[sw_index(nlam, pos, n, lb)] = (T)0;   // padding wavelength
+        }
+        // the never-visited site perm[n] (storage position n-1) keeps I = 0 (voronoi_utils.jl:266)
+        // -- also on a single-layer grid, where no layer kernel ever runs
+        if (blockIdx.x == 0 && tx == 0 && l < nl_pad) Ia[sw_index(l, n - 1, n, lb)] = (T)0;
+    }
+}
+
+
+// J_d[l][p] = Σ_{angles of direction d} w_a I_a[l][p], reference's angle order within the direction
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_reduce_dir(int64_t total, int64_t stride_angle, DirWeights dw, const T *__restrict__ I,
+             T *__restrict__ Jd)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    double acc = 0.0;
+    for (int j = 0; j < dw.count; j++) acc += dw.w[j] * (double)I[(size_t)dw.idx[j] * stride_angle + t];
+    Jd[t] = (T)acc;
+}
+
+// J[site][l] = J_up[l][rank_up[site]] + J_down[l][rank_down[site]], walking sites in up order so
+// the J_up reads are coalesced and the J_down reads are piecewise contiguous on stratified grids.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_combine_J(int64_t n, int nlam, int64_t ldJ, int lb, const int32_t *__restrict__ order_up,
+            const int32_t *__restrict__ rank_down, const T *__restrict__ Ju,
+            const T *__restrict__ Jdn, T *__restrict__ J)
+{
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int l0 = blockIdx.y * 64;
+    const int64_t p = p0 + tx;
+    int32_t site = 0, pd = 0;
+    if (p < n) {
+        site = order_up[p];
+        pd = rank_down[site];
+    }
+    for (int c = ty; c < 64; c += 4) {
+        const int l = l0 + c;
+        if (l < nlam && p < n) {
+            double v = 0.0;
+            if (Ju) v = (double)Ju[sw_index(l, p, n, lb)];
+            if (Jdn) v = v + (double)Jdn[sw_index(l, pd, n, lb)];
+            tile[tx][c] = (T)v;
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t q = p0 + r;
+        if (q < n && l0 + tx < nlam) J[(size_t)order_up[q] * ldJ + l0 + tx] = tile[r][tx];
+    }
+}
+
+// out[order[p]][l] = in[l][p]  (sweep order, wavelength-major -> caller's site-major rows)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_from_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__restrict__ order,
+                   const T *__restrict__ in, T *__restrict__ out)
+{
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int l0 = blockIdx.y * 64;
+    for (int c = ty; c < 64; c += 4) {
+        const int l = l0 + c;
+        if (l < nlam && p0 + tx < n) tile[tx][c] = in ? in[sw_index(l, p0 + tx, n, lb)] : (T)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t q = p0 + r;
+        if (q < n && l0 + tx < nlam) out[(size_t)order[q] * ld + l0 + tx] = tile[r][tx];
+    }
+}
+
+}  // namespace vrt
