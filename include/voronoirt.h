@@ -145,6 +145,10 @@ int64_t vrt_plan_native_alpha_count(const vrt_plan *p, int64_t nlam);
  * Λ-iteration when alpha changes, so that every execute of that iteration reads it in place */
 int vrt_plan_alpha_to_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha,
                                  double *dalpha_native, void *stream);
+/* the same for the fp32 VALUE path: float in, vrt_plan_native_alpha_count(p, nlam) FLOATS out, for
+ * vrt_plan_execute_dev_f32 with VRT_ALPHA_ANGLE_NATIVE */
+int vrt_plan_alpha_to_native_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dalpha,
+                                     float *dalpha_native, void *stream);
 
 /* fp32 VALUE path (BASELINE config C5): S, alpha, I_0, J and the per-angle intensities are stored
  * as float, halving the bytes of this bandwidth-bound path; the geometry tables and all
@@ -250,6 +254,12 @@ int vrt_line_opacity_dev(vrt_plan *p, int64_t nlam, const double *lambda, double
                          const double *d_velocity, const double *d_doppler_width, const double *d_gamma,
                          const double *d_line_strength, const double *d_alpha_cont, double *d_alpha_native,
                          void *stream);
+/* the same with the result STORED as float (fp32 value path; per-site inputs and arithmetic stay fp64):
+ * vrt_plan_native_alpha_count(p, nlam) floats for vrt_plan_execute_dev_f32 with VRT_ALPHA_ANGLE_NATIVE */
+int vrt_line_opacity_dev_f32(vrt_plan *p, int64_t nlam, const double *lambda, double lambda0, double c0,
+                             const double *d_velocity, const double *d_doppler_width, const double *d_gamma,
+                             const double *d_line_strength, const double *d_alpha_cont, float *d_alpha_native,
+                             void *stream);
 
 /* ---- the same from HOST arrays: the whole body of J_λ_voronoi, line case, in one call --------------------
  * src/lambda_iteration.jl:72-111 for a host without device arrays of its own (the reference's Julia driver):

@@ -548,6 +548,34 @@ def test_layers_of_20000_and_30000_sites_run_on_the_patch_kernel(monkeypatch, a,
     hs.close()
 
 
+def test_wall_layer_larger_than_every_other_layer(monkeypatch):
+    """A stratified grid whose boundary layer is its LARGEST layer (1 047 sites against 1 044): the persistent
+    tile kernel keeps that layer in LDS as the first "previous" layer, so its tile stride must count layer 1
+    too.  Up-only single-angle plans on every path against the oracle."""
+    pos, nbr, bounds = synth.voronoi_grid(3000, seed=5, bounds=(0.0, 0.5, 0.0, 1.0, 0.0, 1.0), scale_height=0.06)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    sizes = np.diff(so.layers_up)
+    assert sizes[0] == sizes.max() and sizes[0] > sizes[1:].max()
+    rng = np.random.default_rng(2)
+    n = so.n
+    S = 1 + rng.random(n)
+    alpha = 10 ** rng.uniform(-2, 2, n)
+    I0 = rng.random(so.layers_up[1] - 1)
+    for t, p in ((109.7, 193.6), (152.7, 315.5)):
+        k = vrt.direction(t, p)
+        ref = orc.Delaunay_upII(k, S, I0, alpha, so, 3)
+        for path_ in ("tiles", "patches", "steps", "levels"):
+            hs.set_option("VRT_PATH", path_)
+            plan = vrt.FormalPlan(hs, [k], 3, dirs=[1])
+            for pre in (1, 0):
+                plan.set_option("VRT_TILE_PRE", pre)
+                J, _ = plan.execute(S, alpha, weights=[1.0], I0_up=I0)
+                assert plan.last_path == path_ and _rel(J[:, 0], ref) < RTOL, (path_, pre)
+            plan.close()
+    hs.close()
+
+
 def test_default_path_choice(grids, monkeypatch):
     """The fused patch kernel is the default; a lone (angle, wavelength) problem on small layers takes the
     two launches of the persistent tile kernel.  Options: unknown names and creation-only ones are refused."""

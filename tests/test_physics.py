@@ -182,6 +182,103 @@ def test_gpu_line_opacity_native_layout_and_sweep(voro_small):
 
 
 @pytest.mark.gpu
+def test_gpu_f32_storage_accepts_native_per_angle_alpha(voro_small):
+    """fp32 VALUE path with per-angle α: `vrt_line_opacity_dev_f32` (fused prologue) and
+    `vrt_plan_alpha_to_native_dev_f32` (caller's (n_angles, n, ld) floats) fill the same native float buffer bit
+    for bit, and the sweep over it stays within the fp32 storage tolerance (5e-6) of the fp64 oracle."""
+    import torch
+    pos, nbr, bounds = voro_small
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    so = orc.make_sites(pos, nbr, bounds)
+    n = hs.n
+    c = _line_case(n, 3)
+    nlam = 51
+    lam = c["lam"][:nlam]
+    scale = 3e4 / c["strength"].max() * c["doppler"].mean()
+    strength, alpha_cont = c["strength"] * scale, c["alpha_cont"] * 1e5
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
+    dev = torch.device("cuda", 0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_vel, d_dop, d_gam, d_str, d_ac = t(c["velocity"]), t(c["doppler"]), t(c["gamma"]), t(strength), t(alpha_cont)
+    count = plan.native_alpha_count(nlam)
+    native = torch.full((count,), float("nan"), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.line_opacity_dev(lam, c["lambda0"], C0, d_vel.data_ptr(), d_dop.data_ptr(), d_gam.data_ptr(),
+                          d_str.data_ptr(), d_ac.data_ptr(), native.data_ptr(), stream=st, f32=True)
+    alpha_ref = np.stack([orc.line_opacity(orc.direction(th[a], ph[a]), lam, c["lambda0"], C0, c["velocity"],
+                                           c["doppler"], c["gamma"], strength, alpha_cont) for a in range(nq)])
+    ld = nlam + 2
+    a32 = np.zeros((nq, n, ld), dtype=np.float32)
+    a32[:, :, :nlam] = alpha_ref
+    native2 = torch.full((count,), float("nan"), dtype=torch.float32, device=dev)
+    a32d = t(a32)
+    plan.alpha_to_native_dev(nlam, ld, a32d.data_ptr(), native2.data_ptr(), stream=st, f32=True)
+    torch.cuda.synchronize()
+    nat, nat2 = native.cpu().numpy(), native2.cpu().numpy()
+    assert np.isfinite(nat).all()
+    npad = nlam + 1
+    live = np.ones(npad, dtype=bool)
+    live[nlam:] = False                                            # the pad wavelength of the last pair is unspecified
+    v1 = nat.reshape(nq, npad // 2, n, 2).transpose(0, 2, 1, 3).reshape(nq, n, npad)[:, :, live]
+    v2 = nat2.reshape(nq, npad // 2, n, 2).transpose(0, 2, 1, 3).reshape(nq, n, npad)[:, :, live]
+    assert np.abs(v1 / v2 - 1).max() < 2.5e-7                      # device fp64 -> float vs numpy fp64 -> float: ≤ 1 ulp
+    for a in range(nq):
+        order = hs.storage_order(1 if th[a] > 90 else -1) - 1
+        assert np.array_equal(v2[a], a32[a][order][:, :nlam]), a
+    rng = np.random.default_rng(4)
+    S = 1 + rng.random((n, nlam))
+    I0 = rng.random((so.layers_up[1] - 1, nlam))
+    Sd, I0d = t(S.astype(np.float32)), t(I0.astype(np.float32))
+    ref = orc.J_voronoi(w, th, ph, S, alpha_ref, so, I0_up=I0, nthreads=4)
+    for buf in (native, native2):
+        J = torch.full((n, nlam), float("nan"), dtype=torch.float32, device=dev)
+        plan.execute_dev(nlam, nlam, Sd.data_ptr(), buf.data_ptr(), _lib.ALPHA_ANGLE_NATIVE, w, dJ=J.data_ptr(),
+                         dI0_up=I0d.data_ptr(), stream=st, f32=True)
+        torch.cuda.synchronize()
+        assert plan.last_path == "patches"
+        assert np.abs(J.cpu().numpy() - ref).max() / np.abs(ref).max() < 5e-6
+    plan.close()
+    hs.close()
+
+
+@pytest.mark.gpu
+def test_gpu_physics_entries_with_growing_wavelength_arrays(voro_small):
+    """The wavelength-sized host arrays of the physics entry points go through a device scratch of the grid that
+    grows on demand (first capacity 256 doubles): calls with 10, then 400, then 10 wavelengths, on two streams --
+    the reallocation must not invalidate the event that orders the scratch's reuse."""
+    import torch
+    pos, nbr, bounds = voro_small
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    n = hs.n
+    c = _line_case(n, 9)
+    w, th, ph, nq = vrt.read_quadrature("ul2n3.dat")
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
+    dev = torch.device("cuda", 0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_vel, d_dop, d_gam, d_str, d_ac = t(c["velocity"]), t(c["doppler"]), t(c["gamma"]), t(c["strength"]), t(c["alpha_cont"])
+    side = torch.cuda.Stream()
+    for rep, nlam in enumerate((10, 400, 10, 700, 51)):
+        lam = c["lambda0"] * (1 + np.linspace(-3e-4, 3e-4, nlam))
+        native = torch.full((plan.native_alpha_count(nlam),), float("nan"), dtype=torch.float64, device=dev)
+        stream = side if rep % 2 else torch.cuda.current_stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        plan.line_opacity_dev(lam, c["lambda0"], C0, d_vel.data_ptr(), d_dop.data_ptr(), d_gam.data_ptr(),
+                              d_str.data_ptr(), d_ac.data_ptr(), native.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        npad = (nlam + 1) // 2 * 2
+        nat = native.cpu().numpy().reshape(nq, npad // 2, n, 2)
+        for a in (0, nq - 1):
+            ref = orc.line_opacity(orc.direction(th[a], ph[a]), lam[[0, nlam - 1]], c["lambda0"], C0, c["velocity"],
+                                   c["doppler"], c["gamma"], c["strength"], c["alpha_cont"])
+            order = hs.storage_order(1 if th[a] > 90 else -1) - 1
+            got = nat[a].transpose(1, 0, 2).reshape(n, npad)[:, [0, nlam - 1]]
+            assert np.abs(got / ref[order] - 1).max() < 1e-12, (nlam, a)
+    plan.close()
+    hs.close()
+
+
+@pytest.mark.gpu
 def test_gpu_rates_and_populations_against_oracle(bcc_small):
     import torch
     pos, nbr, bounds = bcc_small

@@ -70,6 +70,8 @@ PROTOTYPES = {
     "vrt_plan_native_alpha_count": (c_i64, [vp, c_i64]),
     "vrt_plan_alpha_to_native_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp]),
     "vrt_line_opacity_dev": (ctypes.c_int, [vp, c_i64, p_dbl, c_dbl, c_dbl, vp, vp, vp, vp, vp, vp, vp]),
+    "vrt_line_opacity_dev_f32": (ctypes.c_int, [vp, c_i64, p_dbl, c_dbl, c_dbl, vp, vp, vp, vp, vp, vp, vp]),
+    "vrt_plan_alpha_to_native_dev_f32": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp]),
     "vrt_plan_execute_line": (ctypes.c_int, [vp, c_i64, c_i64, p_dbl, c_dbl, c_dbl, p_dbl, p_dbl, p_dbl, p_dbl, p_dbl,
                                              p_dbl, p_dbl, p_dbl, p_dbl, p_dbl]),
     "vrt_line_terms_dev": (ctypes.c_int, [vp, vp, vp, vp, c_dbl, c_dbl, c_dbl, vp, vp, vp]),

@@ -293,19 +293,23 @@ class FormalPlan:
         """Number of float64 values of the native per-angle alpha buffer (ALPHA_ANGLE_NATIVE)."""
         return int(_lib.load().vrt_plan_native_alpha_count(self._h, nlam))
 
-    def alpha_to_native_dev(self, nlam: int, ld: int, dalpha: int, dalpha_native: int, stream: int = 0) -> None:
-        """Device (n_angles, n, ld) per-angle alpha -> the native layout, once per change of alpha."""
-        check(_lib.load().vrt_plan_alpha_to_native_dev(self._h, nlam, ld, dalpha, dalpha_native,
-                                                       stream or None))
+    def alpha_to_native_dev(self, nlam: int, ld: int, dalpha: int, dalpha_native: int, stream: int = 0,
+                            f32: bool = False) -> None:
+        """Device (n_angles, n, ld) per-angle alpha -> the native layout, once per change of alpha
+        (f32: float32 buffers, for execute_dev(..., f32=True))."""
+        fn = _lib.load().vrt_plan_alpha_to_native_dev_f32 if f32 else _lib.load().vrt_plan_alpha_to_native_dev
+        check(fn(self._h, nlam, ld, dalpha, dalpha_native, stream or None))
 
     def line_opacity_dev(self, lam, lambda0: float, c0: float, d_velocity: int, d_doppler: int, d_gamma: int,
-                         d_line_strength: int, d_alpha_cont: int, d_alpha_native: int, stream: int = 0) -> None:
-        """Fused opacity prologue (`vrt_line_opacity_dev`): α_tot of every angle of this plan from
-        per-site line parameters (device pointers), written in the native layout."""
+                         d_line_strength: int, d_alpha_cont: int, d_alpha_native: int, stream: int = 0,
+                         f32: bool = False) -> None:
+        """Fused opacity prologue (`vrt_line_opacity_dev[_f32]`): α_tot of every angle of this plan from
+        per-site line parameters (device pointers, float64), written in the native layout (f32: stored as
+        float32 for execute_dev(..., f32=True))."""
         lam = _f64(lam)
-        check(_lib.load().vrt_line_opacity_dev(self._h, lam.size, _d(lam), float(lambda0), float(c0), d_velocity,
-                                               d_doppler, d_gamma, d_line_strength, d_alpha_cont, d_alpha_native,
-                                               stream or None))
+        fn = _lib.load().vrt_line_opacity_dev_f32 if f32 else _lib.load().vrt_line_opacity_dev
+        check(fn(self._h, lam.size, _d(lam), float(lambda0), float(c0), d_velocity, d_doppler, d_gamma, d_line_strength,
+                 d_alpha_cont, d_alpha_native, stream or None))
 
     def set_option(self, name: str, value) -> None:
         """Tuning option of this plan (`vrt_plan_set_option`); results never depend on it."""

@@ -1191,7 +1191,25 @@ int vrt_plan_alpha_to_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const do
         std::lock_guard<std::mutex> lock(p->mu);
         int rc = use_device(p->g->device);
         if (rc) return rc;
-        return alpha_to_native(p, nlam, ld, dalpha, dalpha_native, (hipStream_t)stream);
+        return alpha_to_native(p, nlam, ld, dalpha, dalpha_native, (hipStream_t)stream, false);
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_plan_alpha_to_native_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dalpha, float *dalpha_native,
+                                     void *stream)
+{
+    DeviceScope scope;
+    if (!p || !dalpha || !dalpha_native) return fail(VRT_EINVAL, "NULL argument");
+    if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
+    if (p->A != (int)p->n_angles_user)
+        return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        int rc = use_device(p->g->device);
+        if (rc) return rc;
+        return alpha_to_native(p, nlam, ld, dalpha, dalpha_native, (hipStream_t)stream, true);
     } catch (...) {
         return fail(VRT_EINVAL, "unexpected exception");
     }
@@ -1394,10 +1412,10 @@ static int small_done(vrt_grid *g, hipStream_t st)
     return VRT_OK;
 }
 
-int vrt_line_opacity_dev(vrt_plan *p, int64_t nlam, const double *lambda, double lambda0, double c0,
-                         const double *d_velocity, const double *d_doppler_width, const double *d_gamma,
-                         const double *d_line_strength, const double *d_alpha_cont, double *d_alpha_native,
-                         void *stream)
+static int line_opacity_impl(vrt_plan *p, int64_t nlam, const double *lambda, double lambda0, double c0,
+                             const double *d_velocity, const double *d_doppler_width, const double *d_gamma,
+                             const double *d_line_strength, const double *d_alpha_cont, void *d_alpha_native,
+                             void *stream, bool f32_out)
 {
     DeviceScope scope;
     if (!p || !lambda || !d_velocity || !d_doppler_width || !d_gamma || !d_line_strength || !d_alpha_cont ||
@@ -1415,13 +1433,31 @@ int vrt_line_opacity_dev(vrt_plan *p, int64_t nlam, const double *lambda, double
         std::vector<double> h(lambda, lambda + nlam);
         if ((rc = upload_small(g, h, (hipStream_t)stream))) return rc;
         rc = launch_line_opacity(p, nlam, g->d_small, lambda0, c0, d_velocity, d_doppler_width, d_gamma,
-                                 d_line_strength, d_alpha_cont, d_alpha_native, (hipStream_t)stream);
+                                 d_line_strength, d_alpha_cont, d_alpha_native, (hipStream_t)stream, f32_out);
         return rc ? rc : small_done(g, (hipStream_t)stream);
     } catch (const std::bad_alloc &) {
         return fail(VRT_ENOMEM, "out of host memory");
     } catch (...) {
         return fail(VRT_EINVAL, "unexpected exception");
     }
+}
+
+int vrt_line_opacity_dev(vrt_plan *p, int64_t nlam, const double *lambda, double lambda0, double c0,
+                         const double *d_velocity, const double *d_doppler_width, const double *d_gamma,
+                         const double *d_line_strength, const double *d_alpha_cont, double *d_alpha_native,
+                         void *stream)
+{
+    return line_opacity_impl(p, nlam, lambda, lambda0, c0, d_velocity, d_doppler_width, d_gamma, d_line_strength,
+                             d_alpha_cont, d_alpha_native, stream, false);
+}
+
+int vrt_line_opacity_dev_f32(vrt_plan *p, int64_t nlam, const double *lambda, double lambda0, double c0,
+                             const double *d_velocity, const double *d_doppler_width, const double *d_gamma,
+                             const double *d_line_strength, const double *d_alpha_cont, float *d_alpha_native,
+                             void *stream)
+{
+    return line_opacity_impl(p, nlam, lambda, lambda0, c0, d_velocity, d_doppler_width, d_gamma, d_line_strength,
+                             d_alpha_cont, d_alpha_native, stream, true);
 }
 
 int vrt_rates_populations_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *lambda,

@@ -311,7 +311,8 @@ int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, 
 // ---- physics either side of the formal solve (vrt_physics.hip) -------------------------------------
 int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, double lambda0, double c0,
                         const double *d_velocity, const double *d_doppler, const double *d_gamma,
-                        const double *d_strength, const double *d_alpha_cont, double *d_out, hipStream_t st);
+                        const double *d_strength, const double *d_alpha_cont, void *d_out, hipStream_t st,
+                        bool f32_out = false);
 int launch_line_terms(int64_t n, const double *d_gamma_static, const double *d_gamma_unsold, const double *d_pops,
                       double strength_const, double Bij, double Bji, double *d_gamma, double *d_strength, hipStream_t st);
 int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_t blocks[6],
@@ -331,7 +332,7 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, co
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
 int launch_sorted_tables(vrt_plan *p, int a);
 int launch_gpos(vrt_plan *p, int a);
-int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha, double *out, hipStream_t st);
+int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const void *dalpha, void *out, hipStream_t st, bool f32);
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, const void *dalpha,
                   int alpha_mode, const void *dI0_up, const void *dI0_down,
                   const double *weights_user, void *dJ, void *dI_out, hipStream_t st, bool f32);

@@ -93,7 +93,8 @@ static int build_task_map(vrt_plan *p, int nlam, hipStream_t st)
 }
 
 // caller's per-angle alpha (n_angles, n, ld) -> the native layout of VRT_ALPHA_ANGLE_NATIVE
-int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha, double *out, hipStream_t st)
+template <typename T>
+static int alpha_to_native_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dalpha, T *out, hipStream_t st)
 {
     vrt_grid *g = p->g;
     const int64_t n = g->n;
@@ -102,12 +103,18 @@ int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha,
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
     for (int a = 0; a < p->A; a++) {
         const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-        hipLaunchKernelGGL(k_to_sweep_order<double>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2, dir.d_store,
+        hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2, dir.d_store,
                            dalpha + (size_t)p->user_of_active[(size_t)a] * (size_t)n * (size_t)ld,
                            out + (size_t)a * plane);
     }
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
+}
+
+int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const void *dalpha, void *out, hipStream_t st, bool f32)
+{
+    return f32 ? alpha_to_native_t<float>(p, nlam, ld, (const float *)dalpha, (float *)out, st)
+               : alpha_to_native_t<double>(p, nlam, ld, (const double *)dalpha, (double *)out, st);
 }
 
 // internal streams + angle groups of the layer-step path

@@ -86,12 +86,14 @@ constexpr double kPi = 3.14159265358979323846;
 // ---- opacity prologue -------------------------------------------------------------------------------
 // one thread per storage position of the angle's direction; it walks the wavelength pairs, so the
 // site's seven line parameters are read once and every pair plane is written coalesced (16 B/lane)
+// T2 = double2, or float2 for the fp32 VALUE path (the arithmetic stays fp64, the stored pair is rounded)
+template <typename T2>
 __global__ void __launch_bounds__(256)
 k_line_opacity(int64_t n, int nlam, int npair, const int32_t *__restrict__ store, double k0, double k1, double k2,
                const double *__restrict__ lambda, double lambda0, double c0, const double *__restrict__ velocity,
                const double *__restrict__ doppler, const double *__restrict__ gamma,
                const double *__restrict__ strength, const double *__restrict__ alpha_cont,
-               double2 *__restrict__ out /* [npair][n] */)
+               T2 *__restrict__ out /* [npair][n] */)
 {
     const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= n) return;
@@ -118,13 +120,16 @@ k_line_opacity(int64_t n, int nlam, int npair, const int32_t *__restrict__ store
             } else
                 v2[h] = ac;                                                            // padding wavelength: finite
         }
-        out[(size_t)q * (size_t)n + (size_t)pos] = make_double2(v2[0], v2[1]);
+        T2 o;
+        o.x = (decltype(o.x))v2[0];
+        o.y = (decltype(o.y))v2[1];
+        out[(size_t)q * (size_t)n + (size_t)pos] = o;
     }
 }
 
 int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, double lambda0, double c0,
                         const double *d_velocity, const double *d_doppler, const double *d_gamma,
-                        const double *d_strength, const double *d_alpha_cont, double *d_out, hipStream_t st)
+                        const double *d_strength, const double *d_alpha_cont, void *d_out, hipStream_t st, bool f32_out)
 {
     vrt_grid *g = p->g;
     const int64_t n = g->n;
@@ -133,9 +138,14 @@ int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, doubl
     for (int a = 0; a < p->A; a++) {
         const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
         const double *k = p->k.data() + 3 * (size_t)a;
-        hipLaunchKernelGGL(k_line_opacity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (int)nlam, npair,
-                           dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
-                           d_strength, d_alpha_cont, reinterpret_cast<double2 *>(d_out + (size_t)a * plane));
+        if (f32_out)
+            hipLaunchKernelGGL(k_line_opacity<float2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (int)nlam, npair,
+                               dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
+                               d_strength, d_alpha_cont, reinterpret_cast<float2 *>((float *)d_out + (size_t)a * plane));
+        else
+            hipLaunchKernelGGL(k_line_opacity<double2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (int)nlam, npair,
+                               dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
+                               d_strength, d_alpha_cont, reinterpret_cast<double2 *>((double *)d_out + (size_t)a * plane));
     }
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
