@@ -46,11 +46,15 @@ typedef struct vrt_plan vrt_plan;   /* per-(grid, angle set) upwind tables + swe
 #define VRT_ALPHA_SITE_LAM 1    /* alpha[n][ld]             same for every angle (continuum)      */
 #define VRT_ALPHA_ANGLE_SITE_LAM 2 /* alpha[n_angles][n][ld] per angle (line: lambda_iteration.jl:89-96) */
 /* per angle, already in the library's NATIVE layout (device entry points only): for every angle a
- * block of vrt_plan_native_alpha_count / n_angles doubles holding wavelength PAIRS side by side,
- * element (l, pos) at ((l/2) * n + pos) * 2 + l%2 with pos = the site's position in the storage
- * order of the angle's direction (vrt_grid_get_storage_order); an odd nlam is padded with one
- * finite wavelength.  Written by vrt_plan_alpha_to_native_dev or vrt_line_opacity_dev; saves the
- * 2 x 8 B per (site, angle, wavelength) of the layout change on every execute. */
+ * block of vrt_plan_native_alpha_count / n_angles doubles holding wavelength PAIRS (an odd nlam is
+ * padded with one finite wavelength), B = vrt_plan_native_pair_block(p) pairs of a site side by
+ * side: the pairs form blocks of B, then (B not dividing the pair count) one block per set bit of
+ * the remainder, widest first; pair q of a block [q0, q0 + w) at storage position pos is pair
+ * element q0 * n + pos * w + (q - q0), each element two values (wavelengths 2q, 2q + 1); pos = the
+ * site's position in the storage order of the angle's direction (vrt_grid_get_storage_order).
+ * B = 1: element (l, pos) at ((l/2) * n + pos) * 2 + l%2.  Written by vrt_plan_alpha_to_native_dev
+ * or vrt_line_opacity_dev -- callers need not know the layout; it saves the 2 x 8 B per (site,
+ * angle, wavelength) of the layout change on every execute. */
 #define VRT_ALPHA_ANGLE_NATIVE 3
 
 const char *vrt_last_error(void);
@@ -141,6 +145,8 @@ int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS
 int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out);
 /* number of doubles of the native per-angle alpha buffer for nlam wavelengths */
 int64_t vrt_plan_native_alpha_count(const vrt_plan *p, int64_t nlam);
+/* pairs per block B of the plan's native layout (1, 2, 4, 8 or 16; option VRT_PAIR_BLOCK at creation) */
+int vrt_plan_native_pair_block(const vrt_plan *p);
 /* converts the caller's (nlam, n, n_angles) alpha (VRT_ALPHA_ANGLE_SITE_LAM) once, e.g. per
  * Λ-iteration when alpha changes, so that every execute of that iteration reads it in place */
 int vrt_plan_alpha_to_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha,
@@ -174,6 +180,9 @@ int vrt_plan_last_path(const vrt_plan *p);
  *   VRT_PATH = auto | levels | tiles | steps | patches
  *   VRT_PATCH_Q, VRT_PATCH_TARGET              wavelength pairs at a time / workgroups per launch of the patch kernel
  *   VRT_PATCH_K, VRT_PATCH_NT, VRT_PATCH_OWN   entries per thread, threads, owned sites per patch (creation only)
+ *   VRT_PATCH_PIPE = 0 | 1 | 2                 software-pipelined patch kernel: off, on, with fp32 storage only (default)
+ *   VRT_PAIR_BLOCK = 1 | 2 | 4 | 8 | 16        wavelength pairs of a site side by side in the patch path's planes and
+ *                                              in the plan's native alpha (creation only; default 1)
  *   VRT_STEP_K, VRT_STEP_SINGLE, VRT_STEP_PAIRS, VRT_STEP_XCD, VRT_STEP_STREAMS, VRT_STEP_LEVEL_MAP,
  *   VRT_STEP_GROUP_DIR, VRT_TILE_WIDE, VRT_TILE_PRE, VRT_GRAPH     variants of the older paths
  * VRT_EINVAL for an unknown name, a value out of range, or a creation-only option on a live plan. */

@@ -180,11 +180,21 @@ def test_C4_1M_per_angle_alpha_51_wavelengths(grid_1m):
                      dJ=Jn.data_ptr(), dI0_up=I0.data_ptr(), stream=st)
     torch.cuda.synchronize()
     assert torch.equal(J, Jn)
-    # the native layout is what the header says: element (l, pos) of angle a at ((l/2) n + pos) 2 + l%2
-    a_i, l, npad = 7, 33, 52
-    order = hs.storage_order(1 if th[a_i] > 90 else -1) - 1
-    blk = native[a_i * npad * n:(a_i + 1) * npad * n].view(npad // 2, n, 2)
-    assert torch.equal(blk[l // 2, :, l % 2], alpha[a_i, torch.as_tensor(order, device=dev), l])
+    # the native layout is what the header says: pair q = l/2 of the block [q0, q0 + w) it falls in, at storage
+    # position pos of angle a, is pair element q0 n + pos w + (q - q0) (26 pairs in blocks of B = 8: 8, 8, 8, 2)
+    B = plan.native_pair_block
+    npad = 52
+    for a_i, l in ((7, 33), (2, 50), (11, 0)):
+        order = hs.storage_order(1 if th[a_i] > 90 else -1) - 1
+        q = l // 2
+        widths = [B] * (26 // B) + [1 << b for b in range(B.bit_length() - 2, -1, -1) if (26 % B) & (1 << b)]
+        q0 = 0
+        for wd in widths:
+            if q < q0 + wd:
+                break
+            q0 += wd
+        blk = native[a_i * npad * n:(a_i + 1) * npad * n].view(-1, 2)[q0 * n:(q0 + wd) * n].view(n, wd, 2)
+        assert torch.equal(blk[:, q - q0, l % 2], alpha[a_i, torch.as_tensor(order, device=dev), l])
     sel = [0, 37]
     ref = orc.J_voronoi(w, th, ph, S[:, sel].cpu().numpy(), alpha[:, :, sel].cpu().numpy(), so,
                         I0_up=I0[:, sel].cpu().numpy(), nthreads=8)

@@ -133,10 +133,13 @@ def test_oracle_rates_and_populations_against_numpy_transcription():
 
 
 @pytest.mark.gpu
-def test_gpu_line_opacity_native_layout_and_sweep(voro_small):
+@pytest.mark.parametrize("pair_block", [1, 8])
+def test_gpu_line_opacity_native_layout_and_sweep(voro_small, pair_block, monkeypatch):
     """vrt_line_opacity_dev writes α_tot of every angle in the native layout; the same α through the
-    caller's layout gives the same J bit for bit, and both match the oracle's α / J."""
+    caller's layout gives the same J bit for bit, and both match the oracle's α / J.  Also with eight
+    wavelength pairs of a site side by side (VRT_PAIR_BLOCK=8: 26 pairs in blocks of 8, 8, 8, 2)."""
     import torch
+    monkeypatch.setenv("VRT_PAIR_BLOCK", str(pair_block))
     pos, nbr, bounds = voro_small
     hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
     so = orc.make_sites(pos, nbr, bounds)
@@ -159,13 +162,12 @@ def test_gpu_line_opacity_native_layout_and_sweep(voro_small):
     torch.cuda.synchronize()
     alpha_ref = np.stack([orc.line_opacity(orc.direction(th[a], ph[a]), lam, c["lambda0"], C0, c["velocity"],
                                            c["doppler"], c["gamma"], strength, alpha_cont) for a in range(nq)])
-    npad = nlam + 1
-    nat = native.cpu().numpy().reshape(nq, npad // 2, n, 2)
-    assert np.isfinite(nat).all()
+    assert np.isfinite(native.cpu().numpy()).all()
+    assert plan.native_pair_block == pair_block
+    nat = plan.native_to_site_major(native.cpu().numpy(), nlam, nq)      # [angle][pos][l]
     for a in range(nq):
         order = hs.storage_order(1 if th[a] > 90 else -1) - 1
-        got = nat[a].transpose(1, 0, 2).reshape(n, npad)[:, :nlam]       # [pos][l]
-        assert np.abs(got / alpha_ref[a][order] - 1).max() < 1e-12, a
+        assert np.abs(nat[a] / alpha_ref[a][order] - 1).max() < 1e-12, a
     rng = np.random.default_rng(4)
     S = 1 + rng.random((n, nlam))
     I0 = rng.random((so.layers_up[1] - 1, nlam))
@@ -217,11 +219,8 @@ def test_gpu_f32_storage_accepts_native_per_angle_alpha(voro_small):
     torch.cuda.synchronize()
     nat, nat2 = native.cpu().numpy(), native2.cpu().numpy()
     assert np.isfinite(nat).all()
-    npad = nlam + 1
-    live = np.ones(npad, dtype=bool)
-    live[nlam:] = False                                            # the pad wavelength of the last pair is unspecified
-    v1 = nat.reshape(nq, npad // 2, n, 2).transpose(0, 2, 1, 3).reshape(nq, n, npad)[:, :, live]
-    v2 = nat2.reshape(nq, npad // 2, n, 2).transpose(0, 2, 1, 3).reshape(nq, n, npad)[:, :, live]
+    v1 = plan.native_to_site_major(nat, nlam, nq)                  # the pad wavelength of the last pair is unspecified
+    v2 = plan.native_to_site_major(nat2, nlam, nq)
     assert np.abs(v1 / v2 - 1).max() < 2.5e-7                      # device fp64 -> float vs numpy fp64 -> float: ≤ 1 ulp
     for a in range(nq):
         order = hs.storage_order(1 if th[a] > 90 else -1) - 1
@@ -266,13 +265,12 @@ def test_gpu_physics_entries_with_growing_wavelength_arrays(voro_small):
         plan.line_opacity_dev(lam, c["lambda0"], C0, d_vel.data_ptr(), d_dop.data_ptr(), d_gam.data_ptr(),
                               d_str.data_ptr(), d_ac.data_ptr(), native.data_ptr(), stream=stream.cuda_stream)
         torch.cuda.synchronize()
-        npad = (nlam + 1) // 2 * 2
-        nat = native.cpu().numpy().reshape(nq, npad // 2, n, 2)
+        nat = plan.native_to_site_major(native.cpu().numpy(), nlam, nq)
         for a in (0, nq - 1):
             ref = orc.line_opacity(orc.direction(th[a], ph[a]), lam[[0, nlam - 1]], c["lambda0"], C0, c["velocity"],
                                    c["doppler"], c["gamma"], c["strength"], c["alpha_cont"])
             order = hs.storage_order(1 if th[a] > 90 else -1) - 1
-            got = nat[a].transpose(1, 0, 2).reshape(n, npad)[:, [0, nlam - 1]]
+            got = nat[a][:, [0, nlam - 1]]
             assert np.abs(got / ref[order] - 1).max() < 1e-12, (nlam, a)
     plan.close()
     hs.close()

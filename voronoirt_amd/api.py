@@ -293,6 +293,27 @@ class FormalPlan:
         """Number of float64 values of the native per-angle alpha buffer (ALPHA_ANGLE_NATIVE)."""
         return int(_lib.load().vrt_plan_native_alpha_count(self._h, nlam))
 
+    @property
+    def native_pair_block(self) -> int:
+        """Wavelength pairs of a site kept side by side in the native layout (include/voronoirt.h)."""
+        return int(_lib.load().vrt_plan_native_pair_block(self._h))
+
+    def native_to_site_major(self, native, nlam: int, n_angles: int):
+        """Host helper (tests, debugging): a native per-angle buffer (numpy, any float type) ->
+        (n_angles, n, nlam) with rows in STORAGE order of each angle's direction."""
+        native = np.asarray(native)
+        n, B = self.sites.n, self.native_pair_block
+        npair = (nlam + 1) // 2
+        per = native.reshape(n_angles, npair * n * 2)
+        out = np.empty((n_angles, n, 2 * npair), dtype=native.dtype)
+        q0 = 0
+        widths = [B] * (npair // B) + [1 << b for b in range(B.bit_length() - 2, -1, -1) if (npair % B) & (1 << b)]
+        for w in widths:
+            blk = per[:, q0 * n * 2:(q0 + w) * n * 2].reshape(n_angles, n, 2 * w)
+            out[:, :, 2 * q0:2 * (q0 + w)] = blk
+            q0 += w
+        return out[:, :, :nlam]
+
     def alpha_to_native_dev(self, nlam: int, ld: int, dalpha: int, dalpha_native: int, stream: int = 0,
                             f32: bool = False) -> None:
         """Device (n_angles, n, ld) per-angle alpha -> the native layout, once per change of alpha

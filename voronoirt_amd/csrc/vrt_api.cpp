@@ -25,7 +25,7 @@ void tuning_from_env(Tuning &t)
     static const char *names[] = {"VRT_PATH", "VRT_STEP_K", "VRT_STEP_SINGLE", "VRT_STEP_PAIRS", "VRT_STEP_XCD",
                                   "VRT_STEP_STREAMS", "VRT_STEP_LEVEL_MAP", "VRT_STEP_GROUP_DIR", "VRT_TILE_WIDE",
                                   "VRT_TILE_PRE", "VRT_GRAPH", "VRT_PATCH_K", "VRT_PATCH_NT", "VRT_PATCH_OWN",
-                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
+                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_PIPE", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
                                   "VRT_TILE_DEBUG"};
     for (const char *nm : names) {
         const char *e = std::getenv(nm);
@@ -55,7 +55,8 @@ int tuning_set(Tuning &t, const char *name, const char *value, bool created)
         {"VRT_TILE_PRE", &t.tile_pre, 0, 1, false}, {"VRT_GRAPH", &t.graph, 0, 1, false},
         {"VRT_PATCH_K", &t.patch_K, 1, 8, true}, {"VRT_PATCH_NT", &t.patch_NT, 64, 1024, true},
         {"VRT_PATCH_OWN", &t.patch_own, 0, 65535, true}, {"VRT_PATCH_Q", &t.patch_Q, 1, 4, false},
-        {"VRT_PATCH_TARGET", &t.patch_target, 1, 1 << 20, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
+        {"VRT_PATCH_TARGET", &t.patch_target, 1, 1 << 20, false}, {"VRT_PAIR_BLOCK", &t.pair_block, 1, 16, true},
+        {"VRT_PATCH_PIPE", &t.patch_pipe, 0, 2, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
         {"VRT_DEBUG_SKIP_LEVELS", &t.debug_skip_levels, 0, 1, false}, {"VRT_TILE_DEBUG", &t.tile_debug, 0, 1, false},
     };
     for (auto &o : tab)
@@ -450,6 +451,12 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         p->patch_K = p->tune.patch_K;
         p->patch_NT = p->tune.patch_NT;
         p->patch_cap = p->patch_K * p->patch_NT;
+        // pairs of a site side by side in the patch path's planes: a power of two, and a plane block must stay
+        // addressable with 32-bit byte offsets (n sites x 2^lg pairs x 16 bytes)
+        int lg = 0;
+        while ((2 << lg) <= p->tune.pair_block && lg < 4) lg++;
+        while (lg > 0 && ((uint64_t)n << (lg + 4)) > 0xFFFFFFFFull) lg--;
+        p->lg_pair_block = lg;
     }
     // a patch owns as many consecutive sites as its dependency cone leaves room for (VRT_PATCH_OWN: at most that many)
     const int patch_own = p->tune.patch_own > 0 ? std::min(p->tune.patch_own, p->patch_cap) : p->patch_cap;
@@ -696,8 +703,12 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_, c
             path = 3;
         if (p->tune.path) path = p->tune.path;
         // the native layout IS the storage order of the layer paths
-        if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && path != 3 && path != 4) path = (steps_ok && !f32) ? 3 : 4;
-        if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE && path == 3 && (f32 || !steps_ok)) path = 4;
+        // (laid out for the patch path when the grid fits it: then the steps path can only read it with one pair per block)
+        if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE) {
+            const bool steps_can = steps_ok && !f32 && native_lg(p) == 0;
+            if (path == 3 && !steps_can) path = 4;
+            else if (path != 3 && path != 4) path = p->patch_ok ? 4 : 3;
+        }
         if (p->A == 0) path = 1;      // nothing to solve (every direction skipped): J = 0 via the level path
         if ((path == 3 && !steps_ok) || (path == 2 && !tiles_ok) || (path == 4 && !p->patch_ok))
             return fail(VRT_EINVAL, "VRT_PATH = tiles / steps / patches but the grid (or the fp32 storage type) does not fit those kernels");
@@ -1172,6 +1183,8 @@ int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out)
     for (int64_t i = 0; i < g->n; i++) out[i] = (int64_t)d.store[(size_t)i] + 1;
     return VRT_OK;
 }
+
+int vrt_plan_native_pair_block(const vrt_plan *p) { return p ? 1 << native_lg(p) : 0; }
 
 int64_t vrt_plan_native_alpha_count(const vrt_plan *p, int64_t nlam)
 {

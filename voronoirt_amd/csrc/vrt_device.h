@@ -21,15 +21,64 @@ constexpr bool kDiag = false;
 constexpr uint32_t kNoSlot = 0xFFFFu;   // t_loc entry of an upwind outside the site's own layer (layers <= 8192 sites)
 
 // ---- layout changes -----------------------------------------------------------------------------
-// Storage-order arrays are wavelength-major in blocks of `lb` wavelengths: element (l, p) lives at
-// ((l / lb) * n + p) * lb + l % lb.  lb = 1 (plain planes [λ][pos]) for the persistent tile
-// kernel; lb = 2 (wavelength PAIRS interleaved per site, [λ/2][pos][2]) for the layer-step
-// kernels, whose 16-byte accesses fetch two wavelengths per gathered cache line.  Planes are
-// padded to a multiple of lb wavelengths.
-__device__ __forceinline__ size_t sw_index(int l, int64_t p, int64_t n, int lb)
+// Storage-order arrays are wavelength-major.  lb = 1: plain planes [λ][pos] (persistent tile kernel).
+// lb = 2 B >= 2: wavelength PAIRS (one 16-byte access = two wavelengths), B pairs of a site side by side:
+// pair q of storage position p lives at pair element  k0 n + (p << lw) + (q - k0),  where [k0, k0 + 2^lw) is
+// the BLOCK of pair q: blocks of B pairs, then -- when B does not divide the pair count -- one block per set bit
+// of the remainder, widest first (26 pairs, B = 8: 8, 8, 8, 2), so that no plane is padded and a site's record
+// never holds bytes nobody reads.  B = 1 ([λ/2][pos][2]) is what the layer-step kernels read; B = 8 makes a
+// gathered 128-byte line ONE site's eight pairs, which the eight sibling workgroups of a patch (one pair of the
+// block each) use whole (vrt_patch.hip).  Planes hold ceil(nλ / 2) pairs.
+__host__ __device__ __forceinline__ void pair_block_at(int q, int npair, int lgB, int &k0, int &lw)
+{
+    const int full = npair >> lgB << lgB;
+    if (q < full) { k0 = q >> lgB << lgB; lw = lgB; return; }
+    int k = full;
+    const int r = npair - full;
+    for (int bit = lgB - 1; bit >= 0; bit--)
+        if (r & (1 << bit)) {
+            if (q < k + (1 << bit)) { k0 = k; lw = bit; return; }
+            k += 1 << bit;
+        }
+    k0 = k; lw = 0;                                   // q >= npair: not a pair of the plane
+}
+// block number k -> its first pair and log2 width (k0 = npair when there is no such block)
+__host__ __device__ __forceinline__ void pair_block_of(int k, int npair, int lgB, int &k0, int &lw)
+{
+    const int nfull = npair >> lgB;
+    if (k < nfull) { k0 = k << lgB; lw = lgB; return; }
+    int j = k - nfull;
+    k0 = nfull << lgB;
+    const int r = npair - k0;
+    for (int bit = lgB - 1; bit >= 0; bit--)
+        if (r & (1 << bit)) {
+            if (j == 0) { lw = bit; return; }
+            j--;
+            k0 += 1 << bit;
+        }
+    lw = 0;
+}
+__host__ __device__ __forceinline__ int pair_block_count(int npair, int lgB)
+{
+    return (npair >> lgB) + __builtin_popcount((unsigned)(npair - (npair >> lgB << lgB)));
+}
+__host__ __device__ __forceinline__ size_t pair_index(int q, int64_t p, int64_t n, int lgB, int npair)
+{
+    int k0, lw;
+    pair_block_at(q, npair, lgB, k0, lw);
+    return (size_t)k0 * (size_t)n + ((size_t)p << lw) + (size_t)(q - k0);
+}
+__host__ __device__ __forceinline__ int log2_pairs(int lb)     // lb = 2 B wavelengths per block -> log2 B
+{
+    int lg = 0;
+    while ((2 << lg) < lb) lg++;
+    return lg;
+}
+// scalar element (wavelength l, storage position p); npair = ceil(nλ / 2) (unused for lb = 1)
+__device__ __forceinline__ size_t sw_index(int l, int64_t p, int64_t n, int lb, int npair)
 {
     return lb == 1 ? (size_t)l * (size_t)n + (size_t)p
-                   : (((size_t)(l >> 1) * (size_t)n + (size_t)p) << 1) + (size_t)(l & 1);
+                   : (pair_index(l >> 1, p, n, log2_pairs(lb), npair) << 1) + (size_t)(l & 1);
 }
 
 // storage types: T = double, or float for the fp32 VALUE path (BASELINE config C5: S, α, I, J held as

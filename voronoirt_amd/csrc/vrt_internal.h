@@ -78,6 +78,11 @@ struct Tuning {
     int patch_K = 1, patch_NT = 512;   // VRT_PATCH_K, VRT_PATCH_NT: entries per thread, threads (plan creation only)
     int patch_own = 0;            // VRT_PATCH_OWN: owned sites per patch at most (0: as many as fit; creation only)
     int patch_Q = 1;              // VRT_PATCH_Q: wavelength pairs a patch workgroup solves at a time
+    int pair_block = 1;           // VRT_PAIR_BLOCK: wavelength pairs of a site kept side by side in the patch path's
+                                  //   storage layout, 1 / 2 / 4 / 8 / 16 (vrt_device.h; creation only: the native
+                                  //   per-angle alpha of the plan is laid out with it)
+    int patch_pipe = 2;           // VRT_PATCH_PIPE: the software-pipelined kernel for the (1, 1, NT) shapes: 0 off, 1 on,
+                                  //   2 = with fp32 storage only (C5 -4 %, C3 -1 %, C4 +4 %: DESIGN.md section 5)
     int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
     int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)
 };
@@ -201,6 +206,7 @@ struct vrt_plan {
     std::vector<int32_t> h_step_angles;  // host copy of d_step_angles
     // fused patch path (vrt_patch.hip): per-angle patch schedules, concatenated over the active angles
     bool patch_ok = false;
+    int lg_pair_block = 0;           // log2 of the pairs per block of the patch path's storage layout (vrt_device.h)
     int patch_cap = 0, patch_K = 0, patch_NT = 0;   // entries per patch <= cap = K * NT (fixed at creation)
     int64_t n_patches = 0, n_patch_entries = 0, n_patch_visits = 0;
     std::vector<int32_t> h_patch_first;  // [A][tile_max_layers + 2]: index of the first patch of (angle, layer)
@@ -332,6 +338,8 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, co
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
 int launch_sorted_tables(vrt_plan *p, int a);
 int launch_gpos(vrt_plan *p, int a);
+// log2 of the pairs per block of the plan's NATIVE per-angle alpha (and of every plane of the patch path)
+inline int native_lg(const vrt_plan *p) { return p->patch_ok ? p->lg_pair_block : 0; }
 int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const void *dalpha, void *out, hipStream_t st, bool f32);
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, const void *dalpha,
                   int alpha_mode, const void *dI0_up, const void *dI0_down,

@@ -36,14 +36,19 @@ k_to_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__restr
             if (l < nlam && p0 + tx < n) out[(size_t)l * n + p0 + tx] = tile[tx][ty + 4 * j];
         }
     } else {                                   // one 16-byte store per (site, wavelength pair)
+        // consecutive lanes write the consecutive pairs of a site's block, then the next site: whole lines
+        // (the tile's 32 pairs start on a block boundary: blocks hold at most 32 pairs)
+        const int lgB = log2_pairs(lb), npair = (nlam + 1) >> 1;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int c = 2 * (ty + 4 * j), l = l0 + c;
-            if (l < nlam && p0 + tx < n) {
+            const int e = j * 256 + (int)threadIdx.x;
+            const int pb = e & ((1 << lgB) - 1), px = (e >> lgB) & 63, bt = e >> (lgB + 6);
+            const int c = 2 * ((bt << lgB) + pb), l = l0 + c;
+            if (l < nlam && p0 + px < n) {
                 typename Pair<T>::type v2;
-                v2.x = tile[tx][c];
-                v2.y = l + 1 < nlam ? tile[tx][c + 1] : (T)0;
-                reinterpret_cast<typename Pair<T>::type *>(out)[(size_t)(l >> 1) * (size_t)n + (size_t)(p0 + tx)] = v2;
+                v2.x = tile[px][c];
+                v2.y = l + 1 < nlam ? tile[px][c + 1] : (T)0;
+                reinterpret_cast<typename Pair<T>::type *>(out)[pair_index(l >> 1, p0 + px, n, lgB, npair)] = v2;
             }
         }
     }
@@ -76,19 +81,20 @@ k_boundary_sweep_order(int64_t n, int nlam, int lb, int64_t n1, const int32_t *_
         if (p < n1 && l0 + tx < nlam) tile[r][tx] = I0 ? I0[(size_t)p * nlam + l0 + tx] : (T)0;
     }
     __syncthreads();
-    const int nl_pad = (nlam + lb - 1) / lb * lb;
+    const int npair = (nlam + 1) >> 1;
+    const int nl_pad = lb == 1 ? nlam : 2 * npair;
     T *Ia = I + (size_t)a * (size_t)nl_pad * (size_t)n;
     for (int c = ty; c < 64; c += 4) {
         const int l = l0 + c;
         // I_0 is ordered like perm[1:n1] (irregular_ray_tracing.jl:33); storage is Morton order
         if (l < nlam && p0 + tx < n1) {
             const int32_t pos = srank[order[p0 + tx]];
-            Ia[sw_index(l, pos, n, lb)] = tile[tx][c];
-            if (l == nlam - 1 && nl_pad > nlam) Ia[sw_index(nlam, pos, n, lb)] = (T)0;   // padding wavelength
+            Ia[sw_index(l, pos, n, lb, npair)] = tile[tx][c];
+            if (l == nlam - 1 && nl_pad > nlam) Ia[sw_index(nlam, pos, n, lb, npair)] = (T)0;   // padding wavelength
         }
         // the never-visited site perm[n] (storage position n-1) keeps I = 0 (voronoi_utils.jl:266)
         // -- also on a single-layer grid, where no layer kernel ever runs
-        if (blockIdx.x == 0 && tx == 0 && l < nl_pad) Ia[sw_index(l, n - 1, n, lb)] = (T)0;
+        if (blockIdx.x == 0 && tx == 0 && l < nl_pad) Ia[sw_index(l, n - 1, n, lb, npair)] = (T)0;
     }
 }
 
@@ -124,13 +130,37 @@ k_combine_J(int64_t n, int nlam, int64_t ldJ, int lb, const int32_t *__restrict_
         site = order_up[p];
         pd = rank_down[site];
     }
-    for (int c = ty; c < 64; c += 4) {
-        const int l = l0 + c;
-        if (l < nlam && p < n) {
-            double v = 0.0;
-            if (Ju) v = (double)Ju[sw_index(l, p, n, lb)];
-            if (Jdn) v = v + (double)Jdn[sw_index(l, pd, n, lb)];
-            tile[tx][c] = (T)v;
+    if (lb == 1) {
+        for (int c = ty; c < 64; c += 4) {
+            const int l = l0 + c;
+            if (l < nlam && p < n) {
+                double v = 0.0;
+                if (Ju) v = (double)Ju[(size_t)l * n + p];
+                if (Jdn) v = v + (double)Jdn[(size_t)l * n + pd];
+                tile[tx][c] = (T)v;
+            }
+        }
+    } else {                                   // pair accesses, a site's block of pairs by consecutive lanes
+        typedef typename Pair<T>::type T2;
+        __shared__ int32_t pds[64];
+        if (threadIdx.x < 64) pds[threadIdx.x] = pd;
+        __syncthreads();
+        const int lgB = log2_pairs(lb), npair = (nlam + 1) >> 1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int e = j * 256 + (int)threadIdx.x;
+            const int pb = e & ((1 << lgB) - 1), px = (e >> lgB) & 63, bt = e >> (lgB + 6);
+            const int c = 2 * ((bt << lgB) + pb), l = l0 + c;
+            if (l < nlam && p0 + px < n) {
+                double2 v = make_double2(0.0, 0.0);
+                if (Ju) v = to_d2(reinterpret_cast<const T2 *>(Ju)[pair_index(l >> 1, p0 + px, n, lgB, npair)]);
+                if (Jdn) {
+                    const double2 u = to_d2(reinterpret_cast<const T2 *>(Jdn)[pair_index(l >> 1, pds[px], n, lgB, npair)]);
+                    v.x = v.x + u.x; v.y = v.y + u.y;
+                }
+                tile[px][c] = (T)v.x;
+                tile[px][c + 1] = (T)v.y;
+            }
         }
     }
     __syncthreads();
@@ -152,7 +182,7 @@ k_from_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__res
     const int l0 = blockIdx.y * 64;
     for (int c = ty; c < 64; c += 4) {
         const int l = l0 + c;
-        if (l < nlam && p0 + tx < n) tile[tx][c] = in ? in[sw_index(l, p0 + tx, n, lb)] : (T)0;
+        if (l < nlam && p0 + tx < n) tile[tx][c] = in ? in[sw_index(l, p0 + tx, n, lb, (nlam + 1) >> 1)] : (T)0;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {

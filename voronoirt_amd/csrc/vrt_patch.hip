@@ -28,12 +28,14 @@ struct PatchArgs {
     TileArgs ta;              // n, nlam, alpha_mode, angle_dir, lay, nlayers, S, alpha, alpha_angle, I (pair planes)
     int npair;                // ceil(nlam / 2)
     int layer;                // 1-based BFS layer being solved
-    int ngrp;                 // workgroups per work item: each walks ppw wavelength pairs
-    int ppw;
+    int ngrp;                 // workgroups per work item = siblings (1 << lgB) x splits
+    int bps;                  // pair blocks per split: a workgroup walks ONE pair (its sibling number) of bps blocks
+    int lgB;                  // log2 of the pairs per block of the storage layout (vrt_device.h: pair_block_at)
     int stride;               // tile slots per pair plane (> largest entry count: + the zero slot)
     int cap;                  // entries per patch at most (K * NT): length of the LDS table arrays
     int dbg;                  // timing diagnostics (-DVRT_DIAG build only, WRONG results): 1 no levels, 2 gathers ->
-                              //   coalesced centre reads, 4 no weights arithmetic, 8 no stores
+                              //   coalesced centre reads, 4 no weights arithmetic, 8 no stores, 16 / 32 / 64 no upwind gathers
+                              //   of I / alpha / S, 128 no J reduction
     // J reduction riding along (lagged by one layer): the first nred blocks of the launch do not solve a patch
     // but form J_dir = Σ_a w_a I_a (reference's angle order inside the direction) over storage positions
     // [red_lo, red_hi) of up to two directions -- layers the stream's previous launch has made final
@@ -169,13 +171,84 @@ __device__ __forceinline__ void entry_lambda(double rh1, double rh2, double w1, 
     else entry_terms<2>(d1, d2, w1, w2, wg1, wg2, S_c, S_1, S_2, I_1, I_2, c, g1, g2);
 }
 
+// The same, one upwind at a time: `next` (the optical depth the following evaluation starts from) is tied to this
+// one's results by a compiler fence, so that the four evaluations of an entry's pair follow each other instead of
+// being interleaved -- the pipelined kernel holds the next pair's 32 landed registers while it computes.  The
+// weights w_r are read from the thread's LDS slots where they are used (pw1, pw2), not held.
+template <int MODE>
+__device__ __forceinline__ void entry_terms_seq(double dt1, double dt2, const double *pw1, const double *pw2, bool in1,
+                                                bool in2, double S_c, double S_1, double S_2, double I_1, double I_2,
+                                                double &c, double &g1, double &g2, double &next)
+{
+    double ca, cb, ce;
+    lin_weights_fma<MODE>(dt1, ca, cb, ce);
+    const double w1 = *pw1;
+    double t1 = fma(cb, S_c, fma(ce, I_1, ca * S_1)) * w1;
+    g1 = in1 ? ce * w1 : 0.0;
+    asm volatile("" : "+v"(t1), "+v"(g1), "+v"(dt2));
+    lin_weights_fma<MODE>(dt2, ca, cb, ce);
+    const double w2 = *pw2;
+    const double t2 = fma(cb, S_c, fma(ce, I_2, ca * S_2)) * w2;
+    c = t1 + t2;
+    g2 = in2 ? ce * w2 : 0.0;
+    asm volatile("" : "+v"(c), "+v"(g2), "+v"(next));
+}
+__device__ __forceinline__ void entry_lambda_seq(double d1, double d2, const double *pw1, const double *pw2, bool in1,
+                                                 bool in2, double S_c, double S_1, double S_2, double I_1, double I_2,
+                                                 double &c, double &g1, double &g2, double &next)
+{
+    const bool mid = ((d1 >= 5e-4) & (d1 <= 50.0)) | ((d2 >= 5e-4) & (d2 <= 50.0));
+    const bool thin = (d1 < 5e-4) | (d2 < 5e-4);
+    if (__ballot(mid) == 0ull) entry_terms_seq<0>(d1, d2, pw1, pw2, in1, in2, S_c, S_1, S_2, I_1, I_2, c, g1, g2, next);
+    else if (__ballot(thin) == 0ull) entry_terms_seq<1>(d1, d2, pw1, pw2, in1, in2, S_c, S_1, S_2, I_1, I_2, c, g1, g2, next);
+    else entry_terms_seq<2>(d1, d2, pw1, pw2, in1, in2, S_c, S_1, S_2, I_1, I_2, c, g1, g2, next);
+}
+
 // wavelength pair `idx` of a plane: 32-bit byte offset from a wave-uniform base (planes are < 4 GiB: n < 2^28),
 // so the load takes the saddr + voffset form -- one address VGPR, no 64-bit vector arithmetic
 template <typename T2>
-__device__ __forceinline__ double2 ldpair(const T2 *base, int idx)
+__device__ __forceinline__ double2 ldpair(const T2 *base, int idx, int sh)    // sh = log2(bytes per site of the block)
 {
-    const unsigned off = (unsigned)idx * (unsigned)sizeof(T2);
+    const unsigned off = (unsigned)idx << sh;
     return to_d2(*reinterpret_cast<const T2 *>(reinterpret_cast<const char *>(base) + off));
+}
+template <typename T2> struct Log2Size;
+template <> struct Log2Size<double2> { static constexpr int value = 4; };
+template <> struct Log2Size<float2> { static constexpr int value = 3; };
+
+// ---- reduction role of a patch launch: J_dir of a finished layer (NT x ppb pair elements per block) --------------
+template <typename T, int NT>
+__device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
+{
+    typedef typename Pair<T>::type T2;
+    const TileArgs &ta = pa.ta;
+    const int tid = threadIdx.x;
+    int b = blockIdx.x, r = 0;
+    if (b >= pa.red.nblk[0]) { b -= pa.red.nblk[0]; r = 1; }
+    if (b >= pa.red.nblk[r]) return;                         // padding to a multiple of 8
+    if (kDiag && (pa.dbg & 128)) return;
+    // the range's pair elements of every block are one contiguous run of the plane: walk them flat
+    const int len = pa.red.hi[r] - pa.red.lo[r];
+    const int64_t nn = ta.n;
+    const size_t total = (size_t)len * (size_t)pa.npair;
+    T2 *Jd = reinterpret_cast<T2 *>(pa.red.Jd[r]);
+    const T2 *I0 = reinterpret_cast<const T2 *>(ta.I);
+    const size_t plane = (size_t)pa.npair * (size_t)nn;
+    for (int i = 0; i < pa.red.ppb; i++) {
+        const size_t f = ((size_t)b * pa.red.ppb + i) * NT + tid;
+        if (f >= total) break;
+        int k0, lw;
+        pair_block_at((int)(f / (size_t)len), pa.npair, pa.lgB, k0, lw);
+        const size_t e = (size_t)k0 * (size_t)nn + ((size_t)pa.red.lo[r] << lw) + (f - (size_t)k0 * (size_t)len);
+        double ax = 0.0, ay = 0.0;
+        for (int j = 0; j < pa.red.count[r]; j++) {          // the reference's angle order (lambda_iteration.jl:84,102,107)
+            const int a = pa.red.angles[r][j];
+            const double2 v = to_d2(I0[(size_t)a * plane + e]);
+            ax += pa.red.w[a] * v.x;
+            ay += pa.red.w[a] * v.y;
+        }
+        Jd[e] = from_d2<T>(make_double2(ax, ay));
+    }
 }
 
 // T: storage type of S, α, I; AM: alpha mode (VRT_ALPHA_SITE, _SITE_LAM, _ANGLE_SITE_LAM); K entries per thread;
@@ -185,6 +258,9 @@ __device__ __forceinline__ double2 ldpair(const T2 *base, int idx)
 #define VRT_WPE_ATTR __attribute__((amdgpu_waves_per_eu(VRT_PATCH_WPE, VRT_PATCH_WPE)))
 #else
 #define VRT_WPE_ATTR
+#endif
+#ifndef VRT_PIPE_ATTR
+#define VRT_PIPE_ATTR
 #endif
 template <typename T, int AM, int K, int Q, int NT>
 __global__ void __launch_bounds__(NT) VRT_WPE_ATTR
@@ -198,27 +274,7 @@ k_patch_solve(PatchArgs pa)
     // only); the pair groups of an item follow each other on ONE XCD and read its entry tables
     // through that L2, and consecutive items of an XCD are neighbouring patches / angles of a patch
     if ((int)blockIdx.x < pa.red.nred) {
-        // ---- reduction role: J_dir of a finished layer (512 positions x ppb pairs per block) -----------------
-        int b = blockIdx.x, r = 0;
-        if (b >= pa.red.nblk[0]) { b -= pa.red.nblk[0]; r = 1; }
-        if (b >= pa.red.nblk[r]) return;                         // padding to a multiple of 8
-        const int chunks = (pa.red.hi[r] - pa.red.lo[r] + NT - 1) / NT;
-        const int pos = pa.red.lo[r] + (b % chunks) * NT + tid;
-        const int q0r = (b / chunks) * pa.red.ppb, q1r = min(pa.npair, q0r + pa.red.ppb);
-        if (pos >= pa.red.hi[r]) return;
-        const int64_t nn = ta.n;
-        T2 *Jd = reinterpret_cast<T2 *>(pa.red.Jd[r]);
-        for (int q = q0r; q < q1r; q++) {
-            double ax = 0.0, ay = 0.0;
-            for (int j = 0; j < pa.red.count[r]; j++) {          // the reference's angle order (lambda_iteration.jl:84,102,107)
-                const int a = pa.red.angles[r][j];
-                const double2 v = ldpair(reinterpret_cast<const T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)nn, pos);
-                ax += pa.red.w[a] * v.x;
-                ay += pa.red.w[a] * v.y;
-            }
-            const unsigned off = (unsigned)pos * (unsigned)sizeof(T2);
-            *reinterpret_cast<T2 *>(reinterpret_cast<char *>(Jd + (size_t)q * (size_t)nn) + off) = from_d2<T>(make_double2(ax, ay));
-        }
+        patch_reduce_role<T, NT>(pa);
         return;
     }
     const int bid = (int)blockIdx.x - pa.red.nred;
@@ -226,8 +282,17 @@ k_patch_solve(PatchArgs pa)
     const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
     const int item = pa.work[sj * 8 + x];
     if (item < 0) return;
-    const int qbeg = grp * pa.ppw, qend = min(pa.npair, qbeg + pa.ppw);
-    if (qbeg >= qend) return;
+    // sibling sib solves pair k0 + sib of every block [k0, k0 + 2^lw) with 2^lw > sib among blocks b0 .. b1-1: the
+    // 2^lgB siblings of an item run side by side on one XCD and use a gathered line (one site's pairs) whole
+    const int sib = grp & ((1 << pa.lgB) - 1);
+    const int nblock = pair_block_count(pa.npair, pa.lgB);
+    const int b0 = (grp >> pa.lgB) * pa.bps, b1 = min(nblock, b0 + pa.bps);
+    if (b0 >= b1) return;
+    {
+        int k0, lw;
+        pair_block_of(b0, pa.npair, pa.lgB, k0, lw);
+        if (sib >= (1 << lw)) return;                           // block widths only shrink: nothing for this sibling
+    }
     const int4 rec = pa.rec[item];
     const int2 rec2 = pa.rec2[item];
     const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
@@ -264,7 +329,23 @@ k_patch_solve(PatchArgs pa)
 #pragma unroll
         for (int qi = 0; qi < Q; qi++) ptile[qi * stride + n_ent] = make_double2(0.0, 0.0);   // the zero slot
     }
-    for (int q0 = qbeg; q0 < qend; q0 += Q) {
+    constexpr int lgT2 = Log2Size<T2>::value;
+    for (int bk = b0; bk < b1; bk += Q) {
+        // the Q pairs of this step: (element base of the block + sibling, byte shift of a site); a step past the
+        // sibling's last block repeats the previous pair and stores nothing
+        size_t qbase[Q];
+        int qsh[Q];
+        bool qok[Q];
+#pragma unroll
+        for (int qi = 0; qi < Q; qi++) {
+            int k0, lw;
+            pair_block_of(min(bk + qi, b1 - 1), pa.npair, pa.lgB, k0, lw);
+            qok[qi] = bk + qi < b1 && sib < (1 << lw);
+            if (!qok[qi] && qi > 0) { qbase[qi] = qbase[qi - 1]; qsh[qi] = qsh[qi - 1]; continue; }
+            qbase[qi] = (size_t)k0 * (size_t)n + (size_t)sib;
+            qsh[qi] = lw + lgT2;
+        }
+        if (!qok[0]) break;
         // ---- integration coefficients of the entries for pairs q0 .. q0 + Q - 1 --------------------------
         double2 c[K][Q], g1[K][Q], g2[K][Q];
 #pragma unroll
@@ -276,28 +357,32 @@ k_patch_solve(PatchArgs pa)
             // the intensity of an upwind counts when it lies in an EARLIER layer (final); an upwind in this
             // layer enters through the tile, one in a later layer reads 0 (:23): those gather the never-visited
             // site perm[n] at storage position n - 1, whose intensity is 0 in every plane
-            const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
+            int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
+            if (dbg & 16) { i1 = (int)n - 1; i2 = (int)n - 1; }
+            const int av1 = (dbg & 32) ? p : v1, av2 = (dbg & 32) ? p : v2;       // traffic split (diagnostic build)
+            const int sv1 = (dbg & 64) ? p : v1, sv2 = (dbg & 64) ? p : v2;
             const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
 #pragma unroll
             for (int qi = 0; qi < Q; qi++) {
-                const int q = min(q0 + qi, qend - 1);                      // a partial last step repeats its last pair
-                const T2 *__restrict__ S = reinterpret_cast<const T2 *>(ta.S[d]) + (size_t)q * (size_t)n;
-                const T2 *__restrict__ I = reinterpret_cast<const T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)n;
+                const int sh = qsh[qi];
+                const T2 *__restrict__ S = reinterpret_cast<const T2 *>(ta.S[d]) + qbase[qi];
+                const T2 *__restrict__ I = reinterpret_cast<const T2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n + qbase[qi];
                 // every load of the entry first (8 independent 16-byte gathers in flight), arithmetic after
                 double2 a_c, a_1, a_2;
                 if constexpr (AM == VRT_ALPHA_SITE) {                      // one opacity per site for every λ
                     const T *__restrict__ Al = reinterpret_cast<const T *>(ta.alpha[d]);
-                    const double c0 = Al[p], c1 = Al[v1], c2 = Al[v2];
+                    const double c0 = Al[p], c1 = Al[av1], c2 = Al[av2];
+                    (void)sh;
                     a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
                 } else {
                     const T2 *__restrict__ Al =
                         AM == VRT_ALPHA_SITE_LAM
-                            ? reinterpret_cast<const T2 *>(ta.alpha[d]) + (size_t)q * (size_t)n
-                            : reinterpret_cast<const T2 *>(ta.alpha_angle) + ((size_t)a * pa.npair + q) * (size_t)n;
-                    a_c = ldpair(Al, p); a_1 = ldpair(Al, v1); a_2 = ldpair(Al, v2);
+                            ? reinterpret_cast<const T2 *>(ta.alpha[d]) + qbase[qi]
+                            : reinterpret_cast<const T2 *>(ta.alpha_angle) + (size_t)a * pa.npair * (size_t)n + qbase[qi];
+                    a_c = ldpair(Al, p, sh); a_1 = ldpair(Al, av1, sh); a_2 = ldpair(Al, av2, sh);
                 }
-                const double2 S_c = ldpair(S, p), S_1 = ldpair(S, v1), S_2 = ldpair(S, v2);
-                const double2 I_1 = ldpair(I, i1), I_2 = ldpair(I, i2);
+                const double2 S_c = ldpair(S, p, sh), S_1 = ldpair(S, sv1, sh), S_2 = ldpair(S, sv2, sh);
+                const double2 I_1 = ldpair(I, i1, sh), I_2 = ldpair(I, i2, sh);
                 const double w1 = s_w1[i], w2 = s_w2[i], r1 = s_r1[i], r2 = s_r2[i];
                 const double wg1 = in1 ? w1 : 0.0, wg2 = in2 ? w2 : 0.0;
                 const double rh1 = 0.5 * r1, rh2 = 0.5 * r2;               // exact: r (α_c + α_u) / 2 = (r / 2)(α_c + α_u)
@@ -351,10 +436,9 @@ k_patch_solve(PatchArgs pa)
             if (i < own_cnt) {
 #pragma unroll
                 for (int qi = 0; qi < Q; qi++) {
-                    const int q = q0 + qi;
-                    if (q < qend && !((dbg & 8) && ptile[qi * stride + i].x != 1.2345e300)) {
-                        T2 *I = reinterpret_cast<T2 *>(ta.I) + ((size_t)a * pa.npair + q) * (size_t)n;
-                        const unsigned off = (unsigned)(own_lo + i) * (unsigned)sizeof(T2);
+                    if (qok[qi] && !((dbg & 8) && ptile[qi * stride + i].x != 1.2345e300)) {
+                        T2 *I = reinterpret_cast<T2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n + qbase[qi];
+                        const unsigned off = (unsigned)(own_lo + i) << qsh[qi];
                         *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + off) = from_d2<T>(ptile[qi * stride + i]);
                     }
                 }
@@ -363,13 +447,187 @@ k_patch_solve(PatchArgs pa)
     }
 }
 
+
+// ---- the default shape (one entry per thread, one pair at a time), software-pipelined ------------------------------
+// A workgroup's pair costs ~15 000 cycles end to end: ~6 000 waiting for the eight gathers of an entry, ~1 500 of
+// arithmetic, ~7 000 in the level loop (a barrier and an LDS round trip per level, ~18 levels on an inclined
+// direction).  Here the gathers of the NEXT pair are issued before the level loop of the current one and land
+// while it runs: their destination registers (32) are live across the loop instead of the arithmetic's
+// temporaries, so the kernel keeps its 3 workgroups per CU.
+template <typename T, int AM> struct PatchRaw {
+    typedef typename Pair<T>::type T2;
+    T2 S_c, S_1, S_2, I_1, I_2, a_c, a_1, a_2;           // AM == VRT_ALPHA_SITE: .x of the alphas only
+};
+
+template <typename T, int AM, int NT>
+__global__ void __launch_bounds__(NT) VRT_PIPE_ATTR
+k_patch_pipe(PatchArgs pa)
+{
+    typedef typename Pair<T>::type T2;
+    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
+    const TileArgs &ta = pa.ta;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < pa.red.nred) {
+        patch_reduce_role<T, NT>(pa);
+        return;
+    }
+    const int bid = (int)blockIdx.x - pa.red.nred;
+    const int x = bid & 7, rr = bid >> 3;
+    const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
+    const int item = pa.work[sj * 8 + x];
+    if (item < 0) return;
+    const int sib = grp & ((1 << pa.lgB) - 1);
+    const int nblock = pair_block_count(pa.npair, pa.lgB);
+    const int b0 = (grp >> pa.lgB) * pa.bps, b1 = min(nblock, b0 + pa.bps);
+    if (b0 >= b1) return;
+    constexpr int lgT2 = Log2Size<T2>::value;
+    const int64_t n = ta.n;
+    size_t qb;                                               // element base of the pair being loaded
+    int sh;
+    {
+        int k0, lw;
+        pair_block_of(b0, pa.npair, pa.lgB, k0, lw);
+        if (sib >= (1 << lw)) return;
+        qb = (size_t)k0 * (size_t)n + (size_t)sib;
+        sh = lw + lgT2;
+    }
+    const int4 rec = pa.rec[item];
+    const int2 rec2 = pa.rec2[item];
+    const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
+    const int nlev = rec2.x, a = rec2.y;
+    const int d = ta.angle_dir[a];
+    const int lo = ta.lay[d][pa.layer - 1], hi = ta.lay[d][pa.layer];
+    // one entry per thread: the table arrays have NT slots (compile-time LDS offsets, no address registers)
+    constexpr int CAP = NT;
+    double *s_w1 = reinterpret_cast<double *>(ptile + CAP + 1);
+    double *s_w2 = s_w1 + CAP, *s_r1 = s_w2 + CAP, *s_r2 = s_r1 + CAP;
+    int *s_pos = reinterpret_cast<int *>(s_r2 + CAP);
+    int *s_u1 = s_pos + CAP, *s_u2 = s_u1 + CAP;
+    uint32_t *s_vis = reinterpret_cast<uint32_t *>(s_u2 + CAP), *s_loc = s_vis + CAP;
+    {
+        const bool ok = tid < n_ent;
+        const int e = ent_off + (ok ? tid : n_ent - 1);
+        s_pos[tid] = pa.e_pos[e];
+        s_u1[tid] = pa.e_u1[e];
+        s_u2[tid] = pa.e_u2[e];
+        s_vis[tid] = ok ? pa.e_vis[e] : 0u;
+        const uint32_t lc = pa.e_loc[e], l1 = lc & 0xFFFFu, l2 = lc >> 16;
+        s_loc[tid] = (l1 == 0xFFFFu ? (uint32_t)n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)n_ent : l2) << 16);
+        s_w1[tid] = pa.e_w1[e]; s_w2[tid] = pa.e_w2[e]; s_r1[tid] = pa.e_r1[e]; s_r2[tid] = pa.e_r2[e];
+    }
+    if (tid == 0) ptile[n_ent] = make_double2(0.0, 0.0);     // the zero slot
+
+    const T2 *Sd = reinterpret_cast<const T2 *>(ta.S[d]);
+    const T2 *Ia = reinterpret_cast<const T2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n;
+    PatchRaw<T, AM> raw;
+    // the eight gathers of this thread's entry for the pair at element base qb (own slots of LDS: no barrier)
+    auto issue = [&]() {
+        const int p = s_pos[tid], v1 = s_u1[tid], v2 = s_u2[tid];
+        // an upwind's intensity counts when it lies in an EARLIER layer (final); otherwise the gather reads the
+        // never-visited site at storage position n - 1, whose intensity is 0 in every plane (:23)
+        const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
+        const unsigned op = (unsigned)p << sh, o1 = (unsigned)v1 << sh, o2 = (unsigned)v2 << sh;
+        auto at = [](const T2 *base, unsigned off) { return *reinterpret_cast<const T2 *>(reinterpret_cast<const char *>(base) + off); };
+        if constexpr (AM == VRT_ALPHA_SITE) {
+            const T *__restrict__ Al = reinterpret_cast<const T *>(ta.alpha[d]);
+            raw.a_c.x = Al[p]; raw.a_1.x = Al[v1]; raw.a_2.x = Al[v2];
+        } else {
+            const T2 *__restrict__ Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const T2 *>(ta.alpha[d]) + qb
+                                                                  : reinterpret_cast<const T2 *>(ta.alpha_angle) + (size_t)a * pa.npair * (size_t)n + qb;
+            raw.a_c = at(Al, op); raw.a_1 = at(Al, o1); raw.a_2 = at(Al, o2);
+        }
+        raw.S_c = at(Sd + qb, op); raw.S_1 = at(Sd + qb, o1); raw.S_2 = at(Sd + qb, o2);
+        raw.I_1 = at(Ia + qb, (unsigned)i1 << sh); raw.I_2 = at(Ia + qb, (unsigned)i2 << sh);
+    };
+    issue();
+    for (int bk = b0;; bk++) {
+        // ---- integration coefficients of the entry for the pair that has landed ---------------------------------
+        double2 c, g1, g2;
+        {
+            const int v1 = s_u1[tid], v2 = s_u2[tid];
+            const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
+            const double rh1 = 0.5 * s_r1[tid], rh2 = 0.5 * s_r2[tid];  // exact: r (α_c + α_u) / 2 = (r / 2)(α_c + α_u)
+            double2 a_c, a_1, a_2;
+            if constexpr (AM == VRT_ALPHA_SITE) {
+                a_c = make_double2((double)raw.a_c.x, (double)raw.a_c.x);
+                a_1 = make_double2((double)raw.a_1.x, (double)raw.a_1.x);
+                a_2 = make_double2((double)raw.a_2.x, (double)raw.a_2.x);
+            } else {
+                a_c = to_d2(raw.a_c); a_1 = to_d2(raw.a_1); a_2 = to_d2(raw.a_2);
+            }
+            const double2 S_c = to_d2(raw.S_c), S_1 = to_d2(raw.S_1), S_2 = to_d2(raw.S_2);
+            const double2 I_1 = to_d2(raw.I_1), I_2 = to_d2(raw.I_2);
+            // the four optical depths first (frees the six alpha registers), then one upwind of one wavelength at a time
+            const double d1x = rh1 * (a_c.x + a_1.x), d2x = rh2 * (a_c.x + a_2.x);
+            double d1y = rh1 * (a_c.y + a_1.y), d2y = rh2 * (a_c.y + a_2.y);
+            entry_lambda_seq(d1x, d2x, s_w1 + tid, s_w2 + tid, in1, in2, S_c.x, S_1.x, S_2.x, I_1.x, I_2.x, c.x, g1.x, g2.x, d1y);
+            double sink = 0.0;
+            entry_lambda_seq(d1y, d2y, s_w1 + tid, s_w2 + tid, in1, in2, S_c.y, S_1.y, S_2.y, I_1.y, I_2.y, c.y, g1.y, g2.y, sink);
+        }
+        // ---- the next pair's gathers go out now and land during the level loop ---------------------------------
+        // (compiler fence tied to the coefficients: issued before the arithmetic has consumed the landed pair, the
+        // gathers would need a second set of destination registers)
+        asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(g1.x), "+v"(g1.y), "+v"(g2.x), "+v"(g2.y) : : "memory");
+        const size_t qb_cur = qb;
+        const int sh_cur = sh;
+        bool more = false;
+        if (bk + 1 < b1) {
+            int k0, lw;
+            pair_block_of(bk + 1, pa.npair, pa.lgB, k0, lw);
+            if (sib < (1 << lw)) {
+                more = true;
+                qb = (size_t)k0 * (size_t)n + (size_t)sib;
+                sh = lw + lgT2;
+                issue();
+            }
+        }
+        asm volatile("" ::: "memory");
+        // ---- the patch's Gauss-Seidel levels on the LDS tile ------------------------------------------------------
+        uint32_t vis = s_vis[tid];
+        const uint32_t loc = s_loc[tid];
+        {
+            double z;                                                    // made here: a hoisted zero would hold four
+            asm volatile("v_mov_b64 %0, 0" : "=v"(z));                   // registers across the whole loop
+            if (tid < n_ent) ptile[tid] = make_double2(z, z);            // I = zero(S), :23
+        }
+        __syncthreads();
+        for (int t = 1; t <= nlev; t++) {
+            if ((vis & 0xFFu) == (uint32_t)t) {                          // a site's visits come at increasing levels
+                const double2 xv = ptile[loc & 0xFFFFu], yv = ptile[loc >> 16];
+                double2 r;
+                r.x = fma(g2.x, yv.x, fma(g1.x, xv.x, c.x));
+                r.y = fma(g2.y, yv.y, fma(g1.y, xv.y, c.y));
+                ptile[tid] = r;
+                vis >>= 8;
+            }
+            __syncthreads();
+        }
+        // ---- final intensities of the owned sites --------------------------------------------------------------
+        if (tid < own_cnt) {
+            T2 *I = reinterpret_cast<T2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n + qb_cur;
+            const unsigned off = (unsigned)(own_lo + tid) << sh_cur;
+            *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + off) = from_d2<T>(ptile[tid]);
+        }
+        if (!more) break;
+        __syncthreads();                                                 // the tile is rewritten by the next pair
+    }
+}
+
 // the instantiated launch shapes (entries per thread, pairs at a time, threads)
 #define VRT_PATCH_SHAPES(X) \
     X(1, 1, 256) X(1, 1, 512) X(1, 1, 1024) X(2, 1, 256) X(2, 1, 512) X(1, 2, 256) X(1, 2, 512) X(1, 2, 1024) X(2, 2, 512)
 
 template <typename T, int AM>
-static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa)
+static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa, bool pipe)
 {
+    if (pipe && K == 1 && Q == 1 && !(kDiag && pa.dbg)) {
+        switch (NT) {
+        case 256: hipLaunchKernelGGL((k_patch_pipe<T, AM, 256>), grid, dim3(256), lds, st, pa); return VRT_OK;
+        case 512: hipLaunchKernelGGL((k_patch_pipe<T, AM, 512>), grid, dim3(512), lds, st, pa); return VRT_OK;
+        case 1024: hipLaunchKernelGGL((k_patch_pipe<T, AM, 1024>), grid, dim3(1024), lds, st, pa); return VRT_OK;
+        default: break;
+        }
+    }
 #define VRT_PATCH_CASE(k, q, nt) \
     if (K == k && Q == q && NT == nt) { hipLaunchKernelGGL((k_patch_solve<T, AM, k, q, nt>), grid, dim3(nt), lds, st, pa); return VRT_OK; }
     VRT_PATCH_SHAPES(VRT_PATCH_CASE)
@@ -378,12 +636,12 @@ static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t
 }
 
 template <typename T>
-static int launch_mode(int am, int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa)
+static int launch_mode(int am, int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa, bool pipe)
 {
     switch (am) {
-    case VRT_ALPHA_SITE: return launch_shape<T, VRT_ALPHA_SITE>(K, Q, NT, grid, lds, st, pa);
-    case VRT_ALPHA_SITE_LAM: return launch_shape<T, VRT_ALPHA_SITE_LAM>(K, Q, NT, grid, lds, st, pa);
-    default: return launch_shape<T, VRT_ALPHA_ANGLE_SITE_LAM>(K, Q, NT, grid, lds, st, pa);
+    case VRT_ALPHA_SITE: return launch_shape<T, VRT_ALPHA_SITE>(K, Q, NT, grid, lds, st, pa, pipe);
+    case VRT_ALPHA_SITE_LAM: return launch_shape<T, VRT_ALPHA_SITE_LAM>(K, Q, NT, grid, lds, st, pa, pipe);
+    default: return launch_shape<T, VRT_ALPHA_ANGLE_SITE_LAM>(K, Q, NT, grid, lds, st, pa, pipe);
     }
 }
 
@@ -442,8 +700,9 @@ static void size_reduce(PatchReduce &red, int npair, int NT)
 {
     red.nred = 0;
     for (int r = 0; r < 2; r++) {
-        const int len = red.hi[r] - red.lo[r];
-        red.nblk[r] = (len > 0 && red.count[r] > 0 && red.Jd[r]) ? (len + NT - 1) / NT * ((npair + red.ppb - 1) / red.ppb) : 0;
+        const int64_t len = red.hi[r] - red.lo[r];
+        const int64_t per = (int64_t)NT * red.ppb;               // pair elements per block
+        red.nblk[r] = (len > 0 && red.count[r] > 0 && red.Jd[r]) ? (int)((len * npair + per - 1) / per) : 0;
         red.nred += red.nblk[r];
     }
     red.nred = (red.nred + 7) / 8 * 8;
@@ -466,14 +725,16 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     pa.ta = ta;
     pa.npair = npair;
     pa.layer = layer;
-    pa.ppw = Q;
-    pa.ngrp = 1;
+    pa.lgB = p->lg_pair_block;
+    pa.bps = Q;
+    pa.ngrp = 1 << pa.lgB;
     if (w1 > w0) {
-        const int64_t items = w1 - w0;                         // work-list slots (a few of them padding)
-        const int steps_all = (npair + Q - 1) / Q;             // Q pairs at a time
+        const int64_t items = (w1 - w0) << pa.lgB;             // work-list slots (a few of them padding) x siblings
+        const int nblock = pair_block_count(npair, pa.lgB);
+        const int steps_all = (nblock + Q - 1) / Q;            // Q blocks at a time
         const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(steps_all, (target_wgs + items - 1) / items));
-        pa.ppw = (steps_all + nsplit - 1) / nsplit * Q;
-        pa.ngrp = (npair + pa.ppw - 1) / pa.ppw;
+        pa.bps = (steps_all + nsplit - 1) / nsplit * Q;
+        pa.ngrp = ((nblock + pa.bps - 1) / pa.bps) << pa.lgB;
     }
     pa.stride = p->patch_cap + 1;
     pa.cap = p->patch_cap;
@@ -486,8 +747,9 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     pa.e_w1 = p->e_w1; pa.e_w2 = p->e_w2; pa.e_r1 = p->e_r1; pa.e_r2 = p->e_r2;
     const dim3 grid((unsigned)(pa.red.nred + (w1 - w0) * pa.ngrp));
     const size_t lds = (size_t)Q * (size_t)pa.stride * sizeof(double2) + (size_t)pa.cap * (4 * sizeof(double) + 5 * sizeof(int32_t));
-    const int rc = f32 ? launch_mode<float>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa)
-                       : launch_mode<double>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa);
+    const bool pipe = p->tune.patch_pipe == 1 || (p->tune.patch_pipe == 2 && f32);
+    const int rc = f32 ? launch_mode<float>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa, pipe)
+                       : launch_mode<double>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa, pipe);
     return rc;
 }
 

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <string>
 
+#include "vrt_device.h"
 #include "vrt_internal.h"
 
 namespace vrt {
@@ -89,11 +90,11 @@ constexpr double kPi = 3.14159265358979323846;
 // T2 = double2, or float2 for the fp32 VALUE path (the arithmetic stays fp64, the stored pair is rounded)
 template <typename T2>
 __global__ void __launch_bounds__(256)
-k_line_opacity(int64_t n, int nlam, int npair, const int32_t *__restrict__ store, double k0, double k1, double k2,
+k_line_opacity(int64_t n, int nlam, int npair, int lgB, const int32_t *__restrict__ store, double k0, double k1, double k2,
                const double *__restrict__ lambda, double lambda0, double c0, const double *__restrict__ velocity,
                const double *__restrict__ doppler, const double *__restrict__ gamma,
                const double *__restrict__ strength, const double *__restrict__ alpha_cont,
-               T2 *__restrict__ out /* [npair][n] */)
+               T2 *__restrict__ out /* pair planes of the plan's native layout (vrt_device.h: pair_index) */)
 {
     const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= n) return;
@@ -123,7 +124,7 @@ k_line_opacity(int64_t n, int nlam, int npair, const int32_t *__restrict__ store
         T2 o;
         o.x = (decltype(o.x))v2[0];
         o.y = (decltype(o.y))v2[1];
-        out[(size_t)q * (size_t)n + (size_t)pos] = o;
+        out[pair_index(q, pos, n, lgB, npair)] = o;
     }
 }
 
@@ -140,11 +141,11 @@ int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, doubl
         const double *k = p->k.data() + 3 * (size_t)a;
         if (f32_out)
             hipLaunchKernelGGL(k_line_opacity<float2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (int)nlam, npair,
-                               dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
+                               native_lg(p), dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
                                d_strength, d_alpha_cont, reinterpret_cast<float2 *>((float *)d_out + (size_t)a * plane));
         else
             hipLaunchKernelGGL(k_line_opacity<double2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (int)nlam, npair,
-                               dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
+                               native_lg(p), dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
                                d_strength, d_alpha_cont, reinterpret_cast<double2 *>((double *)d_out + (size_t)a * plane));
     }
     VRT_HIP_TRY(hipGetLastError());
