@@ -288,6 +288,27 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     ta.alpha_angle = nullptr;
     ta.I = p->d_I;
     ta.dbg = nullptr;
+    // a direction whose angles all advance on ONE internal stream gets its layout changes there too: the two
+    // directions' transposes then run side by side instead of one after the other (C4: 0.2 ms of 8.7)
+    hipStream_t dir_st[2] = {st, st};
+    if (steps && A > 0) {
+        const int G = std::max(1, std::min({p->tune.step_streams, 4, A}));
+        if ((rc = ensure_step_streams(p, G))) return rc;
+        bool forked = false;
+        for (int d = 0; d < 2; d++) {
+            if (!use_dir[d]) continue;
+            for (int gi = 1; gi < G; gi++) {
+                int have = 0;
+                for (int j = p->step_group_off[(size_t)gi]; j < p->step_group_off[(size_t)gi + 1]; j++)
+                    have += (p->dir_of_active[(size_t)p->h_step_angles[(size_t)j]] > 0) == (d == 0);
+                if (have != (d == 0 ? p->n_up : p->n_down)) continue;
+                if (!forked) VRT_HIP_TRY(hipEventRecord(p->step_fork, st));
+                forked = true;
+                VRT_HIP_TRY(hipStreamWaitEvent(p->step_stream[gi], p->step_fork, 0));
+                dir_st[d] = p->step_stream[gi];
+            }
+        }
+    }
     for (int d = 0; d < 2; d++) {
         const Direction &dir = d == 0 ? g->up : g->down;
         ta.lay[d] = dir.d_lay;
@@ -295,6 +316,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         ta.S[d] = nullptr;
         ta.alpha[d] = nullptr;
         if (!use_dir[d]) continue;
+        hipStream_t st = dir_st[d];                 // (shadows the caller's stream inside this loop)
         hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store, dS,
                            reinterpret_cast<T *>(p->ws_S[d]));
         ta.S[d] = p->ws_S[d];
@@ -326,8 +348,8 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         if ((rc = ensure_dev(p->ws_AA, p->ws_AA_cap, dcount((size_t)A * plane)))) return rc;
         for (int a = 0; a < A; a++) {
             const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-            hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
-                               dalpha + (size_t)a * (size_t)n * (size_t)ld,
+            hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, dir_st[p->dir_of_active[(size_t)a] > 0 ? 0 : 1],
+                               n, (int)nlam, ld, lb, dir.d_store, dalpha + (size_t)a * (size_t)n * (size_t)ld,
                                reinterpret_cast<T *>(p->ws_AA) + (size_t)a * plane);
         }
         ta.alpha_angle = p->ws_AA;

@@ -227,19 +227,28 @@ __device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
     if (b >= pa.red.nblk[0]) { b -= pa.red.nblk[0]; r = 1; }
     if (b >= pa.red.nblk[r]) return;                         // padding to a multiple of 8
     if (kDiag && (pa.dbg & 128)) return;
-    // the range's pair elements of every block are one contiguous run of the plane: walk them flat
+    // the range's pair elements of a pair block [k0, k0 + 2^lw) are one contiguous run of the plane,
+    // (hi - lo) << lw long: blocks are dealt per pair block (size_reduce counts them the same way)
     const int len = pa.red.hi[r] - pa.red.lo[r];
+    const int per = NT * pa.red.ppb;
+    const int nblock = pair_block_count(pa.npair, pa.lgB);
+    int k0 = 0, lw = 0;
+    for (int k = 0; k < nblock; k++) {
+        pair_block_of(k, pa.npair, pa.lgB, k0, lw);
+        const int cnt = (int)((((int64_t)len << lw) + per - 1) / per);
+        if (b < cnt) break;
+        b -= cnt;
+    }
     const int64_t nn = ta.n;
-    const size_t total = (size_t)len * (size_t)pa.npair;
+    const size_t run = (size_t)len << lw;
+    const size_t base = (size_t)k0 * (size_t)nn + ((size_t)pa.red.lo[r] << lw);
     T2 *Jd = reinterpret_cast<T2 *>(pa.red.Jd[r]);
     const T2 *I0 = reinterpret_cast<const T2 *>(ta.I);
     const size_t plane = (size_t)pa.npair * (size_t)nn;
     for (int i = 0; i < pa.red.ppb; i++) {
         const size_t f = ((size_t)b * pa.red.ppb + i) * NT + tid;
-        if (f >= total) break;
-        int k0, lw;
-        pair_block_at((int)(f / (size_t)len), pa.npair, pa.lgB, k0, lw);
-        const size_t e = (size_t)k0 * (size_t)nn + ((size_t)pa.red.lo[r] << lw) + (f - (size_t)k0 * (size_t)len);
+        if (f >= run) break;
+        const size_t e = base + f;
         double ax = 0.0, ay = 0.0;
         for (int j = 0; j < pa.red.count[r]; j++) {          // the reference's angle order (lambda_iteration.jl:84,102,107)
             const int a = pa.red.angles[r][j];
@@ -696,13 +705,26 @@ int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angl
 
 // one layer of one stream group
 // fills the block counts of a reduction request for NT-thread blocks
-static void size_reduce(PatchReduce &red, int npair, int NT)
+static void size_reduce(PatchReduce &red, int npair, int lgB, int NT)
 {
     red.nred = 0;
+    // elements per thread: one while the whole reduction is a fraction of a round of workgroups (a launch of a small
+    // layer lasts as long as its slowest block), four otherwise
+    int64_t total = 0;
+    for (int r = 0; r < 2; r++)
+        if (red.count[r] > 0 && red.Jd[r]) total += (int64_t)std::max(0, red.hi[r] - red.lo[r]) * npair;
+    red.ppb = total <= (int64_t)NT * 1024 ? 1 : 4;
+    const int64_t per = (int64_t)NT * red.ppb;               // pair elements per block
+    const int nblock = pair_block_count(npair, lgB);
     for (int r = 0; r < 2; r++) {
         const int64_t len = red.hi[r] - red.lo[r];
-        const int64_t per = (int64_t)NT * red.ppb;               // pair elements per block
-        red.nblk[r] = (len > 0 && red.count[r] > 0 && red.Jd[r]) ? (int)((len * npair + per - 1) / per) : 0;
+        red.nblk[r] = 0;
+        if (len > 0 && red.count[r] > 0 && red.Jd[r])
+            for (int k = 0; k < nblock; k++) {
+                int k0, lw;
+                pair_block_of(k, npair, lgB, k0, lw);
+                red.nblk[r] += (int)(((len << lw) + per - 1) / per);
+            }
         red.nred += red.nblk[r];
     }
     red.nred = (red.nred + 7) / 8 * 8;
@@ -719,7 +741,7 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     PatchArgs pa;
     if (reduce) {
         pa.red = *reduce;
-        size_reduce(pa.red, npair, p->patch_NT);
+        size_reduce(pa.red, npair, p->lg_pair_block, p->patch_NT);
     }
     if (w1 <= w0 && pa.red.nred == 0) return VRT_OK;
     pa.ta = ta;
