@@ -180,7 +180,7 @@ int vrt_plan_last_path(const vrt_plan *p);
  *   VRT_PATH = auto | levels | tiles | steps | patches
  *   VRT_PATCH_Q, VRT_PATCH_TARGET              wavelength pairs at a time / workgroups per launch of the patch kernel
  *   VRT_PATCH_K, VRT_PATCH_NT, VRT_PATCH_OWN   entries per thread, threads, owned sites per patch (creation only)
- *   VRT_PATCH_PIPE = 0 | 1 | 2                 software-pipelined patch kernel: off, on, with fp32 storage only (default)
+ *   VRT_PATCH_PIPE = 0 | 1 | 2                 software-pipelined patch kernel: off (default), on, with fp32 storage only
  *   VRT_PAIR_BLOCK = 1 | 2 | 4 | 8 | 16        wavelength pairs of a site side by side in the patch path's planes and
  *                                              in the plan's native alpha (creation only; default 1)
  *   VRT_STEP_K, VRT_STEP_SINGLE, VRT_STEP_PAIRS, VRT_STEP_XCD, VRT_STEP_STREAMS, VRT_STEP_LEVEL_MAP,

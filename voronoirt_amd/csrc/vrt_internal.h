@@ -81,8 +81,8 @@ struct Tuning {
     int pair_block = 1;           // VRT_PAIR_BLOCK: wavelength pairs of a site kept side by side in the patch path's
                                   //   storage layout, 1 / 2 / 4 / 8 / 16 (vrt_device.h; creation only: the native
                                   //   per-angle alpha of the plan is laid out with it)
-    int patch_pipe = 2;           // VRT_PATCH_PIPE: the software-pipelined kernel for the (1, 1, NT) shapes: 0 off, 1 on,
-                                  //   2 = with fp32 storage only (C5 -4 %, C3 -1 %, C4 +4 %: DESIGN.md section 5)
+    int patch_pipe = 0;           // VRT_PATCH_PIPE: the software-pipelined kernel for the (1, 1, NT) shapes: 0 off, 1 on,
+                                  //   2 = with fp32 storage only (within the noise everywhere: DESIGN.md section 5)
     int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
     int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)
 };

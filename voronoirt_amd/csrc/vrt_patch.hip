@@ -268,8 +268,8 @@ __device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
 #else
 #define VRT_WPE_ATTR
 #endif
-#ifndef VRT_PIPE_ATTR
-#define VRT_PIPE_ATTR
+#ifndef VRT_PIPE_ATTR            // the pipelined kernel: 80 VGPRs = three 512-thread workgroups per CU (no scratch at that budget)
+#define VRT_PIPE_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
 #endif
 template <typename T, int AM, int K, int Q, int NT>
 __global__ void __launch_bounds__(NT) VRT_WPE_ATTR
