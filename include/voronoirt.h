@@ -147,6 +147,9 @@ int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out);
 int64_t vrt_plan_native_alpha_count(const vrt_plan *p, int64_t nlam);
 /* pairs per block B of the plan's native layout (1, 2, 4, 8 or 16; option VRT_PAIR_BLOCK at creation) */
 int vrt_plan_native_pair_block(const vrt_plan *p);
+/* the same for the FLOAT native buffer (vrt_plan_alpha_to_native_dev_f32, vrt_line_opacity_dev_f32): at least 2,
+ * two neighbouring pairs being one 16-byte access of the fp32 kernel (option VRT_PATCH_QUAD, default on) */
+int vrt_plan_native_pair_block_f32(const vrt_plan *p);
 /* converts the caller's (nlam, n, n_angles) alpha (VRT_ALPHA_ANGLE_SITE_LAM) once, e.g. per
  * Λ-iteration when alpha changes, so that every execute of that iteration reads it in place */
 int vrt_plan_alpha_to_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dalpha,
@@ -181,6 +184,7 @@ int vrt_plan_last_path(const vrt_plan *p);
  *   VRT_PATCH_Q, VRT_PATCH_TARGET              wavelength pairs at a time / workgroups per launch of the patch kernel
  *   VRT_PATCH_K, VRT_PATCH_NT, VRT_PATCH_OWN   entries per thread, threads, owned sites per patch (creation only)
  *   VRT_PATCH_PIPE = 0 | 1 | 2                 software-pipelined patch kernel: off (default), on, with fp32 storage only
+ *   VRT_PATCH_QUAD = 0 | 1                     fp32 storage: four wavelengths per lane (creation only; default 1)
  *   VRT_PAIR_BLOCK = 1 | 2 | 4 | 8 | 16        wavelength pairs of a site side by side in the patch path's planes and
  *                                              in the plan's native alpha (creation only; default 1)
  *   VRT_STEP_K, VRT_STEP_SINGLE, VRT_STEP_PAIRS, VRT_STEP_XCD, VRT_STEP_STREAMS, VRT_STEP_LEVEL_MAP,

@@ -112,6 +112,51 @@ def test_every_patch_kernel_instantiation(grids, shape, f32, variant, monkeypatc
     plan.close()
 
 
+@pytest.mark.parametrize("pair_block", [1, 4])
+@pytest.mark.parametrize("mode", ["site", "site_lam", "angle"])
+def test_fp32_quad_kernel_equals_pair_kernel(grids, pair_block, mode, monkeypatch):
+    """fp32 storage: k_patch_quad (two neighbouring wavelength pairs per lane, 16-byte accesses, option
+    VRT_PATCH_QUAD) gives the pair kernel's J bit for bit -- 12 wavelengths = 6 pairs, in blocks of 2, 2, 2
+    (VRT_PAIR_BLOCK=1 -> 2 for floats) and 4, 2 -- and both stay within 5e-6 of the fp64 oracle; an odd pair count
+    (10 wavelengths) runs on the pair kernel."""
+    import torch
+    hs, so = grids["voronoi"]
+    n = so.n
+    w, th, ph, nq = vrt.read_quadrature("ul2n3.dat")
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setenv("VRT_PATH", "patches")
+    monkeypatch.setenv("VRT_PAIR_BLOCK", str(pair_block))
+    monkeypatch.setenv("VRT_PATCH_OWN", "120")
+    for nlam in (12, 10):
+        S, al, I0u, I0d = _case(so, nlam, 17 + nlam)
+        if mode == "site":
+            al, amode = al[:, 0].copy(), _lib.ALPHA_SITE
+        elif mode == "angle":
+            rng = np.random.default_rng(3)
+            al, amode = al[None, :, :] * rng.uniform(0.5, 2.0, (nq, 1, nlam)), _lib.ALPHA_ANGLE_SITE_LAM
+        else:
+            amode = _lib.ALPHA_SITE_LAM
+        f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+        Sd, Ad, Ud, Dd = f(S), f(al), f(I0u), f(I0d)
+        got = {}
+        for quad in (1, 0):
+            monkeypatch.setenv("VRT_PATCH_QUAD", str(quad))
+            plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
+            assert plan.native_pair_block_f32 == (max(pair_block, 2) if quad else pair_block)
+            Jd = torch.full((n, nlam), float("nan"), dtype=torch.float32, device=dev)
+            plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), amode, w, dJ=Jd.data_ptr(),
+                             dI0_up=Ud.data_ptr(), dI0_down=Dd.data_ptr(), stream=st, f32=True)
+            torch.cuda.synchronize()
+            assert plan.last_path == "patches"
+            got[quad] = Jd.cpu().numpy()
+            plan.close()
+        assert np.array_equal(got[0], got[1])
+        r = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
+        ref = orc.J_voronoi(w, th, ph, r(S), r(al), so, I0_up=r(I0u), I0_down=r(I0d), nthreads=4)
+        assert _rel(got[1].astype(np.float64), ref) < 5e-6
+
+
 def test_patches_single_solves_and_sweep_counts(grids, monkeypatch):
     """Delaunay_upII / Delaunay_downII (one problem, one wavelength) and n_sweeps 1, 2, 4 on the patch path."""
     monkeypatch.setenv("VRT_PATH", "patches")      # read when the grid creates the plans of the single solves

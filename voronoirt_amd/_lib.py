@@ -69,6 +69,7 @@ PROTOTYPES = {
     "vrt_grid_get_storage_order": (ctypes.c_int, [vp, ctypes.c_int, p_i64]),
     "vrt_plan_native_alpha_count": (c_i64, [vp, c_i64]),
     "vrt_plan_native_pair_block": (ctypes.c_int, [vp]),
+    "vrt_plan_native_pair_block_f32": (ctypes.c_int, [vp]),
     "vrt_plan_alpha_to_native_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp]),
     "vrt_line_opacity_dev": (ctypes.c_int, [vp, c_i64, p_dbl, c_dbl, c_dbl, vp, vp, vp, vp, vp, vp, vp]),
     "vrt_line_opacity_dev_f32": (ctypes.c_int, [vp, c_i64, p_dbl, c_dbl, c_dbl, vp, vp, vp, vp, vp, vp, vp]),

@@ -298,11 +298,17 @@ class FormalPlan:
         """Wavelength pairs of a site kept side by side in the native layout (include/voronoirt.h)."""
         return int(_lib.load().vrt_plan_native_pair_block(self._h))
 
+    @property
+    def native_pair_block_f32(self) -> int:
+        """The same for the float native buffer (fp32 value path)."""
+        return int(_lib.load().vrt_plan_native_pair_block_f32(self._h))
+
     def native_to_site_major(self, native, nlam: int, n_angles: int):
-        """Host helper (tests, debugging): a native per-angle buffer (numpy, any float type) ->
+        """Host helper (tests, debugging): a native per-angle buffer (numpy float64 or float32) ->
         (n_angles, n, nlam) with rows in STORAGE order of each angle's direction."""
         native = np.asarray(native)
-        n, B = self.sites.n, self.native_pair_block
+        n = self.sites.n
+        B = self.native_pair_block_f32 if native.dtype == np.float32 else self.native_pair_block
         npair = (nlam + 1) // 2
         per = native.reshape(n_angles, npair * n * 2)
         out = np.empty((n_angles, n, 2 * npair), dtype=native.dtype)

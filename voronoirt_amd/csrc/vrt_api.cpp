@@ -25,7 +25,7 @@ void tuning_from_env(Tuning &t)
     static const char *names[] = {"VRT_PATH", "VRT_STEP_K", "VRT_STEP_SINGLE", "VRT_STEP_PAIRS", "VRT_STEP_XCD",
                                   "VRT_STEP_STREAMS", "VRT_STEP_LEVEL_MAP", "VRT_STEP_GROUP_DIR", "VRT_TILE_WIDE",
                                   "VRT_TILE_PRE", "VRT_GRAPH", "VRT_PATCH_K", "VRT_PATCH_NT", "VRT_PATCH_OWN",
-                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_PIPE", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
+                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_PIPE", "VRT_PATCH_QUAD", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
                                   "VRT_TILE_DEBUG"};
     for (const char *nm : names) {
         const char *e = std::getenv(nm);
@@ -56,7 +56,7 @@ int tuning_set(Tuning &t, const char *name, const char *value, bool created)
         {"VRT_PATCH_K", &t.patch_K, 1, 8, true}, {"VRT_PATCH_NT", &t.patch_NT, 64, 1024, true},
         {"VRT_PATCH_OWN", &t.patch_own, 0, 65535, true}, {"VRT_PATCH_Q", &t.patch_Q, 1, 4, false},
         {"VRT_PATCH_TARGET", &t.patch_target, 1, 1 << 20, false}, {"VRT_PAIR_BLOCK", &t.pair_block, 1, 16, true},
-        {"VRT_PATCH_PIPE", &t.patch_pipe, 0, 2, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
+        {"VRT_PATCH_PIPE", &t.patch_pipe, 0, 2, false}, {"VRT_PATCH_QUAD", &t.patch_quad, 0, 1, true}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
         {"VRT_DEBUG_SKIP_LEVELS", &t.debug_skip_levels, 0, 1, false}, {"VRT_TILE_DEBUG", &t.tile_debug, 0, 1, false},
     };
     for (auto &o : tab)
@@ -705,7 +705,7 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_, c
         // the native layout IS the storage order of the layer paths
         // (laid out for the patch path when the grid fits it: then the steps path can only read it with one pair per block)
         if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE) {
-            const bool steps_can = steps_ok && !f32 && native_lg(p) == 0;
+            const bool steps_can = steps_ok && !f32 && native_lg(p, f32) == 0;
             if (path == 3 && !steps_can) path = 4;
             else if (path != 3 && path != 4) path = p->patch_ok ? 4 : 3;
         }
@@ -1184,7 +1184,8 @@ int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out)
     return VRT_OK;
 }
 
-int vrt_plan_native_pair_block(const vrt_plan *p) { return p ? 1 << native_lg(p) : 0; }
+int vrt_plan_native_pair_block(const vrt_plan *p) { return p ? 1 << native_lg(p, false) : 0; }
+int vrt_plan_native_pair_block_f32(const vrt_plan *p) { return p ? 1 << native_lg(p, true) : 0; }
 
 int64_t vrt_plan_native_alpha_count(const vrt_plan *p, int64_t nlam)
 {

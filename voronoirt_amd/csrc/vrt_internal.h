@@ -83,6 +83,8 @@ struct Tuning {
                                   //   per-angle alpha of the plan is laid out with it)
     int patch_pipe = 0;           // VRT_PATCH_PIPE: the software-pipelined kernel for the (1, 1, NT) shapes: 0 off, 1 on,
                                   //   2 = with fp32 storage only (within the noise everywhere: DESIGN.md section 5)
+    int patch_quad = 1;           // VRT_PATCH_QUAD: fp32 storage in blocks of >= 2 pairs, four wavelengths per lane
+                                  //   (k_patch_quad; creation only: the native float alpha is laid out with it)
     int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
     int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)
 };
@@ -339,7 +341,12 @@ int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
 int launch_sorted_tables(vrt_plan *p, int a);
 int launch_gpos(vrt_plan *p, int a);
 // log2 of the pairs per block of the plan's NATIVE per-angle alpha (and of every plane of the patch path)
-inline int native_lg(const vrt_plan *p) { return p->patch_ok ? p->lg_pair_block : 0; }
+// (fp32 storage: at least two pairs, so that k_patch_quad can take them as one 16-byte access)
+inline int native_lg(const vrt_plan *p, bool f32)
+{
+    if (!p->patch_ok) return 0;
+    return f32 && p->tune.patch_quad != 0 && p->patch_K == 1 ? std::max(p->lg_pair_block, 1) : p->lg_pair_block;
+}
 int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const void *dalpha, void *out, hipStream_t st, bool f32);
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, const void *dalpha,
                   int alpha_mode, const void *dI0_up, const void *dI0_down,

@@ -103,7 +103,7 @@ static int alpha_to_native_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dal
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
     for (int a = 0; a < p->A; a++) {
         const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-        hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2 << native_lg(p), dir.d_store,
+        hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2 << native_lg(p, sizeof(T) == 4), dir.d_store,
                            dalpha + (size_t)p->user_of_active[(size_t)a] * (size_t)n * (size_t)ld,
                            out + (size_t)a * plane);
     }
@@ -255,7 +255,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                                   p->tune.step_single == 1);
     // storage layout: wavelength pairs side by side on the layer-step path, plain planes on the
     // persistent tile path (sw_index); planes are padded to a whole number of blocks
-    const int lb = patches ? 2 << native_lg(p) : steps ? 2 : 1;
+    const int lb = patches ? 2 << native_lg(p, kF32) : steps ? 2 : 1;
     const int64_t nl_pad = lb == 1 ? nlam : (nlam + 1) / 2 * 2;
     const size_t plane = (size_t)nl_pad * (size_t)n;
     // workspaces are kept as double buffers; a plane of T needs this many doubles

@@ -33,6 +33,7 @@ struct PatchArgs {
     int lgB;                  // log2 of the pairs per block of the storage layout (vrt_device.h: pair_block_at)
     int stride;               // tile slots per pair plane (> largest entry count: + the zero slot)
     int cap;                  // entries per patch at most (K * NT): length of the LDS table arrays
+    int quad;                 // fp32 storage: k_patch_quad (two neighbouring pairs of a block per workgroup)
     int dbg;                  // timing diagnostics (-DVRT_DIAG build only, WRONG results): 1 no levels, 2 gathers ->
                               //   coalesced centre reads, 4 no weights arithmetic, 8 no stores, 16 / 32 / 64 no upwind gathers
                               //   of I / alpha / S, 128 no J reduction
@@ -622,6 +623,158 @@ k_patch_pipe(PatchArgs pa)
     }
 }
 
+
+// ---- fp32 storage, FOUR wavelengths per lane ---------------------------------------------------------------------
+// With float values a wavelength pair is an 8-byte access, and the patch kernel issues as many memory instructions
+// per wavelength as with doubles: the memory path, which bounds it, sees twice the requests
+// per byte.  In the layout with two (or more) pairs of a site side by side (pair blocks, vrt_device.h) two
+// neighbouring pairs are ONE 16-byte access: this kernel solves both at once -- eight float4 gathers per entry,
+// the four evaluations of the weights one after the other (compiler fences as in the pipelined kernel), two planes
+// of the LDS tile walked by one level loop, one float4 store.  Half the memory instructions and half the barriers
+// per wavelength.  (An odd pair count leaves a last block of one pair: the host then launches the pair kernel.)
+template <int AM, int NT>
+__global__ void __launch_bounds__(NT) VRT_PIPE_ATTR
+k_patch_quad(PatchArgs pa)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
+    const TileArgs &ta = pa.ta;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < pa.red.nred) {
+        patch_reduce_role<float, NT>(pa);
+        return;
+    }
+    const int bid = (int)blockIdx.x - pa.red.nred;
+    const int x = bid & 7, rr = bid >> 3;
+    const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
+    const int item = pa.work[sj * 8 + x];
+    if (item < 0) return;
+    // workgroup (item, sib2, split): the pairs 2 sib2, 2 sib2 + 1 of every block among blocks b0 .. b1-1
+    const int lgH = pa.lgB - 1;                              // log2 of the sibling workgroups per block
+    const int sib2 = grp & ((1 << lgH) - 1);
+    const int nblock = pair_block_count(pa.npair, pa.lgB);
+    const int b0 = (grp >> lgH) * pa.bps, b1 = min(nblock, b0 + pa.bps);
+    if (b0 >= b1) return;
+    const int64_t n = ta.n;
+    const int4 rec = pa.rec[item];
+    const int2 rec2 = pa.rec2[item];
+    const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
+    const int nlev = rec2.x, a = rec2.y;
+    const int d = ta.angle_dir[a];
+    const int lo = ta.lay[d][pa.layer - 1], hi = ta.lay[d][pa.layer];
+
+    constexpr int CAP = NT;
+    double2 *tileA = ptile, *tileB = ptile + (CAP + 1);
+    double *s_w1 = reinterpret_cast<double *>(ptile + 2 * (CAP + 1));
+    double *s_w2 = s_w1 + CAP, *s_r1 = s_w2 + CAP, *s_r2 = s_r1 + CAP;
+    int *s_pos = reinterpret_cast<int *>(s_r2 + CAP);
+    int *s_u1 = s_pos + CAP, *s_u2 = s_u1 + CAP;
+    uint32_t *s_vis = reinterpret_cast<uint32_t *>(s_u2 + CAP), *s_loc = s_vis + CAP;
+    {
+        const bool ok = tid < n_ent;
+        const int e = ent_off + (ok ? tid : n_ent - 1);
+        s_pos[tid] = pa.e_pos[e];
+        s_u1[tid] = pa.e_u1[e];
+        s_u2[tid] = pa.e_u2[e];
+        s_vis[tid] = ok ? pa.e_vis[e] : 0u;
+        const uint32_t lc = pa.e_loc[e], l1 = lc & 0xFFFFu, l2 = lc >> 16;
+        s_loc[tid] = (l1 == 0xFFFFu ? (uint32_t)n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)n_ent : l2) << 16);
+        s_w1[tid] = pa.e_w1[e]; s_w2[tid] = pa.e_w2[e]; s_r1[tid] = pa.e_r1[e]; s_r2[tid] = pa.e_r2[e];
+    }
+    if (tid == 0) {
+        tileA[n_ent] = make_double2(0.0, 0.0);               // the zero slots
+        tileB[n_ent] = make_double2(0.0, 0.0);
+    }
+    const float2 *Sd = reinterpret_cast<const float2 *>(ta.S[d]);
+    const float2 *Ia = reinterpret_cast<const float2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n;
+    for (int bk = b0; bk < b1; bk++) {
+        int k0, lw;
+        pair_block_of(bk, pa.npair, pa.lgB, k0, lw);
+        if (2 * sib2 >= (1 << lw)) break;                    // block widths only shrink (and are >= 2: even pair count)
+        const size_t qb = (size_t)k0 * (size_t)n + (size_t)(2 * sib2);
+        const int sh = lw + 3;                               // log2 bytes per site of the block
+        float4 S_c, S_1, S_2, I_1, I_2, a_c, a_1, a_2;
+        {
+            const int p = s_pos[tid], v1 = s_u1[tid], v2 = s_u2[tid];
+            const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
+            const unsigned op = (unsigned)p << sh, o1 = (unsigned)v1 << sh, o2 = (unsigned)v2 << sh;
+            const unsigned oi1 = (unsigned)i1 << sh, oi2 = (unsigned)i2 << sh;
+            auto at4 = [](const float2 *base, unsigned off) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off); };
+            const float2 *Al = nullptr;
+            if constexpr (AM == VRT_ALPHA_SITE) {
+                const float *__restrict__ A1 = reinterpret_cast<const float *>(ta.alpha[d]);
+                a_c.x = A1[p]; a_1.x = A1[v1]; a_2.x = A1[v2];
+            } else
+                Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const float2 *>(ta.alpha[d]) + qb
+                                              : reinterpret_cast<const float2 *>(ta.alpha_angle) + (size_t)a * pa.npair * (size_t)n + qb;
+            if constexpr (AM != VRT_ALPHA_SITE) { a_c = at4(Al, op); a_1 = at4(Al, o1); a_2 = at4(Al, o2); }
+            S_c = at4(Sd + qb, op); S_1 = at4(Sd + qb, o1); S_2 = at4(Sd + qb, o2);
+            I_1 = at4(Ia + qb, oi1); I_2 = at4(Ia + qb, oi2);
+            if constexpr (AM == VRT_ALPHA_SITE) {
+                a_c = make_float4(a_c.x, a_c.x, a_c.x, a_c.x);
+                a_1 = make_float4(a_1.x, a_1.x, a_1.x, a_1.x);
+                a_2 = make_float4(a_2.x, a_2.x, a_2.x, a_2.x);
+            }
+        }
+        // ---- integration coefficients of the entry, four wavelengths one after the other -------------------------
+        double2 cA, g1A, g2A, cB, g1B, g2B;
+        {
+            const int v1 = s_u1[tid], v2 = s_u2[tid];
+            const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
+            const double rh1 = 0.5 * s_r1[tid], rh2 = 0.5 * s_r2[tid];
+            const double d1x = rh1 * ((double)a_c.x + (double)a_1.x), d2x = rh2 * ((double)a_c.x + (double)a_2.x);
+            double d1y = rh1 * ((double)a_c.y + (double)a_1.y), d2y = rh2 * ((double)a_c.y + (double)a_2.y);
+            entry_lambda_seq(d1x, d2x, s_w1 + tid, s_w2 + tid, in1, in2, (double)S_c.x, (double)S_1.x, (double)S_2.x,
+                             (double)I_1.x, (double)I_2.x, cA.x, g1A.x, g2A.x, d1y);
+            double d1z = rh1 * ((double)a_c.z + (double)a_1.z);
+            entry_lambda_seq(d1y, d2y, s_w1 + tid, s_w2 + tid, in1, in2, (double)S_c.y, (double)S_1.y, (double)S_2.y,
+                             (double)I_1.y, (double)I_2.y, cA.y, g1A.y, g2A.y, d1z);
+            const double d2z = rh2 * ((double)a_c.z + (double)a_2.z);
+            double d1w = rh1 * ((double)a_c.w + (double)a_1.w);
+            entry_lambda_seq(d1z, d2z, s_w1 + tid, s_w2 + tid, in1, in2, (double)S_c.z, (double)S_1.z, (double)S_2.z,
+                             (double)I_1.z, (double)I_2.z, cB.x, g1B.x, g2B.x, d1w);
+            const double d2w = rh2 * ((double)a_c.w + (double)a_2.w);
+            double sink = 0.0;
+            entry_lambda_seq(d1w, d2w, s_w1 + tid, s_w2 + tid, in1, in2, (double)S_c.w, (double)S_1.w, (double)S_2.w,
+                             (double)I_1.w, (double)I_2.w, cB.y, g1B.y, g2B.y, sink);
+        }
+        // ---- the patch's Gauss-Seidel levels, both pairs per level -------------------------------------------------
+        uint32_t vis = s_vis[tid];
+        const uint32_t loc = s_loc[tid];
+        {
+            double z;
+            asm volatile("v_mov_b64 %0, 0" : "=v"(z));
+            if (tid < n_ent) {
+                tileA[tid] = make_double2(z, z);             // I = zero(S), :23
+                tileB[tid] = make_double2(z, z);
+            }
+        }
+        __syncthreads();
+        for (int t = 1; t <= nlev; t++) {
+            if ((vis & 0xFFu) == (uint32_t)t) {
+                const uint32_t l1 = loc & 0xFFFFu, l2 = loc >> 16;
+                const double2 xa = tileA[l1], ya = tileA[l2], xb = tileB[l1], yb = tileB[l2];
+                double2 ra, rb;
+                ra.x = fma(g2A.x, ya.x, fma(g1A.x, xa.x, cA.x));
+                ra.y = fma(g2A.y, ya.y, fma(g1A.y, xa.y, cA.y));
+                rb.x = fma(g2B.x, yb.x, fma(g1B.x, xb.x, cB.x));
+                rb.y = fma(g2B.y, yb.y, fma(g1B.y, xb.y, cB.y));
+                tileA[tid] = ra;
+                tileB[tid] = rb;
+                vis >>= 8;
+            }
+            __syncthreads();
+        }
+        // ---- final intensities of the owned sites ---------------------------------------------------------------
+        if (tid < own_cnt) {
+            float2 *I = reinterpret_cast<float2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n + qb;
+            char *dst = reinterpret_cast<char *>(I) + ((unsigned)(own_lo + tid) << sh);
+            const double2 ra = tileA[tid], rb = tileB[tid];
+            *reinterpret_cast<float4 *>(dst) = make_float4((float)ra.x, (float)ra.y, (float)rb.x, (float)rb.y);
+        }
+        __syncthreads();                                     // the tiles are rewritten by the next block
+    }
+}
+
 // the instantiated launch shapes (entries per thread, pairs at a time, threads)
 #define VRT_PATCH_SHAPES(X) \
     X(1, 1, 256) X(1, 1, 512) X(1, 1, 1024) X(2, 1, 256) X(2, 1, 512) X(1, 2, 256) X(1, 2, 512) X(1, 2, 1024) X(2, 2, 512)
@@ -629,6 +782,16 @@ k_patch_pipe(PatchArgs pa)
 template <typename T, int AM>
 static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa, bool pipe)
 {
+    if constexpr (sizeof(T) == 4) {
+        if (pa.quad) {
+            switch (NT) {
+            case 256: hipLaunchKernelGGL((k_patch_quad<AM, 256>), grid, dim3(256), lds, st, pa); return VRT_OK;
+            case 512: hipLaunchKernelGGL((k_patch_quad<AM, 512>), grid, dim3(512), lds, st, pa); return VRT_OK;
+            case 1024: hipLaunchKernelGGL((k_patch_quad<AM, 1024>), grid, dim3(1024), lds, st, pa); return VRT_OK;
+            default: break;
+            }
+        }
+    }
     if (pipe && K == 1 && Q == 1 && !(kDiag && pa.dbg)) {
         switch (NT) {
         case 256: hipLaunchKernelGGL((k_patch_pipe<T, AM, 256>), grid, dim3(256), lds, st, pa); return VRT_OK;
@@ -741,22 +904,27 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     PatchArgs pa;
     if (reduce) {
         pa.red = *reduce;
-        size_reduce(pa.red, npair, p->lg_pair_block, p->patch_NT);
+        size_reduce(pa.red, npair, native_lg(p, f32), p->patch_NT);
     }
     if (w1 <= w0 && pa.red.nred == 0) return VRT_OK;
     pa.ta = ta;
     pa.npair = npair;
     pa.layer = layer;
-    pa.lgB = p->lg_pair_block;
+    pa.lgB = native_lg(p, f32);
+    // fp32 storage: two neighbouring pairs of a block per workgroup as 16-byte accesses (k_patch_quad) when the pair
+    // count is even (every block then holds >= 2 pairs and every plane starts 16-byte aligned; else the pair kernel)
+    pa.quad = (f32 && pa.lgB >= 1 && p->patch_K == 1 && p->tune.patch_quad != 0 && (npair & 1) == 0) ? 1 : 0;
+    if (pa.quad) Q = 1;
+    const int lgS = pa.lgB - pa.quad;                          // log2 of the sibling workgroups per block
     pa.bps = Q;
-    pa.ngrp = 1 << pa.lgB;
+    pa.ngrp = 1 << lgS;
     if (w1 > w0) {
-        const int64_t items = (w1 - w0) << pa.lgB;             // work-list slots (a few of them padding) x siblings
+        const int64_t items = (w1 - w0) << lgS;                // work-list slots (a few of them padding) x siblings
         const int nblock = pair_block_count(npair, pa.lgB);
         const int steps_all = (nblock + Q - 1) / Q;            // Q blocks at a time
         const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(steps_all, (target_wgs + items - 1) / items));
         pa.bps = (steps_all + nsplit - 1) / nsplit * Q;
-        pa.ngrp = ((nblock + pa.bps - 1) / pa.bps) << pa.lgB;
+        pa.ngrp = ((nblock + pa.bps - 1) / pa.bps) << lgS;
     }
     pa.stride = p->patch_cap + 1;
     pa.cap = p->patch_cap;
@@ -768,7 +936,7 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     pa.e_vis = p->e_vis; pa.e_loc = p->e_loc;
     pa.e_w1 = p->e_w1; pa.e_w2 = p->e_w2; pa.e_r1 = p->e_r1; pa.e_r2 = p->e_r2;
     const dim3 grid((unsigned)(pa.red.nred + (w1 - w0) * pa.ngrp));
-    const size_t lds = (size_t)Q * (size_t)pa.stride * sizeof(double2) + (size_t)pa.cap * (4 * sizeof(double) + 5 * sizeof(int32_t));
+    const size_t lds = (size_t)(pa.quad ? 2 : Q) * (size_t)pa.stride * sizeof(double2) + (size_t)pa.cap * (4 * sizeof(double) + 5 * sizeof(int32_t));
     const bool pipe = p->tune.patch_pipe == 1 || (p->tune.patch_pipe == 2 && f32);
     const int rc = f32 ? launch_mode<float>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa, pipe)
                        : launch_mode<double>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa, pipe);

@@ -141,11 +141,11 @@ int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, doubl
         const double *k = p->k.data() + 3 * (size_t)a;
         if (f32_out)
             hipLaunchKernelGGL(k_line_opacity<float2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (int)nlam, npair,
-                               native_lg(p), dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
+                               native_lg(p, f32_out), dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
                                d_strength, d_alpha_cont, reinterpret_cast<float2 *>((float *)d_out + (size_t)a * plane));
         else
             hipLaunchKernelGGL(k_line_opacity<double2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (int)nlam, npair,
-                               native_lg(p), dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
+                               native_lg(p, f32_out), dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
                                d_strength, d_alpha_cont, reinterpret_cast<double2 *>((double *)d_out + (size_t)a * plane));
     }
     VRT_HIP_TRY(hipGetLastError());
