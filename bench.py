@@ -375,7 +375,9 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         "kernel": {"levels": "k_sweep_level (one launch per dependency level)",
                    "steps": "k_step_coeffs + k_step_levels (two launches per BFS layer)",
                    "tiles": "k_sweep_tiles (one persistent launch)",
-                   "patches": "k_patch_solve (one fused launch per BFS layer and direction: coefficients + "
+                   "patches": ("k_patch_quad (fp32 storage: two wavelength pairs per lane; " if f32 and ((nlam + 1) // 2) % 2 == 0
+                               else "k_patch_solve (") +
+                              "one fused launch per BFS layer and direction: coefficients + "
                               "Gauss-Seidel levels of every patch, J reduction of the previous layer riding along)"
                    }.get(plan.last_path, plan.last_path),
         "path": plan.last_path, "launches_per_step": launches,
