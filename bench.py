@@ -212,11 +212,11 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     stream = torch.cuda.current_stream().cuda_stream
 
     alpha_native = None
-    if per_angle and not f32 and args.alpha_layout == "native" and args.angle_groups == 1:
+    if per_angle and args.alpha_layout == "native" and args.angle_groups == 1:
         # one-time layout change outside the timed region: per-angle alpha is produced once per
         # Λ-iteration (lambda_iteration.jl:89-96) -- by vrt_line_opacity_dev directly in this layout
-        alpha_native = torch.empty(plan.native_alpha_count(nlam), device=dev, dtype=torch.float64)
-        plan.alpha_to_native_dev(nlam, nlam, alpha.data_ptr(), alpha_native.data_ptr(), stream=stream)
+        alpha_native = torch.empty(plan.native_alpha_count(nlam), device=dev, dtype=torch.float32 if f32 else torch.float64)
+        plan.alpha_to_native_dev(nlam, nlam, alpha.data_ptr(), alpha_native.data_ptr(), stream=stream, f32=f32)
         torch.cuda.synchronize()
 
     groups = None
@@ -255,7 +255,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
             return
         if alpha_native is not None:
             plan.execute_dev(nlam, nlam, S.data_ptr(), alpha_native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE,
-                             w_mine, dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream)
+                             w_mine, dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
         else:
             plan.execute_dev(nlam, nlam, S.data_ptr(), alpha.data_ptr(), alpha_mode, w_mine,
                              dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
