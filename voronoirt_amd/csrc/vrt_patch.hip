@@ -34,6 +34,7 @@ struct PatchArgs {
     int stride;               // tile slots per pair plane (> largest entry count: + the zero slot)
     int cap;                  // entries per patch at most (K * NT): length of the LDS table arrays
     int quad;                 // fp32 storage: k_patch_quad (two neighbouring pairs of a block per workgroup)
+    int duo;                  // fp64 storage: k_patch_duo (two pairs per step, one level loop)
     int dbg;                  // timing diagnostics (-DVRT_DIAG build only, WRONG results): 1 no levels, 2 gathers ->
                               //   coalesced centre reads, 4 no weights arithmetic, 8 no stores, 16 / 32 / 64 no upwind gathers
                               //   of I / alpha / S, 128 no J reduction
@@ -775,6 +776,145 @@ k_patch_quad(PatchArgs pa)
     }
 }
 
+
+// ---- fp64 storage, TWO wavelength pairs per workgroup step ----------------------------------------------------------
+// The level loop (a barrier, an LDS round trip and a handful of scalar / vector instructions per level and wave,
+// ~18 levels on an inclined direction) costs about as many instruction issues as the weights of a pair.  Here two
+// pairs share it: the gathers and the arithmetic of pair A, then those of pair B (so that only one set of eight
+// landed gathers is live at a time: 80 registers hold), then ONE level loop over both tile planes.
+template <int AM, int NT>
+__global__ void __launch_bounds__(NT) VRT_PIPE_ATTR
+k_patch_duo(PatchArgs pa)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
+    const TileArgs &ta = pa.ta;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < pa.red.nred) {
+        patch_reduce_role<double, NT>(pa);
+        return;
+    }
+    const int bid = (int)blockIdx.x - pa.red.nred;
+    const int x = bid & 7, rr = bid >> 3;
+    const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
+    const int item = pa.work[sj * 8 + x];
+    if (item < 0) return;
+    const int sib = grp & ((1 << pa.lgB) - 1);
+    const int nblock = pair_block_count(pa.npair, pa.lgB);
+    const int b0 = (grp >> pa.lgB) * pa.bps, b1 = min(nblock, b0 + pa.bps);
+    if (b0 >= b1) return;
+    const int64_t n = ta.n;
+    const int4 rec = pa.rec[item];
+    const int2 rec2 = pa.rec2[item];
+    const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
+    const int nlev = rec2.x, a = rec2.y;
+    const int d = ta.angle_dir[a];
+    const int lo = ta.lay[d][pa.layer - 1], hi = ta.lay[d][pa.layer];
+
+    constexpr int CAP = NT;
+    double2 *tileA = ptile, *tileB = ptile + (CAP + 1);
+    double *s_w1 = reinterpret_cast<double *>(ptile + 2 * (CAP + 1));
+    double *s_w2 = s_w1 + CAP, *s_r1 = s_w2 + CAP, *s_r2 = s_r1 + CAP;
+    int *s_pos = reinterpret_cast<int *>(s_r2 + CAP);
+    int *s_u1 = s_pos + CAP, *s_u2 = s_u1 + CAP;
+    uint32_t *s_vis = reinterpret_cast<uint32_t *>(s_u2 + CAP), *s_loc = s_vis + CAP;
+    {
+        const bool ok = tid < n_ent;
+        const int e = ent_off + (ok ? tid : n_ent - 1);
+        s_pos[tid] = pa.e_pos[e];
+        s_u1[tid] = pa.e_u1[e];
+        s_u2[tid] = pa.e_u2[e];
+        s_vis[tid] = ok ? pa.e_vis[e] : 0u;
+        const uint32_t lc = pa.e_loc[e], l1 = lc & 0xFFFFu, l2 = lc >> 16;
+        s_loc[tid] = (l1 == 0xFFFFu ? (uint32_t)n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)n_ent : l2) << 16);
+        s_w1[tid] = pa.e_w1[e]; s_w2[tid] = pa.e_w2[e]; s_r1[tid] = pa.e_r1[e]; s_r2[tid] = pa.e_r2[e];
+    }
+    if (tid == 0) {
+        tileA[n_ent] = make_double2(0.0, 0.0);               // the zero slots
+        tileB[n_ent] = make_double2(0.0, 0.0);
+    }
+    const double2 *Sd = reinterpret_cast<const double2 *>(ta.S[d]);
+    const double2 *Ia = reinterpret_cast<const double2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n;
+    // gathers + weights of the entry for the pair at element base qb -> (c, g1, g2)
+    auto coefficients = [&](size_t qb, int sh, double2 &c, double2 &g1, double2 &g2) {
+        const int p = s_pos[tid], v1 = s_u1[tid], v2 = s_u2[tid];
+        const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
+        const unsigned op = (unsigned)p << sh, o1 = (unsigned)v1 << sh, o2 = (unsigned)v2 << sh;
+        auto at = [](const double2 *base, unsigned off) { return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + off); };
+        double2 a_c, a_1, a_2;
+        if constexpr (AM == VRT_ALPHA_SITE) {
+            const double *__restrict__ A1 = ta.alpha[d];
+            const double c0 = A1[p], c1 = A1[v1], c2 = A1[v2];
+            a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
+        } else {
+            const double2 *Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const double2 *>(ta.alpha[d]) + qb
+                                                         : reinterpret_cast<const double2 *>(ta.alpha_angle) + (size_t)a * pa.npair * (size_t)n + qb;
+            a_c = at(Al, op); a_1 = at(Al, o1); a_2 = at(Al, o2);
+        }
+        const double2 S_c = at(Sd + qb, op), S_1 = at(Sd + qb, o1), S_2 = at(Sd + qb, o2);
+        const double2 I_1 = at(Ia + qb, (unsigned)i1 << sh), I_2 = at(Ia + qb, (unsigned)i2 << sh);
+        const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
+        const double rh1 = 0.5 * s_r1[tid], rh2 = 0.5 * s_r2[tid];
+        const double d1x = rh1 * (a_c.x + a_1.x), d2x = rh2 * (a_c.x + a_2.x);
+        double d1y = rh1 * (a_c.y + a_1.y), d2y = rh2 * (a_c.y + a_2.y);
+        entry_lambda_seq(d1x, d2x, s_w1 + tid, s_w2 + tid, in1, in2, S_c.x, S_1.x, S_2.x, I_1.x, I_2.x, c.x, g1.x, g2.x, d1y);
+        double sink = 0.0;
+        entry_lambda_seq(d1y, d2y, s_w1 + tid, s_w2 + tid, in1, in2, S_c.y, S_1.y, S_2.y, I_1.y, I_2.y, c.y, g1.y, g2.y, sink);
+    };
+    for (int bk = b0; bk < b1; bk += 2) {
+        int k0, lw;
+        pair_block_of(bk, pa.npair, pa.lgB, k0, lw);
+        if (sib >= (1 << lw)) break;                         // block widths only shrink
+        const size_t qbA = (size_t)k0 * (size_t)n + (size_t)sib;
+        const int shA = lw + 4;
+        bool haveB = bk + 1 < b1;
+        size_t qbB = qbA;
+        int shB = shA;
+        if (haveB) {
+            pair_block_of(bk + 1, pa.npair, pa.lgB, k0, lw);
+            haveB = sib < (1 << lw);
+            if (haveB) { qbB = (size_t)k0 * (size_t)n + (size_t)sib; shB = lw + 4; }
+        }
+        double2 cA, g1A, g2A, cB, g1B, g2B;
+        coefficients(qbA, shA, cA, g1A, g2A);
+        asm volatile("" : "+v"(cA.x), "+v"(cA.y), "+v"(g1A.x), "+v"(g1A.y), "+v"(g2A.x), "+v"(g2A.y) : : "memory");
+        if (haveB) coefficients(qbB, shB, cB, g1B, g2B);
+        else { cB = make_double2(0.0, 0.0); g1B = cB; g2B = cB; }
+        // ---- the patch's Gauss-Seidel levels, both pairs per level -------------------------------------------------
+        uint32_t vis = s_vis[tid];
+        const uint32_t loc = s_loc[tid];
+        {
+            double z;
+            asm volatile("v_mov_b64 %0, 0" : "=v"(z));
+            if (tid < n_ent) {
+                tileA[tid] = make_double2(z, z);             // I = zero(S), :23
+                tileB[tid] = make_double2(z, z);
+            }
+        }
+        __syncthreads();
+        for (int t = 1; t <= nlev; t++) {
+            if ((vis & 0xFFu) == (uint32_t)t) {
+                const uint32_t l1 = loc & 0xFFFFu, l2 = loc >> 16;
+                const double2 xa = tileA[l1], ya = tileA[l2], xb = tileB[l1], yb = tileB[l2];
+                double2 ra, rb;
+                ra.x = fma(g2A.x, ya.x, fma(g1A.x, xa.x, cA.x));
+                ra.y = fma(g2A.y, ya.y, fma(g1A.y, xa.y, cA.y));
+                rb.x = fma(g2B.x, yb.x, fma(g1B.x, xb.x, cB.x));
+                rb.y = fma(g2B.y, yb.y, fma(g1B.y, xb.y, cB.y));
+                tileA[tid] = ra;
+                tileB[tid] = rb;
+                vis >>= 8;
+            }
+            __syncthreads();
+        }
+        if (tid < own_cnt) {
+            double2 *I = reinterpret_cast<double2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n;
+            *reinterpret_cast<double2 *>(reinterpret_cast<char *>(I + qbA) + ((unsigned)(own_lo + tid) << shA)) = tileA[tid];
+            if (haveB) *reinterpret_cast<double2 *>(reinterpret_cast<char *>(I + qbB) + ((unsigned)(own_lo + tid) << shB)) = tileB[tid];
+        }
+        __syncthreads();                                     // the tiles are rewritten by the next step
+    }
+}
+
 // the instantiated launch shapes (entries per thread, pairs at a time, threads)
 #define VRT_PATCH_SHAPES(X) \
     X(1, 1, 256) X(1, 1, 512) X(1, 1, 1024) X(2, 1, 256) X(2, 1, 512) X(1, 2, 256) X(1, 2, 512) X(1, 2, 1024) X(2, 2, 512)
@@ -788,6 +928,16 @@ static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t
             case 256: hipLaunchKernelGGL((k_patch_quad<AM, 256>), grid, dim3(256), lds, st, pa); return VRT_OK;
             case 512: hipLaunchKernelGGL((k_patch_quad<AM, 512>), grid, dim3(512), lds, st, pa); return VRT_OK;
             case 1024: hipLaunchKernelGGL((k_patch_quad<AM, 1024>), grid, dim3(1024), lds, st, pa); return VRT_OK;
+            default: break;
+            }
+        }
+    }
+    if constexpr (sizeof(T) == 8) {
+        if (pa.duo && K == 1 && Q == 2 && !(kDiag && pa.dbg)) {
+            switch (NT) {
+            case 256: hipLaunchKernelGGL((k_patch_duo<AM, 256>), grid, dim3(256), lds, st, pa); return VRT_OK;
+            case 512: hipLaunchKernelGGL((k_patch_duo<AM, 512>), grid, dim3(512), lds, st, pa); return VRT_OK;
+            case 1024: hipLaunchKernelGGL((k_patch_duo<AM, 1024>), grid, dim3(1024), lds, st, pa); return VRT_OK;
             default: break;
             }
         }
@@ -915,6 +1065,8 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     // count is even (every block then holds >= 2 pairs and every plane starts 16-byte aligned; else the pair kernel)
     pa.quad = (f32 && pa.lgB >= 1 && p->patch_K == 1 && p->tune.patch_quad != 0 && (npair & 1) == 0) ? 1 : 0;
     if (pa.quad) Q = 1;
+    pa.duo = (!f32 && p->tune.patch_duo != 0 && p->patch_K == 1 && Q == 1 && npair >= 2) ? 1 : 0;
+    if (pa.duo) Q = 2;
     const int lgS = pa.lgB - pa.quad;                          // log2 of the sibling workgroups per block
     pa.bps = Q;
     pa.ngrp = 1 << lgS;
