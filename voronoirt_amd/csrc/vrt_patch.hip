@@ -29,7 +29,7 @@ struct PatchArgs {
     int npair;                // ceil(nlam / 2)
     int layer;                // 1-based BFS layer being solved
     int ngrp;                 // workgroups per work item = siblings (1 << lgB) x splits
-    int bps;                  // pair blocks per split: a workgroup walks ONE pair (its sibling number) of bps blocks
+    int nsplit, Q;            // the pair blocks are dealt to nsplit workgroups per sibling in steps of Q blocks (split_blocks)
     int lgB;                  // log2 of the pairs per block of the storage layout (vrt_device.h: pair_block_at)
     int stride;               // tile slots per pair plane (> largest entry count: + the zero slot)
     int cap;                  // entries per patch at most (K * NT): length of the LDS table arrays
@@ -218,6 +218,17 @@ template <typename T2> struct Log2Size;
 template <> struct Log2Size<double2> { static constexpr int value = 4; };
 template <> struct Log2Size<float2> { static constexpr int value = 3; };
 
+// blocks [b0, b1) of split number `split`: the steps (Q blocks each) are dealt evenly, the first (steps % nsplit)
+// splits taking one more (26 pairs over 5 splits: 6, 5, 5, 5, 5 -- not 6, 6, 6, 6, 2)
+__device__ __forceinline__ void split_blocks(const PatchArgs &pa, int split, int nblock, int &b0, int &b1)
+{
+    const int nstep = (nblock + pa.Q - 1) / pa.Q;
+    const int base = nstep / pa.nsplit, rem = nstep - base * pa.nsplit;
+    const int s0 = split * base + min(split, rem), s1 = s0 + base + (split < rem ? 1 : 0);
+    b0 = s0 * pa.Q;
+    b1 = min(nblock, s1 * pa.Q);
+}
+
 // ---- reduction role of a patch launch: J_dir of a finished layer (NT x ppb pair elements per block) --------------
 template <typename T, int NT>
 __device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
@@ -297,7 +308,8 @@ k_patch_solve(PatchArgs pa)
     // 2^lgB siblings of an item run side by side on one XCD and use a gathered line (one site's pairs) whole
     const int sib = grp & ((1 << pa.lgB) - 1);
     const int nblock = pair_block_count(pa.npair, pa.lgB);
-    const int b0 = (grp >> pa.lgB) * pa.bps, b1 = min(nblock, b0 + pa.bps);
+    int b0, b1;
+    split_blocks(pa, grp >> pa.lgB, nblock, b0, b1);
     if (b0 >= b1) return;
     {
         int k0, lw;
@@ -489,7 +501,8 @@ k_patch_pipe(PatchArgs pa)
     if (item < 0) return;
     const int sib = grp & ((1 << pa.lgB) - 1);
     const int nblock = pair_block_count(pa.npair, pa.lgB);
-    const int b0 = (grp >> pa.lgB) * pa.bps, b1 = min(nblock, b0 + pa.bps);
+    int b0, b1;
+    split_blocks(pa, grp >> pa.lgB, nblock, b0, b1);
     if (b0 >= b1) return;
     constexpr int lgT2 = Log2Size<T2>::value;
     const int64_t n = ta.n;
@@ -653,7 +666,8 @@ k_patch_quad(PatchArgs pa)
     const int lgH = pa.lgB - 1;                              // log2 of the sibling workgroups per block
     const int sib2 = grp & ((1 << lgH) - 1);
     const int nblock = pair_block_count(pa.npair, pa.lgB);
-    const int b0 = (grp >> lgH) * pa.bps, b1 = min(nblock, b0 + pa.bps);
+    int b0, b1;
+    split_blocks(pa, grp >> lgH, nblock, b0, b1);
     if (b0 >= b1) return;
     const int64_t n = ta.n;
     const int4 rec = pa.rec[item];
@@ -800,7 +814,8 @@ k_patch_duo(PatchArgs pa)
     if (item < 0) return;
     const int sib = grp & ((1 << pa.lgB) - 1);
     const int nblock = pair_block_count(pa.npair, pa.lgB);
-    const int b0 = (grp >> pa.lgB) * pa.bps, b1 = min(nblock, b0 + pa.bps);
+    int b0, b1;
+    split_blocks(pa, grp >> pa.lgB, nblock, b0, b1);
     if (b0 >= b1) return;
     const int64_t n = ta.n;
     const int4 rec = pa.rec[item];
@@ -1068,15 +1083,16 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     pa.duo = (!f32 && p->tune.patch_duo != 0 && p->patch_K == 1 && Q == 1 && npair >= 2) ? 1 : 0;
     if (pa.duo) Q = 2;
     const int lgS = pa.lgB - pa.quad;                          // log2 of the sibling workgroups per block
-    pa.bps = Q;
+    pa.Q = Q;
+    pa.nsplit = 1;
     pa.ngrp = 1 << lgS;
     if (w1 > w0) {
         const int64_t items = (w1 - w0) << lgS;                // work-list slots (a few of them padding) x siblings
         const int nblock = pair_block_count(npair, pa.lgB);
         const int steps_all = (nblock + Q - 1) / Q;            // Q blocks at a time
         const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(steps_all, (target_wgs + items - 1) / items));
-        pa.bps = (steps_all + nsplit - 1) / nsplit * Q;
-        pa.ngrp = ((nblock + pa.bps - 1) / pa.bps) << lgS;
+        pa.nsplit = nsplit;
+        pa.ngrp = nsplit << lgS;
     }
     pa.stride = p->patch_cap + 1;
     pa.cap = p->patch_cap;
