@@ -471,6 +471,64 @@ k_patch_solve(PatchArgs pa)
 }
 
 
+// ---- what the one-entry-per-thread kernels (k_patch_pipe, k_patch_quad, k_patch_duo) share ----------------------------
+// the work of this workgroup: patch, sibling number inside a pair block, blocks [b0, b1), the patch's record
+struct PatchItem {
+    int sib, b0, b1;
+    int ent_off, n_ent, own_lo, own_cnt, nlev, a, d, lo, hi;
+};
+// lgS: log2 of the sibling workgroups per pair block (lgB, or lgB - 1 when a workgroup takes two pairs of a block);
+// false: a padding slot, or nothing of the item for this workgroup
+__device__ __forceinline__ bool patch_item(const PatchArgs &pa, int lgS, PatchItem &it)
+{
+    const int bid = (int)blockIdx.x - pa.red.nred;
+    const int x = bid & 7, rr = bid >> 3;
+    const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
+    const int item = pa.work[sj * 8 + x];
+    if (item < 0) return false;
+    it.sib = grp & ((1 << lgS) - 1);
+    split_blocks(pa, grp >> lgS, pair_block_count(pa.npair, pa.lgB), it.b0, it.b1);
+    if (it.b0 >= it.b1) return false;
+    const int4 rec = pa.rec[item];
+    const int2 rec2 = pa.rec2[item];
+    it.ent_off = rec.x; it.n_ent = rec.y; it.own_lo = rec.z; it.own_cnt = rec.w;
+    it.nlev = rec2.x; it.a = rec2.y;
+    it.d = pa.ta.angle_dir[it.a];
+    it.lo = pa.ta.lay[it.d][pa.layer - 1];
+    it.hi = pa.ta.lay[it.d][pa.layer];
+    return true;
+}
+// the patch's entry table in LDS behind `planes` tile planes of CAP + 1 slots: every thread parks the entry it owns
+// in slots only it ever reads (a register file extension: no barrier, no bank conflict; compile-time offsets)
+template <int CAP>
+struct EntryTable {
+    double *w1, *w2, *r1, *r2;
+    int *pos, *u1, *u2;
+    uint32_t *vis, *loc;
+    __device__ __forceinline__ EntryTable(double2 *tiles, int planes)
+    {
+        w1 = reinterpret_cast<double *>(tiles + planes * (CAP + 1));
+        w2 = w1 + CAP; r1 = w2 + CAP; r2 = r1 + CAP;
+        pos = reinterpret_cast<int *>(r2 + CAP);
+        u1 = pos + CAP; u2 = u1 + CAP;
+        vis = reinterpret_cast<uint32_t *>(u2 + CAP);
+        loc = vis + CAP;
+    }
+    __device__ __forceinline__ void park(const PatchArgs &pa, const PatchItem &it, int tid) const
+    {
+        const bool ok = tid < it.n_ent;
+        const int e = it.ent_off + (ok ? tid : it.n_ent - 1);
+        pos[tid] = pa.e_pos[e];
+        u1[tid] = pa.e_u1[e];
+        u2[tid] = pa.e_u2[e];
+        vis[tid] = ok ? pa.e_vis[e] : 0u;
+        // an upwind outside the cone reads the zero slot (coupling x a finite 0)
+        const uint32_t lc = pa.e_loc[e], l1 = lc & 0xFFFFu, l2 = lc >> 16;
+        loc[tid] = (l1 == 0xFFFFu ? (uint32_t)it.n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)it.n_ent : l2) << 16);
+        w1[tid] = pa.e_w1[e]; w2[tid] = pa.e_w2[e]; r1[tid] = pa.e_r1[e]; r2[tid] = pa.e_r2[e];
+    }
+};
+
 // ---- the default shape (one entry per thread, one pair at a time), software-pipelined ------------------------------
 // A workgroup's pair costs ~15 000 cycles end to end: ~6 000 waiting for the eight gathers of an entry, ~1 500 of
 // arithmetic, ~7 000 in the level loop (a barrier and an LDS round trip per level, ~18 levels on an inclined
@@ -494,16 +552,9 @@ k_patch_pipe(PatchArgs pa)
         patch_reduce_role<T, NT>(pa);
         return;
     }
-    const int bid = (int)blockIdx.x - pa.red.nred;
-    const int x = bid & 7, rr = bid >> 3;
-    const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
-    const int item = pa.work[sj * 8 + x];
-    if (item < 0) return;
-    const int sib = grp & ((1 << pa.lgB) - 1);
-    const int nblock = pair_block_count(pa.npair, pa.lgB);
-    int b0, b1;
-    split_blocks(pa, grp >> pa.lgB, nblock, b0, b1);
-    if (b0 >= b1) return;
+    PatchItem it;
+    if (!patch_item(pa, pa.lgB, it)) return;
+    const int sib = it.sib, b0 = it.b0, b1 = it.b1;
     constexpr int lgT2 = Log2Size<T2>::value;
     const int64_t n = ta.n;
     size_t qb;                                               // element base of the pair being loaded
@@ -515,30 +566,14 @@ k_patch_pipe(PatchArgs pa)
         qb = (size_t)k0 * (size_t)n + (size_t)sib;
         sh = lw + lgT2;
     }
-    const int4 rec = pa.rec[item];
-    const int2 rec2 = pa.rec2[item];
-    const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
-    const int nlev = rec2.x, a = rec2.y;
-    const int d = ta.angle_dir[a];
-    const int lo = ta.lay[d][pa.layer - 1], hi = ta.lay[d][pa.layer];
-    // one entry per thread: the table arrays have NT slots (compile-time LDS offsets, no address registers)
+    const int n_ent = it.n_ent, own_lo = it.own_lo, own_cnt = it.own_cnt, nlev = it.nlev, a = it.a, d = it.d;
+    const int lo = it.lo, hi = it.hi;
     constexpr int CAP = NT;
-    double *s_w1 = reinterpret_cast<double *>(ptile + CAP + 1);
-    double *s_w2 = s_w1 + CAP, *s_r1 = s_w2 + CAP, *s_r2 = s_r1 + CAP;
-    int *s_pos = reinterpret_cast<int *>(s_r2 + CAP);
-    int *s_u1 = s_pos + CAP, *s_u2 = s_u1 + CAP;
-    uint32_t *s_vis = reinterpret_cast<uint32_t *>(s_u2 + CAP), *s_loc = s_vis + CAP;
-    {
-        const bool ok = tid < n_ent;
-        const int e = ent_off + (ok ? tid : n_ent - 1);
-        s_pos[tid] = pa.e_pos[e];
-        s_u1[tid] = pa.e_u1[e];
-        s_u2[tid] = pa.e_u2[e];
-        s_vis[tid] = ok ? pa.e_vis[e] : 0u;
-        const uint32_t lc = pa.e_loc[e], l1 = lc & 0xFFFFu, l2 = lc >> 16;
-        s_loc[tid] = (l1 == 0xFFFFu ? (uint32_t)n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)n_ent : l2) << 16);
-        s_w1[tid] = pa.e_w1[e]; s_w2[tid] = pa.e_w2[e]; s_r1[tid] = pa.e_r1[e]; s_r2[tid] = pa.e_r2[e];
-    }
+    const EntryTable<CAP> tab(ptile, 1);
+    tab.park(pa, it, tid);
+    double *const s_w1 = tab.w1, *const s_w2 = tab.w2, *const s_r1 = tab.r1, *const s_r2 = tab.r2;
+    int *const s_pos = tab.pos, *const s_u1 = tab.u1, *const s_u2 = tab.u2;
+    uint32_t *const s_vis = tab.vis, *const s_loc = tab.loc;
     if (tid == 0) ptile[n_ent] = make_double2(0.0, 0.0);     // the zero slot
 
     const T2 *Sd = reinterpret_cast<const T2 *>(ta.S[d]);
@@ -657,44 +692,20 @@ k_patch_quad(PatchArgs pa)
         patch_reduce_role<float, NT>(pa);
         return;
     }
-    const int bid = (int)blockIdx.x - pa.red.nred;
-    const int x = bid & 7, rr = bid >> 3;
-    const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
-    const int item = pa.work[sj * 8 + x];
-    if (item < 0) return;
     // workgroup (item, sib2, split): the pairs 2 sib2, 2 sib2 + 1 of every block among blocks b0 .. b1-1
-    const int lgH = pa.lgB - 1;                              // log2 of the sibling workgroups per block
-    const int sib2 = grp & ((1 << lgH) - 1);
-    const int nblock = pair_block_count(pa.npair, pa.lgB);
-    int b0, b1;
-    split_blocks(pa, grp >> lgH, nblock, b0, b1);
-    if (b0 >= b1) return;
+    PatchItem it;
+    if (!patch_item(pa, pa.lgB - 1, it)) return;
+    const int sib2 = it.sib, b0 = it.b0, b1 = it.b1;
     const int64_t n = ta.n;
-    const int4 rec = pa.rec[item];
-    const int2 rec2 = pa.rec2[item];
-    const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
-    const int nlev = rec2.x, a = rec2.y;
-    const int d = ta.angle_dir[a];
-    const int lo = ta.lay[d][pa.layer - 1], hi = ta.lay[d][pa.layer];
-
+    const int n_ent = it.n_ent, own_lo = it.own_lo, own_cnt = it.own_cnt, nlev = it.nlev, a = it.a, d = it.d;
+    const int lo = it.lo, hi = it.hi;
     constexpr int CAP = NT;
     double2 *tileA = ptile, *tileB = ptile + (CAP + 1);
-    double *s_w1 = reinterpret_cast<double *>(ptile + 2 * (CAP + 1));
-    double *s_w2 = s_w1 + CAP, *s_r1 = s_w2 + CAP, *s_r2 = s_r1 + CAP;
-    int *s_pos = reinterpret_cast<int *>(s_r2 + CAP);
-    int *s_u1 = s_pos + CAP, *s_u2 = s_u1 + CAP;
-    uint32_t *s_vis = reinterpret_cast<uint32_t *>(s_u2 + CAP), *s_loc = s_vis + CAP;
-    {
-        const bool ok = tid < n_ent;
-        const int e = ent_off + (ok ? tid : n_ent - 1);
-        s_pos[tid] = pa.e_pos[e];
-        s_u1[tid] = pa.e_u1[e];
-        s_u2[tid] = pa.e_u2[e];
-        s_vis[tid] = ok ? pa.e_vis[e] : 0u;
-        const uint32_t lc = pa.e_loc[e], l1 = lc & 0xFFFFu, l2 = lc >> 16;
-        s_loc[tid] = (l1 == 0xFFFFu ? (uint32_t)n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)n_ent : l2) << 16);
-        s_w1[tid] = pa.e_w1[e]; s_w2[tid] = pa.e_w2[e]; s_r1[tid] = pa.e_r1[e]; s_r2[tid] = pa.e_r2[e];
-    }
+    const EntryTable<CAP> tab(ptile, 2);
+    tab.park(pa, it, tid);
+    double *const s_w1 = tab.w1, *const s_w2 = tab.w2, *const s_r1 = tab.r1, *const s_r2 = tab.r2;
+    int *const s_pos = tab.pos, *const s_u1 = tab.u1, *const s_u2 = tab.u2;
+    uint32_t *const s_vis = tab.vis, *const s_loc = tab.loc;
     if (tid == 0) {
         tileA[n_ent] = make_double2(0.0, 0.0);               // the zero slots
         tileB[n_ent] = make_double2(0.0, 0.0);
@@ -807,42 +818,19 @@ k_patch_duo(PatchArgs pa)
         patch_reduce_role<double, NT>(pa);
         return;
     }
-    const int bid = (int)blockIdx.x - pa.red.nred;
-    const int x = bid & 7, rr = bid >> 3;
-    const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
-    const int item = pa.work[sj * 8 + x];
-    if (item < 0) return;
-    const int sib = grp & ((1 << pa.lgB) - 1);
-    const int nblock = pair_block_count(pa.npair, pa.lgB);
-    int b0, b1;
-    split_blocks(pa, grp >> pa.lgB, nblock, b0, b1);
-    if (b0 >= b1) return;
+    PatchItem it;
+    if (!patch_item(pa, pa.lgB, it)) return;
+    const int sib = it.sib, b0 = it.b0, b1 = it.b1;
     const int64_t n = ta.n;
-    const int4 rec = pa.rec[item];
-    const int2 rec2 = pa.rec2[item];
-    const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
-    const int nlev = rec2.x, a = rec2.y;
-    const int d = ta.angle_dir[a];
-    const int lo = ta.lay[d][pa.layer - 1], hi = ta.lay[d][pa.layer];
-
+    const int n_ent = it.n_ent, own_lo = it.own_lo, own_cnt = it.own_cnt, nlev = it.nlev, a = it.a, d = it.d;
+    const int lo = it.lo, hi = it.hi;
     constexpr int CAP = NT;
     double2 *tileA = ptile, *tileB = ptile + (CAP + 1);
-    double *s_w1 = reinterpret_cast<double *>(ptile + 2 * (CAP + 1));
-    double *s_w2 = s_w1 + CAP, *s_r1 = s_w2 + CAP, *s_r2 = s_r1 + CAP;
-    int *s_pos = reinterpret_cast<int *>(s_r2 + CAP);
-    int *s_u1 = s_pos + CAP, *s_u2 = s_u1 + CAP;
-    uint32_t *s_vis = reinterpret_cast<uint32_t *>(s_u2 + CAP), *s_loc = s_vis + CAP;
-    {
-        const bool ok = tid < n_ent;
-        const int e = ent_off + (ok ? tid : n_ent - 1);
-        s_pos[tid] = pa.e_pos[e];
-        s_u1[tid] = pa.e_u1[e];
-        s_u2[tid] = pa.e_u2[e];
-        s_vis[tid] = ok ? pa.e_vis[e] : 0u;
-        const uint32_t lc = pa.e_loc[e], l1 = lc & 0xFFFFu, l2 = lc >> 16;
-        s_loc[tid] = (l1 == 0xFFFFu ? (uint32_t)n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)n_ent : l2) << 16);
-        s_w1[tid] = pa.e_w1[e]; s_w2[tid] = pa.e_w2[e]; s_r1[tid] = pa.e_r1[e]; s_r2[tid] = pa.e_r2[e];
-    }
+    const EntryTable<CAP> tab(ptile, 2);
+    tab.park(pa, it, tid);
+    double *const s_w1 = tab.w1, *const s_w2 = tab.w2, *const s_r1 = tab.r1, *const s_r2 = tab.r2;
+    int *const s_pos = tab.pos, *const s_u1 = tab.u1, *const s_u2 = tab.u2;
+    uint32_t *const s_vis = tab.vis, *const s_loc = tab.loc;
     if (tid == 0) {
         tileA[n_ent] = make_double2(0.0, 0.0);               // the zero slots
         tileB[n_ent] = make_double2(0.0, 0.0);
