@@ -184,6 +184,7 @@ int vrt_plan_last_path(const vrt_plan *p);
  *   VRT_PATCH_Q, VRT_PATCH_TARGET              wavelength pairs at a time / workgroups per launch of the patch kernel
  *   VRT_PATCH_K, VRT_PATCH_NT, VRT_PATCH_OWN   entries per thread, threads, owned sites per patch (creation only)
  *   VRT_PATCH_PIPE = 0 | 1 | 2                 software-pipelined patch kernel: off (default), on, with fp32 storage only
+ *   VRT_PATCH_LEAN = 0 | 1                     the 64-register patch kernel, four workgroups per CU (default 1)
  *   VRT_PATCH_DUO = 0 | 1                      fp64 storage: two wavelength pairs per workgroup step (default 0)
  *   VRT_PATCH_QUAD = 0 | 1                     fp32 storage: four wavelengths per lane (creation only; default 1)
  *   VRT_PAIR_BLOCK = 1 | 2 | 4 | 8 | 16        wavelength pairs of a site side by side in the patch path's planes and

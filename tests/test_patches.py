@@ -74,11 +74,12 @@ def test_patches_J_matches_oracle_and_steps(grids, name, own, nlam, monkeypatch)
 @pytest.mark.parametrize("shape", [(1, 1, 256), (1, 1, 512), (1, 1, 1024), (2, 1, 256), (2, 1, 512), (1, 2, 256),
                                    (1, 2, 512), (1, 2, 1024), (2, 2, 512)])
 @pytest.mark.parametrize("f32", [False, True])
-@pytest.mark.parametrize("variant", ["plain", "pipe", "block8", "block4-pipe", "duo", "block4-duo"])
+@pytest.mark.parametrize("variant", ["plain", "lean", "pipe", "block8", "block8-lean", "block4-pipe", "duo", "block4-duo"])
 def test_every_patch_kernel_instantiation(grids, shape, f32, variant, monkeypatch):
     """Every (entries per thread, wavelength pairs, threads) instantiation of k_patch_solve, fp64 and fp32
     storage: same results (fp64: to rounding; fp32: 5e-6 against the fp64 oracle on the rounded inputs).
-    Variants: the software-pipelined kernel of the (1, 1, NT) shapes (VRT_PATCH_PIPE), the two-pairs-per-step
+    Variants: the 64-register kernel (VRT_PATCH_LEAN, the default of the (1, 1, NT) shapes; "plain" = the 72-register
+    one), the software-pipelined kernel (VRT_PATCH_PIPE), the two-pairs-per-step
     kernel for doubles (VRT_PATCH_DUO; floats run k_patch_quad or, with an odd pair count as here, the pair kernel)
     and the storage layout with 8 / 4 wavelength pairs of a site side by side (VRT_PAIR_BLOCK; 9 wavelengths = 5
     pairs: blocks 4 + 1)."""
@@ -89,6 +90,9 @@ def test_every_patch_kernel_instantiation(grids, shape, f32, variant, monkeypatc
         pytest.skip("the pipelined kernel exists for one entry per thread, one pair at a time")
     if "duo" in variant and (K, Q) != (1, 1):
         pytest.skip("the two-pair kernel replaces the (1, 1, NT) shapes")
+    if "lean" in variant and (K, Q) != (1, 1):
+        pytest.skip("the 64-register kernel replaces the (1, 1, NT) shapes")
+    monkeypatch.setenv("VRT_PATCH_LEAN", "1" if "lean" in variant else "0")
     monkeypatch.setenv("VRT_PATCH_DUO", "1" if "duo" in variant else "0")
     monkeypatch.setenv("VRT_PATCH_PIPE", "1" if "pipe" in variant else "0")
     monkeypatch.setenv("VRT_PAIR_BLOCK", "8" if "block8" in variant else "4" if "block4" in variant else "1")

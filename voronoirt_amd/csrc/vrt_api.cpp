@@ -25,7 +25,7 @@ void tuning_from_env(Tuning &t)
     static const char *names[] = {"VRT_PATH", "VRT_STEP_K", "VRT_STEP_SINGLE", "VRT_STEP_PAIRS", "VRT_STEP_XCD",
                                   "VRT_STEP_STREAMS", "VRT_STEP_LEVEL_MAP", "VRT_STEP_GROUP_DIR", "VRT_TILE_WIDE",
                                   "VRT_TILE_PRE", "VRT_GRAPH", "VRT_PATCH_K", "VRT_PATCH_NT", "VRT_PATCH_OWN",
-                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_PIPE", "VRT_PATCH_QUAD", "VRT_PATCH_DUO", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
+                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_PIPE", "VRT_PATCH_QUAD", "VRT_PATCH_DUO", "VRT_PATCH_LEAN", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
                                   "VRT_TILE_DEBUG"};
     for (const char *nm : names) {
         const char *e = std::getenv(nm);
@@ -56,7 +56,7 @@ int tuning_set(Tuning &t, const char *name, const char *value, bool created)
         {"VRT_PATCH_K", &t.patch_K, 1, 8, true}, {"VRT_PATCH_NT", &t.patch_NT, 64, 1024, true},
         {"VRT_PATCH_OWN", &t.patch_own, 0, 65535, true}, {"VRT_PATCH_Q", &t.patch_Q, 1, 4, false},
         {"VRT_PATCH_TARGET", &t.patch_target, 1, 1 << 20, false}, {"VRT_PAIR_BLOCK", &t.pair_block, 1, 16, true},
-        {"VRT_PATCH_PIPE", &t.patch_pipe, 0, 2, false}, {"VRT_PATCH_QUAD", &t.patch_quad, 0, 1, true}, {"VRT_PATCH_DUO", &t.patch_duo, 0, 1, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
+        {"VRT_PATCH_PIPE", &t.patch_pipe, 0, 2, false}, {"VRT_PATCH_QUAD", &t.patch_quad, 0, 1, true}, {"VRT_PATCH_DUO", &t.patch_duo, 0, 1, false}, {"VRT_PATCH_LEAN", &t.patch_lean, 0, 1, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
         {"VRT_DEBUG_SKIP_LEVELS", &t.debug_skip_levels, 0, 1, false}, {"VRT_TILE_DEBUG", &t.tile_debug, 0, 1, false},
     };
     for (auto &o : tab)

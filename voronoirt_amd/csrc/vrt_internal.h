@@ -85,6 +85,8 @@ struct Tuning {
                                   //   2 = with fp32 storage only (within the noise everywhere: DESIGN.md section 5)
     int patch_quad = 1;           // VRT_PATCH_QUAD: fp32 storage in blocks of >= 2 pairs, four wavelengths per lane
                                   //   (k_patch_quad; creation only: the native float alpha is laid out with it)
+    int patch_lean = 1;           // VRT_PATCH_LEAN: the 64-register form of the (1, 1, NT) kernel (four workgroups per CU;
+                                  //   default for two and more wavelength pairs)
     int patch_duo = 0;            // VRT_PATCH_DUO: fp64 storage, two wavelength pairs per workgroup step (k_patch_duo)
     int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
     int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)

@@ -35,6 +35,7 @@ struct PatchArgs {
     int cap;                  // entries per patch at most (K * NT): length of the LDS table arrays
     int quad;                 // fp32 storage: k_patch_quad (two neighbouring pairs of a block per workgroup)
     int duo;                  // fp64 storage: k_patch_duo (two pairs per step, one level loop)
+    int lean;                 // k_patch_lean (64 registers: four workgroups per CU)
     int dbg;                  // timing diagnostics (-DVRT_DIAG build only, WRONG results): 1 no levels, 2 gathers ->
                               //   coalesced centre reads, 4 no weights arithmetic, 8 no stores, 16 / 32 / 64 no upwind gathers
                               //   of I / alpha / S, 128 no J reduction
@@ -918,6 +919,106 @@ k_patch_duo(PatchArgs pa)
     }
 }
 
+
+// ---- one pair at a time within 64 registers: FOUR workgroups per CU ---------------------------------------------------
+// No unit of the chip is saturated by the patch kernel; its phases (gathers, arithmetic, level loop) overlap only as
+// far as three 512-thread workgroups per CU allow (72 registers).  This form fits the 64 of a fourth: the three
+// alpha gathers first, the four optical depths from them (the alphas die), then the five S / I gathers in flight
+// while the weights are evaluated one after the other, each folded into its share of the visit as soon as it exists.
+#ifndef VRT_LEAN_ATTR
+#define VRT_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+template <typename T, int AM, int NT>
+__global__ void __launch_bounds__(NT) VRT_LEAN_ATTR
+k_patch_lean(PatchArgs pa)
+{
+    typedef typename Pair<T>::type T2;
+    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
+    const TileArgs &ta = pa.ta;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < pa.red.nred) {
+        patch_reduce_role<T, NT>(pa);
+        return;
+    }
+    PatchItem it;
+    if (!patch_item(pa, pa.lgB, it)) return;
+    constexpr int lgT2 = Log2Size<T2>::value;
+    const int64_t n = ta.n;
+    constexpr int CAP = NT;
+    const EntryTable<CAP> tab(ptile, 1);
+    tab.park(pa, it, tid);
+    if (tid == 0) ptile[it.n_ent] = make_double2(0.0, 0.0);  // the zero slot
+    const T2 *Sd = reinterpret_cast<const T2 *>(ta.S[it.d]);
+    const T2 *Ia = reinterpret_cast<const T2 *>(ta.I) + (size_t)it.a * pa.npair * (size_t)n;
+    auto at = [](const T2 *base, unsigned off) { return *reinterpret_cast<const T2 *>(reinterpret_cast<const char *>(base) + off); };
+    for (int bk = it.b0; bk < it.b1; bk++) {
+        int k0, lw;
+        pair_block_of(bk, pa.npair, pa.lgB, k0, lw);
+        if (it.sib >= (1 << lw)) break;                      // block widths only shrink
+        const size_t qb = (size_t)k0 * (size_t)n + (size_t)it.sib;
+        const int sh = lw + lgT2;
+        double2 c, g1, g2;
+        {
+            const int p = tab.pos[tid], v1 = tab.u1[tid], v2 = tab.u2[tid];
+            // ---- the four optical depths: r (alpha_c + alpha_u) / 2 = (r / 2)(alpha_c + alpha_u) ----------------
+            double d1x, d2x, d1y, d2y;
+            {
+                double2 a_c, a_1, a_2;
+                if constexpr (AM == VRT_ALPHA_SITE) {
+                    const T *__restrict__ A1 = reinterpret_cast<const T *>(ta.alpha[it.d]);
+                    const double c0 = A1[p], c1 = A1[v1], c2 = A1[v2];
+                    a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
+                } else {
+                    const T2 *Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const T2 *>(ta.alpha[it.d]) + qb
+                                                            : reinterpret_cast<const T2 *>(ta.alpha_angle) + (size_t)it.a * pa.npair * (size_t)n + qb;
+                    a_c = to_d2(at(Al, (unsigned)p << sh)); a_1 = to_d2(at(Al, (unsigned)v1 << sh)); a_2 = to_d2(at(Al, (unsigned)v2 << sh));
+                }
+                const double rh1 = 0.5 * tab.r1[tid], rh2 = 0.5 * tab.r2[tid];
+                d1x = rh1 * (a_c.x + a_1.x); d2x = rh2 * (a_c.x + a_2.x);
+                d1y = rh1 * (a_c.y + a_1.y); d2y = rh2 * (a_c.y + a_2.y);
+            }
+            asm volatile("" : "+v"(d1x), "+v"(d2x), "+v"(d1y), "+v"(d2y) : : "memory");
+            // ---- S and I in flight, the weights one after the other -------------------------------------------------
+            // an upwind's intensity counts when it lies in an EARLIER layer (final); otherwise the gather reads the
+            // never-visited site at storage position n - 1, whose intensity is 0 in every plane (:23)
+            const int i1 = v1 < it.lo ? v1 : (int)n - 1, i2 = v2 < it.lo ? v2 : (int)n - 1;
+            const T2 rS_c = at(Sd + qb, (unsigned)p << sh), rS_1 = at(Sd + qb, (unsigned)v1 << sh), rS_2 = at(Sd + qb, (unsigned)v2 << sh);
+            const T2 rI_1 = at(Ia + qb, (unsigned)i1 << sh), rI_2 = at(Ia + qb, (unsigned)i2 << sh);
+            const bool in1 = (v1 >= it.lo) & (v1 < it.hi), in2 = (v2 >= it.lo) & (v2 < it.hi);
+            entry_lambda_seq(d1x, d2x, tab.w1 + tid, tab.w2 + tid, in1, in2, (double)rS_c.x, (double)rS_1.x, (double)rS_2.x,
+                             (double)rI_1.x, (double)rI_2.x, c.x, g1.x, g2.x, d1y);
+            double sink = 0.0;
+            entry_lambda_seq(d1y, d2y, tab.w1 + tid, tab.w2 + tid, in1, in2, (double)rS_c.y, (double)rS_1.y, (double)rS_2.y,
+                             (double)rI_1.y, (double)rI_2.y, c.y, g1.y, g2.y, sink);
+        }
+        // ---- the patch's Gauss-Seidel levels on the LDS tile ------------------------------------------------------
+        uint32_t vis = tab.vis[tid];
+        const uint32_t loc = tab.loc[tid];
+        {
+            double z;
+            asm volatile("v_mov_b64 %0, 0" : "=v"(z));
+            if (tid < it.n_ent) ptile[tid] = make_double2(z, z);         // I = zero(S), :23
+        }
+        __syncthreads();
+        for (int t = 1; t <= it.nlev; t++) {
+            if ((vis & 0xFFu) == (uint32_t)t) {                          // a site's visits come at increasing levels
+                const double2 xv = ptile[loc & 0xFFFFu], yv = ptile[loc >> 16];
+                double2 r;
+                r.x = fma(g2.x, yv.x, fma(g1.x, xv.x, c.x));
+                r.y = fma(g2.y, yv.y, fma(g1.y, xv.y, c.y));
+                ptile[tid] = r;
+                vis >>= 8;
+            }
+            __syncthreads();
+        }
+        if (tid < it.own_cnt) {
+            T2 *I = reinterpret_cast<T2 *>(ta.I) + (size_t)it.a * pa.npair * (size_t)n + qb;
+            *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + ((unsigned)(it.own_lo + tid) << sh)) = from_d2<T>(ptile[tid]);
+        }
+        __syncthreads();                                                 // the tile is rewritten by the next pair
+    }
+}
+
 // the instantiated launch shapes (entries per thread, pairs at a time, threads)
 #define VRT_PATCH_SHAPES(X) \
     X(1, 1, 256) X(1, 1, 512) X(1, 1, 1024) X(2, 1, 256) X(2, 1, 512) X(1, 2, 256) X(1, 2, 512) X(1, 2, 1024) X(2, 2, 512)
@@ -943,6 +1044,14 @@ static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t
             case 1024: hipLaunchKernelGGL((k_patch_duo<AM, 1024>), grid, dim3(1024), lds, st, pa); return VRT_OK;
             default: break;
             }
+        }
+    }
+    if (pa.lean && K == 1 && Q == 1 && !(kDiag && pa.dbg)) {
+        switch (NT) {
+        case 256: hipLaunchKernelGGL((k_patch_lean<T, AM, 256>), grid, dim3(256), lds, st, pa); return VRT_OK;
+        case 512: hipLaunchKernelGGL((k_patch_lean<T, AM, 512>), grid, dim3(512), lds, st, pa); return VRT_OK;
+        case 1024: hipLaunchKernelGGL((k_patch_lean<T, AM, 1024>), grid, dim3(1024), lds, st, pa); return VRT_OK;
+        default: break;
         }
     }
     if (pipe && K == 1 && Q == 1 && !(kDiag && pa.dbg)) {
@@ -1070,6 +1179,8 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     if (pa.quad) Q = 1;
     pa.duo = (!f32 && p->tune.patch_duo != 0 && p->patch_K == 1 && Q == 1 && npair >= 2) ? 1 : 0;
     if (pa.duo) Q = 2;
+    // (a lone pair per workgroup is a latency chain: the plain kernel's single gather phase is 3 % shorter there)
+    pa.lean = (p->tune.patch_lean != 0 && p->patch_K == 1 && Q == 1 && !pa.quad && npair >= 2) ? 1 : 0;
     const int lgS = pa.lgB - pa.quad;                          // log2 of the sibling workgroups per block
     pa.Q = Q;
     pa.nsplit = 1;
