@@ -376,6 +376,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
                    "steps": "k_step_coeffs + k_step_levels (two launches per BFS layer)",
                    "tiles": "k_sweep_tiles (one persistent launch)",
                    "patches": ("k_patch_quad (fp32 storage: two wavelength pairs per lane; " if f32 and ((nlam + 1) // 2) % 2 == 0
+                               else "k_patch_lean (64 registers, four workgroups per CU; " if (nlam + 1) // 2 >= 2
                                else "k_patch_solve (") +
                               "one fused launch per BFS layer and direction: coefficients + "
                               "Gauss-Seidel levels of every patch, J reduction of the previous layer riding along)"
