@@ -678,10 +678,10 @@ k_patch_pipe(PatchArgs pa)
 // With float values a wavelength pair is an 8-byte access, and the patch kernel issues as many memory instructions
 // per wavelength as with doubles: the memory path, which bounds it, sees twice the requests
 // per byte.  In the layout with two (or more) pairs of a site side by side (pair blocks, vrt_device.h) two
-// neighbouring pairs are ONE 16-byte access: this kernel solves both at once -- eight float4 gathers per entry,
-// the four evaluations of the weights one after the other (compiler fences as in the pipelined kernel), two planes
-// of the LDS tile walked by one level loop, one float4 store.  Half the memory instructions and half the barriers
-// per wavelength.  (An odd pair count leaves a last block of one pair: the host then launches the pair kernel.)
+// neighbouring pairs are ONE 16-byte access: this kernel solves both at once -- eight float4 gathers per entry (the
+// three alphas first, then S and I under the weights, as in k_patch_lean), the four evaluations of the weights one
+// after the other (compiler fences), two planes of the LDS tile walked by one level loop, one float4 store.  Half
+// the memory instructions and half the barriers per wavelength.  (An odd pair count leaves a last block of one pair: the host then launches the pair kernel.)
 template <int AM, int NT>
 __global__ void __launch_bounds__(NT) VRT_PIPE_ATTR
 k_patch_quad(PatchArgs pa)
@@ -713,53 +713,48 @@ k_patch_quad(PatchArgs pa)
     }
     const float2 *Sd = reinterpret_cast<const float2 *>(ta.S[d]);
     const float2 *Ia = reinterpret_cast<const float2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n;
+    auto at4 = [](const float2 *base, unsigned off) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off); };
     for (int bk = b0; bk < b1; bk++) {
         int k0, lw;
         pair_block_of(bk, pa.npair, pa.lgB, k0, lw);
         if (2 * sib2 >= (1 << lw)) break;                    // block widths only shrink (and are >= 2: even pair count)
         const size_t qb = (size_t)k0 * (size_t)n + (size_t)(2 * sib2);
         const int sh = lw + 3;                               // log2 bytes per site of the block
-        float4 S_c, S_1, S_2, I_1, I_2, a_c, a_1, a_2;
+        const int p = s_pos[tid], v1 = s_u1[tid], v2 = s_u2[tid];
+        // ---- the eight optical depths from the three alpha gathers (two gather phases as in k_patch_lean: the
+        // alphas are dead before the S / I gathers land) ------------------------------------------------------------
+        double d1x, d2x, d1y, d2y, d1z, d2z, d1w, d2w;
         {
-            const int p = s_pos[tid], v1 = s_u1[tid], v2 = s_u2[tid];
-            const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
-            const unsigned op = (unsigned)p << sh, o1 = (unsigned)v1 << sh, o2 = (unsigned)v2 << sh;
-            const unsigned oi1 = (unsigned)i1 << sh, oi2 = (unsigned)i2 << sh;
-            auto at4 = [](const float2 *base, unsigned off) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off); };
-            const float2 *Al = nullptr;
+            float4 a_c, a_1, a_2;
             if constexpr (AM == VRT_ALPHA_SITE) {
                 const float *__restrict__ A1 = reinterpret_cast<const float *>(ta.alpha[d]);
-                a_c.x = A1[p]; a_1.x = A1[v1]; a_2.x = A1[v2];
-            } else
-                Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const float2 *>(ta.alpha[d]) + qb
-                                              : reinterpret_cast<const float2 *>(ta.alpha_angle) + (size_t)a * pa.npair * (size_t)n + qb;
-            if constexpr (AM != VRT_ALPHA_SITE) { a_c = at4(Al, op); a_1 = at4(Al, o1); a_2 = at4(Al, o2); }
-            S_c = at4(Sd + qb, op); S_1 = at4(Sd + qb, o1); S_2 = at4(Sd + qb, o2);
-            I_1 = at4(Ia + qb, oi1); I_2 = at4(Ia + qb, oi2);
-            if constexpr (AM == VRT_ALPHA_SITE) {
-                a_c = make_float4(a_c.x, a_c.x, a_c.x, a_c.x);
-                a_1 = make_float4(a_1.x, a_1.x, a_1.x, a_1.x);
-                a_2 = make_float4(a_2.x, a_2.x, a_2.x, a_2.x);
+                const float c0 = A1[p], c1 = A1[v1], c2 = A1[v2];
+                a_c = make_float4(c0, c0, c0, c0); a_1 = make_float4(c1, c1, c1, c1); a_2 = make_float4(c2, c2, c2, c2);
+            } else {
+                const float2 *Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const float2 *>(ta.alpha[d]) + qb
+                                                            : reinterpret_cast<const float2 *>(ta.alpha_angle) + (size_t)a * pa.npair * (size_t)n + qb;
+                a_c = at4(Al, (unsigned)p << sh); a_1 = at4(Al, (unsigned)v1 << sh); a_2 = at4(Al, (unsigned)v2 << sh);
             }
+            const double rh1 = 0.5 * s_r1[tid], rh2 = 0.5 * s_r2[tid];
+            d1x = rh1 * ((double)a_c.x + (double)a_1.x); d2x = rh2 * ((double)a_c.x + (double)a_2.x);
+            d1y = rh1 * ((double)a_c.y + (double)a_1.y); d2y = rh2 * ((double)a_c.y + (double)a_2.y);
+            d1z = rh1 * ((double)a_c.z + (double)a_1.z); d2z = rh2 * ((double)a_c.z + (double)a_2.z);
+            d1w = rh1 * ((double)a_c.w + (double)a_1.w); d2w = rh2 * ((double)a_c.w + (double)a_2.w);
         }
-        // ---- integration coefficients of the entry, four wavelengths one after the other -------------------------
+        asm volatile("" : "+v"(d1x), "+v"(d2x), "+v"(d1y), "+v"(d2y), "+v"(d1z), "+v"(d2z), "+v"(d1w), "+v"(d2w) : : "memory");
+        // ---- S and I in flight, the weights of the four wavelengths one after the other --------------------------
         double2 cA, g1A, g2A, cB, g1B, g2B;
         {
-            const int v1 = s_u1[tid], v2 = s_u2[tid];
+            const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
             const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
-            const double rh1 = 0.5 * s_r1[tid], rh2 = 0.5 * s_r2[tid];
-            const double d1x = rh1 * ((double)a_c.x + (double)a_1.x), d2x = rh2 * ((double)a_c.x + (double)a_2.x);
-            double d1y = rh1 * ((double)a_c.y + (double)a_1.y), d2y = rh2 * ((double)a_c.y + (double)a_2.y);
+            const float4 S_c = at4(Sd + qb, (unsigned)p << sh), S_1 = at4(Sd + qb, (unsigned)v1 << sh), S_2 = at4(Sd + qb, (unsigned)v2 << sh);
+            const float4 I_1 = at4(Ia + qb, (unsigned)i1 << sh), I_2 = at4(Ia + qb, (unsigned)i2 << sh);
             entry_lambda_seq(d1x, d2x, s_w1 + tid, s_w2 + tid, in1, in2, (double)S_c.x, (double)S_1.x, (double)S_2.x,
                              (double)I_1.x, (double)I_2.x, cA.x, g1A.x, g2A.x, d1y);
-            double d1z = rh1 * ((double)a_c.z + (double)a_1.z);
             entry_lambda_seq(d1y, d2y, s_w1 + tid, s_w2 + tid, in1, in2, (double)S_c.y, (double)S_1.y, (double)S_2.y,
                              (double)I_1.y, (double)I_2.y, cA.y, g1A.y, g2A.y, d1z);
-            const double d2z = rh2 * ((double)a_c.z + (double)a_2.z);
-            double d1w = rh1 * ((double)a_c.w + (double)a_1.w);
             entry_lambda_seq(d1z, d2z, s_w1 + tid, s_w2 + tid, in1, in2, (double)S_c.z, (double)S_1.z, (double)S_2.z,
                              (double)I_1.z, (double)I_2.z, cB.x, g1B.x, g2B.x, d1w);
-            const double d2w = rh2 * ((double)a_c.w + (double)a_2.w);
             double sink = 0.0;
             entry_lambda_seq(d1w, d2w, s_w1 + tid, s_w2 + tid, in1, in2, (double)S_c.w, (double)S_1.w, (double)S_2.w,
                              (double)I_1.w, (double)I_2.w, cB.y, g1B.y, g2B.y, sink);
