@@ -34,6 +34,42 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().vrt_version() >= 100
 
 
+def test_default_patch_kernels_hold_their_register_budget(tmp_path):
+    """The default sweep kernel owes its speed to FOUR 512-thread workgroups per CU: k_patch_lean must fit 64
+    VGPRs without scratch (8 bytes of scratch cost 3.5 %, 56 bytes 80 %: DESIGN.md section 5), the 72-register
+    kernel and k_patch_quad at most 80 (three workgroups).  Read from hipcc's own resource report."""
+    import subprocess
+    from voronoirt_amd import build
+    src = os.path.join(ROOT, "voronoirt_amd", "csrc", "vrt_patch.hip")
+    cmd = [build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "voronoirt_amd", "csrc"), "-c", src,
+           "-o", str(tmp_path / "p.o"), "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    usage = {}
+    name = None
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        for key in ("VGPRs", "ScratchSize [bytes/lane]"):
+            m = re.search(re.escape(key) + r": (\d+)", line)
+            if m and name:
+                usage[name][key] = int(m.group(1))
+    lean = {k: v for k, v in usage.items() if "k_patch_lean" in k and "Li512E" in k}
+    assert len(lean) == 6                                   # double / float x three alpha modes
+    for k, v in lean.items():
+        assert v["VGPRs"] <= 64 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
+    plain = {k: v for k, v in usage.items() if "k_patch_solveI" in k and "Li1ELi1ELi512E" in k}
+    assert len(plain) == 6
+    for k, v in plain.items():
+        assert v["VGPRs"] <= 80 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
+    quad = {k: v for k, v in usage.items() if "k_patch_quad" in k and "Li512E" in k}
+    assert len(quad) == 3
+    for k, v in quad.items():
+        assert v["VGPRs"] <= 80 and v["ScratchSize [bytes/lane]"] <= 8, (k, v)
+
+
 def test_no_cpu_fallback(bcc_small):
     """Without a HIP device every compute entry point fails loudly."""
     L = _lib.load()
