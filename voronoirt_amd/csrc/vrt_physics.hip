@@ -34,52 +34,63 @@ __device__ __forceinline__ cplx c_add(cplx a, cplx b) { return {a.re + b.re, a.i
 __device__ __forceinline__ cplx c_sub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ cplx c_real(double x) { return {x, 0.0}; }
 __device__ __forceinline__ cplx c_scale(cplx a, double s) { return {a.re * s, a.im * s}; }
-__device__ __forceinline__ cplx c_div(cplx a, cplx b)
-{
-    const double d = b.re * b.re + b.im * b.im;
-    return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
-}
 
-// Re w4(x + i y), y >= 0: Humlíček's four regions
+// Re w4(x + i y), y >= 0: Humlíček's four regions.  The opacity kernel is bound by this arithmetic (51 evaluations
+// per site and angle, ~290 fp64 instruction slots each as the oracle writes it), so the Horner steps use fused
+// multiply-adds (c + t p in 4 instructions instead of 7) and the one real part that is needed is formed with a
+// Newton-refined reciprocal instead of two divisions: last-bit differences from the oracle (contract 1e-12).
+__device__ __forceinline__ cplx c_fma(cplx t, cplx p, double c)           // c + t p
+{
+    return {fma(t.re, p.re, fma(-t.im, p.im, c)), fma(t.re, p.im, t.im * p.re)};
+}
+__device__ __forceinline__ cplx c_fms(cplx t, cplx p, double c)           // c - t p
+{
+    return {fma(-t.re, p.re, fma(t.im, p.im, c)), -fma(t.re, p.im, t.im * p.re)};
+}
+__device__ __forceinline__ double c_div_re(cplx a, cplx b)                // Re(a / b)
+{
+    const double d = fma(b.re, b.re, b.im * b.im);
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return fma(a.re, b.re, a.im * b.im) * r;
+}
 __device__ double humlicek_w4_re(double x, double y)
 {
     const cplx t = {y, -x};
     const double s = fabs(x) + y;
-    if (s >= 15.0) return c_div(c_scale(t, 0.5641896), c_add(c_real(0.5), c_mul(t, t))).re;
+    if (s >= 15.0) return c_div_re(c_scale(t, 0.5641896), c_fma(t, t, 0.5));
     if (s >= 5.5) {
         const cplx u = c_mul(t, t);
-        return c_div(c_mul(t, c_add(c_real(1.410474), c_scale(u, 0.5641896))),
-                     c_add(c_real(0.75), c_mul(u, c_add(c_real(3.0), u)))).re;
+        return c_div_re(c_mul(t, c_add(c_real(1.410474), c_scale(u, 0.5641896))), c_fma(u, c_add(c_real(3.0), u), 0.75));
     }
     if (y >= 0.195 * fabs(x) - 0.176) {
         cplx num = c_add(c_real(3.778987), c_scale(t, 0.5642236));
-        num = c_add(c_real(11.96482), c_mul(t, num));
-        num = c_add(c_real(20.20933), c_mul(t, num));
-        num = c_add(c_real(16.4955), c_mul(t, num));
+        num = c_fma(t, num, 11.96482);
+        num = c_fma(t, num, 20.20933);
+        num = c_fma(t, num, 16.4955);
         cplx den = c_add(c_real(6.699398), t);
-        den = c_add(c_real(21.69274), c_mul(t, den));
-        den = c_add(c_real(39.27121), c_mul(t, den));
-        den = c_add(c_real(38.82363), c_mul(t, den));
-        den = c_add(c_real(16.4955), c_mul(t, den));
-        return c_div(num, den).re;
+        den = c_fma(t, den, 21.69274);
+        den = c_fma(t, den, 39.27121);
+        den = c_fma(t, den, 38.82363);
+        den = c_fma(t, den, 16.4955);
+        return c_div_re(num, den);
     }
     const cplx u = c_mul(t, t);
     cplx num = c_sub(c_real(1.320522), c_scale(u, 0.56419));
-    num = c_sub(c_real(35.76683), c_mul(u, num));
-    num = c_sub(c_real(219.0313), c_mul(u, num));
-    num = c_sub(c_real(1540.787), c_mul(u, num));
-    num = c_sub(c_real(3321.9905), c_mul(u, num));
-    num = c_sub(c_real(36183.31), c_mul(u, num));
+    num = c_fms(u, num, 35.76683);
+    num = c_fms(u, num, 219.0313);
+    num = c_fms(u, num, 1540.787);
+    num = c_fms(u, num, 3321.9905);
+    num = c_fms(u, num, 36183.31);
     cplx den = c_sub(c_real(1.841439), u);
-    den = c_sub(c_real(61.57037), c_mul(u, den));
-    den = c_sub(c_real(364.2191), c_mul(u, den));
-    den = c_sub(c_real(2186.181), c_mul(u, den));
-    den = c_sub(c_real(9022.228), c_mul(u, den));
-    den = c_sub(c_real(24322.84), c_mul(u, den));
-    den = c_sub(c_real(32066.6), c_mul(u, den));
-    const double e = exp(u.re);
-    const cplx ex = {e * cos(u.im), e * sin(u.im)};
-    return c_sub(ex, c_div(c_mul(t, num), den)).re;
+    den = c_fms(u, den, 61.57037);
+    den = c_fms(u, den, 364.2191);
+    den = c_fms(u, den, 2186.181);
+    den = c_fms(u, den, 9022.228);
+    den = c_fms(u, den, 24322.84);
+    den = c_fms(u, den, 32066.6);
+    return exp(u.re) * cos(u.im) - c_div_re(c_mul(t, num), den);
 }
 
 constexpr double kPi = 3.14159265358979323846;
