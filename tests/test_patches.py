@@ -121,6 +121,45 @@ def test_every_patch_kernel_instantiation(grids, shape, f32, variant, monkeypatc
     plan.close()
 
 
+@pytest.mark.parametrize("f32", [False, True])
+def test_kernel_variants_agree_bit_for_bit(grids, f32, monkeypatch):
+    """The 64-register kernel (default), the 72-register one, the pipelined one and the two-pairs-per-step one
+    evaluate the same expressions in the same order: J and the per-angle intensities are bitwise equal."""
+    import torch
+    hs, so = grids["bcc"]
+    n, nlam = so.n, 14
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setenv("VRT_PATH", "patches")
+    monkeypatch.setenv("VRT_PATCH_OWN", "200")
+    monkeypatch.setenv("VRT_PATCH_QUAD", "0")
+    S, al, I0u, I0d = _case(so, nlam, 23, per_angle=nq)
+    dt = torch.float32 if f32 else torch.float64
+    f = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev).to(dt).contiguous()
+    Sd, Ad, Ud, Dd = f(S), f(al), f(I0u), f(I0d)
+    got = {}
+    for name, env in (("lean", {"VRT_PATCH_LEAN": "1"}), ("plain", {"VRT_PATCH_LEAN": "0"}),
+                      ("pipe", {"VRT_PATCH_LEAN": "0", "VRT_PATCH_PIPE": "1"}),
+                      ("duo", {"VRT_PATCH_LEAN": "0", "VRT_PATCH_DUO": "1"})):
+        if name == "duo" and f32:
+            continue
+        for k in ("VRT_PATCH_LEAN", "VRT_PATCH_PIPE", "VRT_PATCH_DUO"):
+            monkeypatch.setenv(k, env.get(k, "0"))
+        plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
+        Jd = torch.full((n, nlam), float("nan"), dtype=dt, device=dev)
+        Id = torch.full((nq, n, nlam), float("nan"), dtype=dt, device=dev)
+        plan.execute_dev(nlam, nlam, Sd.data_ptr(), Ad.data_ptr(), _lib.ALPHA_ANGLE_SITE_LAM, w, dJ=Jd.data_ptr(),
+                         dI0_up=Ud.data_ptr(), dI0_down=Dd.data_ptr(), dI_out=Id.data_ptr(), stream=st, f32=f32)
+        torch.cuda.synchronize()
+        assert plan.last_path == "patches"
+        got[name] = (Jd.cpu().numpy(), Id.cpu().numpy())
+        plan.close()
+    for name in got:
+        assert np.array_equal(got[name][0], got["lean"][0]), name
+        assert np.array_equal(got[name][1], got["lean"][1]), name
+
+
 @pytest.mark.parametrize("pair_block", [1, 4])
 @pytest.mark.parametrize("mode", ["site", "site_lam", "angle"])
 def test_fp32_quad_kernel_equals_pair_kernel(grids, pair_block, mode, monkeypatch):
