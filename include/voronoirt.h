@@ -169,11 +169,13 @@ int vrt_plan_execute_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float 
                              const float *dI0_down, const double *weights_host, float *dJ,
                              float *dI_out, void *stream);
 /* time (ms, HIP events on the launch stream) the sweep kernels of the last execute took, and the
- * number of sweep-kernel launches it made */
+ * number of sweep-kernel launches it made (waits for the sweep; VRT_ENODEVICE if its chained patch launch gave up
+ * waiting for a dependency -- a bounded spin expired: the results of that execute are invalid; also reported by the
+ * next execute of the plan) */
 int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches);
 /* which device path the last execute took: 1 = "levels" (one launch per dependency level),
- * 2 = "tiles" (one persistent launch), 3 = "steps" (two launches per BFS layer), 4 = "patches" (one
- * fused launch per BFS layer, layers cut into patches; the default); 0 = none yet.  The paths give the
+ * 2 = "tiles" (one persistent launch), 3 = "steps" (two launches per BFS layer), 4 = "patches" (layers cut
+ * into patches, the default: ONE chained launch for every layer, or one fused launch per BFS layer); 0 = none yet.  The paths give the
  * same results; option VRT_PATH selects one (performance experiments, the parity tests' cross-checks). */
 int vrt_plan_last_path(const vrt_plan *p);
 /* Tuning options (performance experiments and the tests' cross-checks; results never depend on them).
@@ -183,9 +185,11 @@ int vrt_plan_last_path(const vrt_plan *p);
  *   VRT_PATH = auto | levels | tiles | steps | patches
  *   VRT_PATCH_Q, VRT_PATCH_TARGET              wavelength pairs at a time / workgroups per launch of the patch kernel
  *   VRT_PATCH_K, VRT_PATCH_NT, VRT_PATCH_OWN   entries per thread, threads, owned sites per patch (creation only)
- *   VRT_PATCH_PIPE = 0 | 1 | 2                 software-pipelined patch kernel: off (default), on, with fp32 storage only
  *   VRT_PATCH_LEAN = 0 | 1                     the 64-register patch kernel, four workgroups per CU (default 1)
- *   VRT_PATCH_DUO = 0 | 1                      fp64 storage: two wavelength pairs per workgroup step (default 0)
+ *   VRT_PATCH_CHAIN = 0 | 1                    every layer inside one launch, ordered by the data's own dependencies
+ *                                              (default 1; 0 = one launch per layer and direction)
+ *   VRT_CHAIN_PAIRS, VRT_CHAIN_SPIN            wavelength-pair blocks per item of the chained launch (default 5); polls
+ *                                              (x 1024) after which a waiting workgroup gives up (default 2048)
  *   VRT_PATCH_QUAD = 0 | 1                     fp32 storage: four wavelengths per lane (creation only; default 1)
  *   VRT_PAIR_BLOCK = 1 | 2 | 4 | 8 | 16        wavelength pairs of a site side by side in the patch path's planes and
  *                                              in the plan's native alpha (creation only; default 1)
@@ -231,6 +235,12 @@ int vrt_patch_schedule_build(const vrt_grid *g, int dir, const int64_t *up, int 
 int vrt_patch_schedule_get(const vrt_patch_schedule *s, int32_t *layer_patch_off, int32_t *patch_own_lo,
                            int32_t *patch_own_cnt, int32_t *patch_nlev, int64_t *patch_ent_off,
                            int32_t *entry_pos, uint32_t *entry_vis, uint32_t *entry_loc);
+/* Dependencies BETWEEN patches (what the chained launch of the patch path waits on, vrt_patch.hip: k_patch_chain):
+ * patch q gathers, as upwind intensities of EARLIER layers (irregular_ray_tracing.jl:75), values that the
+ * patches dep_list[dep_off[q] .. dep_off[q+1]) store (sorted patch indices of this schedule; the boundary layer
+ * and the never-visited last site have no owner).  dep_off [patches + 1] first, then dep_list [dep_off[patches]];
+ * either pointer may be NULL. */
+int vrt_patch_schedule_get_deps(const vrt_patch_schedule *s, int64_t *dep_off, int32_t *dep_list);
 void vrt_patch_schedule_destroy(vrt_patch_schedule *s);
 
 /* ---- single solves: drop-in bodies for Delaunay_upII / Delaunay_downII --------------------

@@ -52,7 +52,7 @@ def test_default_patch_kernels_hold_their_register_budget(tmp_path):
         if m:
             name = m.group(1)
             usage[name] = {}
-        for key in ("VGPRs", "ScratchSize [bytes/lane]"):
+        for key in ("VGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]"):
             m = re.search(re.escape(key) + r": (\d+)", line)
             if m and name:
                 usage[name][key] = int(m.group(1))
@@ -68,6 +68,12 @@ def test_default_patch_kernels_hold_their_register_budget(tmp_path):
     assert len(quad) == 3
     for k, v in quad.items():
         assert v["VGPRs"] <= 80 and v["ScratchSize [bytes/lane]"] <= 8, (k, v)
+    # the chained launch of the default (fp64) storage: the same budget as k_patch_lean, at eight waves per SIMD
+    # (a ninth scalar register over 80 would be spilled into a vector register's lanes, and the solver has none to spare)
+    chain = {k: v for k, v in usage.items() if "k_patch_chainId" in k and "Li512E" in k}
+    assert len(chain) == 3
+    for k, v in chain.items():
+        assert v["VGPRs"] <= 64 and v["ScratchSize [bytes/lane]"] == 0 and v["Occupancy [waves/SIMD]"] == 8, (k, v)
 
 
 def test_no_cpu_fallback(bcc_small):
@@ -459,6 +465,71 @@ def test_patch_schedule_equals_serial_gauss_seidel(grid, bcc_small, voro_small):
     with pytest.raises(vrt.VrtError):     # the cone of a single site does not fit 4 entries
         up, *_ = orc.upwind_table(so, orc.direction(109.7, 193.6))
         build_patch_schedule(hs, +1, up, 3, 2, 4)
+
+
+@pytest.mark.parametrize("grid", ["bcc", "voronoi"])
+def test_patch_dependency_lists_cover_every_gathered_intensity(grid, bcc_small, voro_small):
+    """The chained launch orders patches by data only: patch q waits for dep_list[dep_off[q] .. dep_off[q+1]).
+    Those lists must name the owner of EVERY earlier-layer intensity q gathers (irregular_ray_tracing.jl:75) and
+    nothing of q's own or a later layer: then any order that respects them reads final values only."""
+    pos, nbr, bounds = bcc_small if grid == "bcc" else voro_small
+    so = orc.make_sites(pos, nbr, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)
+    n = so.n
+    w, th, ph, _ = vrt.read_quadrature("ul7n12.dat")
+    rng = np.random.default_rng(7)
+    for own, cap in ((24, 128), (7, 128), (120, 512)):
+        for t, p in list(zip(th, ph))[::3]:
+            dirn = 1 if t > 90 else -1
+            up, *_ = orc.upwind_table(so, orc.direction(t, p))
+            ps = build_patch_schedule(hs, dirn, up, 3, own, cap)
+            store = hs.storage_order(dirn) - 1
+            lay = so.layers_up if dirn > 0 else so.layers_down
+            srank = np.empty(n, dtype=np.int64)
+            srank[store] = np.arange(n)
+            P = ps["patches"]
+            owner = np.full(n, -1, dtype=np.int64)              # storage position -> patch that stores it
+            layer_of_patch = np.zeros(P, dtype=np.int64)
+            for layer in range(2, len(lay)):
+                for q in range(ps["layer_patch_off"][layer], ps["layer_patch_off"][layer + 1]):
+                    owner[ps["patch_own_lo"][q]: ps["patch_own_lo"][q] + ps["patch_own_cnt"][q]] = q
+                    layer_of_patch[q] = layer
+            assert (owner[lay[1] - 1: n - 1] >= 0).all() and (owner[: lay[1] - 1] == -1).all() and owner[n - 1] == -1
+            doff, dl = ps["dep_off"], ps["dep_list"]
+            assert doff[0] == 0 and doff[-1] == dl.size and (np.diff(doff) >= 0).all()
+            for q in range(P):
+                lo = lay[layer_of_patch[q] - 1] - 1
+                e0, e1 = ps["patch_ent_off"][q], ps["patch_ent_off"][q + 1]
+                sites = store[ps["entry_pos"][e0:e1].astype(np.int64)]
+                u = srank[np.concatenate([up[sites, 0], up[sites, 1]]) - 1]
+                need = np.unique(owner[u[u < lo]])
+                need = need[need >= 0]
+                got = dl[doff[q]: doff[q + 1]]
+                assert np.array_equal(got, need), (q, got, need)
+                assert (layer_of_patch[got] < layer_of_patch[q]).all()
+            # an execution order that respects nothing but the lists: the patches in a random order, each deferred
+            # until its dependencies have run -- never reads an intensity that is not final
+            done = np.zeros(P, dtype=bool)
+            final = np.zeros(n, dtype=bool)
+            final[: lay[1] - 1] = True                          # the boundary layer
+            final[n - 1] = True                                 # the never-visited site (I = 0)
+            pending = list(rng.permutation(P))
+            while pending:
+                rest = []
+                for q in pending:
+                    if done[dl[doff[q]: doff[q + 1]]].all():
+                        lo = lay[layer_of_patch[q] - 1] - 1
+                        e0, e1 = ps["patch_ent_off"][q], ps["patch_ent_off"][q + 1]
+                        sites = store[ps["entry_pos"][e0:e1].astype(np.int64)]
+                        u = srank[np.concatenate([up[sites, 0], up[sites, 1]]) - 1]
+                        assert final[u[u < lo]].all()
+                        final[ps["patch_own_lo"][q]: ps["patch_own_lo"][q] + ps["patch_own_cnt"][q]] = True
+                        done[q] = True
+                    else:
+                        rest.append(q)
+                assert len(rest) < len(pending)                 # no cycle
+                pending = rest
+            assert final.all()
 
 
 def test_schedule_rejects_site_without_upwind(bcc_small):

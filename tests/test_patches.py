@@ -74,27 +74,25 @@ def test_patches_J_matches_oracle_and_steps(grids, name, own, nlam, monkeypatch)
 @pytest.mark.parametrize("shape", [(1, 1, 256), (1, 1, 512), (1, 1, 1024), (2, 1, 256), (2, 1, 512), (1, 2, 256),
                                    (1, 2, 512), (1, 2, 1024), (2, 2, 512)])
 @pytest.mark.parametrize("f32", [False, True])
-@pytest.mark.parametrize("variant", ["plain", "lean", "pipe", "block8", "block8-lean", "block4-pipe", "duo", "block4-duo"])
+@pytest.mark.parametrize("variant", ["plain", "lean", "chain", "block8", "block8-lean"])
 def test_every_patch_kernel_instantiation(grids, shape, f32, variant, monkeypatch):
     """Every (entries per thread, wavelength pairs, threads) instantiation of k_patch_solve, fp64 and fp32
     storage: same results (fp64: to rounding; fp32: 5e-6 against the fp64 oracle on the rounded inputs).
     Variants: the 64-register kernel (VRT_PATCH_LEAN, the default of the (1, 1, NT) shapes; "plain" = the 72-register
-    one), the software-pipelined kernel (VRT_PATCH_PIPE), the two-pairs-per-step
-    kernel for doubles (VRT_PATCH_DUO; floats run k_patch_quad or, with an odd pair count as here, the pair kernel)
-    and the storage layout with 8 / 4 wavelength pairs of a site side by side (VRT_PAIR_BLOCK; 9 wavelengths = 5
-    pairs: blocks 4 + 1)."""
+    one) with one launch per layer, the chained launch (VRT_PATCH_CHAIN, the default: k_patch_chain; floats with an odd pair
+    count as here run the pair kernel inside it) and the storage layout with 8 wavelength pairs of a site side by
+    side (VRT_PAIR_BLOCK; 9 wavelengths = 5 pairs: blocks 4 + 1)."""
     import torch
     hs, so = grids["voronoi"]
     K, Q, NT = shape
-    if "pipe" in variant and (K, Q) != (1, 1):
-        pytest.skip("the pipelined kernel exists for one entry per thread, one pair at a time")
-    if "duo" in variant and (K, Q) != (1, 1):
-        pytest.skip("the two-pair kernel replaces the (1, 1, NT) shapes")
-    if "lean" in variant and (K, Q) != (1, 1):
+    if ("lean" in variant or variant == "chain") and (K, Q) != (1, 1):
         pytest.skip("the 64-register kernel replaces the (1, 1, NT) shapes")
-    monkeypatch.setenv("VRT_PATCH_LEAN", "1" if "lean" in variant else "0")
-    monkeypatch.setenv("VRT_PATCH_DUO", "1" if "duo" in variant else "0")
-    monkeypatch.setenv("VRT_PATCH_PIPE", "1" if "pipe" in variant else "0")
+    if variant == "chain" and NT != 512:
+        pytest.skip("the chained launch exists for 512-thread workgroups")
+    monkeypatch.setenv("VRT_PATCH_LEAN", "1" if ("lean" in variant or variant == "chain") else "0")
+    monkeypatch.setenv("VRT_PATCH_CHAIN", "1" if variant == "chain" else "0")
+    if variant == "chain" and f32:          # 5 pairs: floats in blocks of two pairs would need sibling workgroups (per-layer launches)
+        monkeypatch.setenv("VRT_PATCH_QUAD", "0")
     monkeypatch.setenv("VRT_PAIR_BLOCK", "8" if "block8" in variant else "4" if "block4" in variant else "1")
     monkeypatch.setenv("VRT_PATCH_K", str(K))
     monkeypatch.setenv("VRT_PATCH_Q", str(Q))
@@ -115,6 +113,7 @@ def test_every_patch_kernel_instantiation(grids, shape, f32, variant, monkeypatc
                      dI0_up=Ud.data_ptr(), dI0_down=Dd.data_ptr(), stream=st, f32=f32)
     torch.cuda.synchronize()
     assert plan.last_path == "patches"
+    assert (plan.last_launches == 1) == (variant == "chain")
     r = lambda x: x.astype(npdt).astype(np.float64)
     ref = orc.J_voronoi(w, th, ph, r(S), r(al), so, I0_up=r(I0u), I0_down=r(I0d), nthreads=4)
     assert _rel(Jd.cpu().numpy().astype(np.float64), ref) < (5e-6 if f32 else RTOL)
@@ -123,11 +122,12 @@ def test_every_patch_kernel_instantiation(grids, shape, f32, variant, monkeypatc
 
 @pytest.mark.parametrize("f32", [False, True])
 def test_kernel_variants_agree_bit_for_bit(grids, f32, monkeypatch):
-    """The 64-register kernel (default), the 72-register one, the pipelined one and the two-pairs-per-step one
-    evaluate the same expressions in the same order: J and the per-angle intensities are bitwise equal."""
+    """The chained launch (default), the 64-register kernel launched per layer and the 72-register one
+    evaluate the same expressions in the same order on the same values: J and the per-angle intensities are bitwise
+    equal (fp32 storage, 16 wavelengths: the chained launch runs k_patch_quad's pair loop with VRT_PATCH_QUAD=1)."""
     import torch
     hs, so = grids["bcc"]
-    n, nlam = so.n, 14
+    n, nlam = so.n, 16                  # 8 pairs: an even count, so that fp32 storage can take them four wavelengths at a time
     w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
@@ -140,11 +140,12 @@ def test_kernel_variants_agree_bit_for_bit(grids, f32, monkeypatch):
     Sd, Ad, Ud, Dd = f(S), f(al), f(I0u), f(I0d)
     got = {}
     for name, env in (("lean", {"VRT_PATCH_LEAN": "1"}), ("plain", {"VRT_PATCH_LEAN": "0"}),
-                      ("pipe", {"VRT_PATCH_LEAN": "0", "VRT_PATCH_PIPE": "1"}),
-                      ("duo", {"VRT_PATCH_LEAN": "0", "VRT_PATCH_DUO": "1"})):
-        if name == "duo" and f32:
+                      ("chain", {"VRT_PATCH_LEAN": "1", "VRT_PATCH_CHAIN": "1"}),
+                      ("chain-quad", {"VRT_PATCH_LEAN": "1", "VRT_PATCH_CHAIN": "1", "VRT_PATCH_QUAD": "1"}),
+                      ("lean-quad", {"VRT_PATCH_LEAN": "1", "VRT_PATCH_QUAD": "1"})):
+        if "quad" in name and not f32:
             continue
-        for k in ("VRT_PATCH_LEAN", "VRT_PATCH_PIPE", "VRT_PATCH_DUO"):
+        for k in ("VRT_PATCH_LEAN", "VRT_PATCH_CHAIN", "VRT_PATCH_QUAD"):
             monkeypatch.setenv(k, env.get(k, "0"))
         plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
         Jd = torch.full((n, nlam), float("nan"), dtype=dt, device=dev)
@@ -153,6 +154,7 @@ def test_kernel_variants_agree_bit_for_bit(grids, f32, monkeypatch):
                          dI0_up=Ud.data_ptr(), dI0_down=Dd.data_ptr(), dI_out=Id.data_ptr(), stream=st, f32=f32)
         torch.cuda.synchronize()
         assert plan.last_path == "patches"
+        assert (plan.last_launches == 1) == ("chain" in name)
         got[name] = (Jd.cpu().numpy(), Id.cpu().numpy())
         plan.close()
     for name in got:

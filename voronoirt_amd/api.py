@@ -351,6 +351,12 @@ class FormalPlan:
         return ms.value, launches.value
 
     @property
+    def last_launches(self) -> int:
+        """Kernel launches of the last execute's sweep (1: the chained patch launch); waits for it to finish and
+        raises if a chained launch gave up waiting for a dependency."""
+        return int(self.last_sweep_timing()[1])
+
+    @property
     def last_path(self) -> str:
         """Device path of the last execute: "levels", "tiles" or "steps" ("" before the first)."""
         return {0: "", 1: "levels", 2: "tiles", 3: "steps", 4: "patches"}[int(_lib.load().vrt_plan_last_path(self._h))]
@@ -538,6 +544,10 @@ def build_patch_schedule(sites: VoronoiSites, dir: int, up, n_sweeps: int = 3, o
                                        out["patch_nlev"].ctypes.data_as(_lib.p_i32), _i(out["patch_ent_off"]),
                                        out["entry_pos"].ctypes.data_as(_lib.p_i32),
                                        out["entry_vis"].ctypes.data_as(u32), out["entry_loc"].ctypes.data_as(u32)))
+        out["dep_off"] = np.zeros(P + 1, dtype=np.int64)
+        check(L.vrt_patch_schedule_get_deps(h, _i(out["dep_off"]), None))
+        out["dep_list"] = np.zeros(int(out["dep_off"][-1]), dtype=np.int32)
+        check(L.vrt_patch_schedule_get_deps(h, None, out["dep_list"].ctypes.data_as(_lib.p_i32)))
     finally:
         L.vrt_patch_schedule_destroy(h)
     out.update(patches=P, entries=E, visits=int(cnt[2]), live_visits=int(cnt[3]), max_entries=int(cnt[4]))

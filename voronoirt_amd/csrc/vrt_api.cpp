@@ -25,7 +25,7 @@ void tuning_from_env(Tuning &t)
     static const char *names[] = {"VRT_PATH", "VRT_STEP_K", "VRT_STEP_SINGLE", "VRT_STEP_PAIRS", "VRT_STEP_XCD",
                                   "VRT_STEP_STREAMS", "VRT_STEP_LEVEL_MAP", "VRT_STEP_GROUP_DIR", "VRT_TILE_WIDE",
                                   "VRT_TILE_PRE", "VRT_GRAPH", "VRT_PATCH_K", "VRT_PATCH_NT", "VRT_PATCH_OWN",
-                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_PIPE", "VRT_PATCH_QUAD", "VRT_PATCH_DUO", "VRT_PATCH_LEAN", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
+                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_QUAD", "VRT_PATCH_LEAN", "VRT_PATCH_CHAIN", "VRT_CHAIN_PAIRS", "VRT_CHAIN_SPIN", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
                                   "VRT_TILE_DEBUG"};
     for (const char *nm : names) {
         const char *e = std::getenv(nm);
@@ -56,7 +56,9 @@ int tuning_set(Tuning &t, const char *name, const char *value, bool created)
         {"VRT_PATCH_K", &t.patch_K, 1, 8, true}, {"VRT_PATCH_NT", &t.patch_NT, 64, 1024, true},
         {"VRT_PATCH_OWN", &t.patch_own, 0, 65535, true}, {"VRT_PATCH_Q", &t.patch_Q, 1, 4, false},
         {"VRT_PATCH_TARGET", &t.patch_target, 1, 1 << 20, false}, {"VRT_PAIR_BLOCK", &t.pair_block, 1, 16, true},
-        {"VRT_PATCH_PIPE", &t.patch_pipe, 0, 2, false}, {"VRT_PATCH_QUAD", &t.patch_quad, 0, 1, true}, {"VRT_PATCH_DUO", &t.patch_duo, 0, 1, false}, {"VRT_PATCH_LEAN", &t.patch_lean, 0, 1, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
+        {"VRT_PATCH_QUAD", &t.patch_quad, 0, 1, true}, {"VRT_PATCH_LEAN", &t.patch_lean, 0, 1, false},
+        {"VRT_PATCH_CHAIN", &t.patch_chain, 0, 1, false}, {"VRT_CHAIN_PAIRS", &t.chain_pairs, 1, 256, false},
+        {"VRT_CHAIN_SPIN", &t.chain_spin, 1, 1 << 20, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
         {"VRT_DEBUG_SKIP_LEVELS", &t.debug_skip_levels, 0, 1, false}, {"VRT_TILE_DEBUG", &t.tile_debug, 0, 1, false},
     };
     for (auto &o : tab)
@@ -242,6 +244,11 @@ static void free_plan(vrt_plan *p)
     dev_free(p->d_step_angles);
     dev_free(p->d_level_map);
     dev_free(p->d_patch_rec); dev_free(p->d_patch_rec2); dev_free(p->d_patch_work);
+    dev_free(p->d_chain_items); dev_free(p->d_chain_deps); dev_free(p->d_chain_progress); dev_free(p->d_chain_ctrl);
+    if (p->h_chain_status) { (void)hipHostFree(p->h_chain_status); p->h_chain_status = nullptr; }
+    if (p->d_chain_dev) { (void)hipFree(p->d_chain_dev); p->d_chain_dev = nullptr; }
+    if (p->h_chain_dev_pinned) { (void)hipHostFree(p->h_chain_dev_pinned); p->h_chain_dev_pinned = nullptr; }
+    if (p->chain_dev_ev) (void)hipEventDestroy(p->chain_dev_ev);
     dev_free(p->e_pos); dev_free(p->e_u1); dev_free(p->e_u2); dev_free(p->e_vis); dev_free(p->e_loc);
     dev_free(p->e_w1); dev_free(p->e_w2); dev_free(p->e_r1); dev_free(p->e_r2);
     if (p->step_fork) (void)hipEventDestroy(p->step_fork);
@@ -600,6 +607,9 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                                                            (int)(ps.patch_ent_off[q + 1] - ps.patch_ent_off[q]),
                                                            ps.patch_own_lo[q], ps.patch_own_cnt[q]));
                         rec2.push_back(make_int2(ps.patch_nlev[q], a));
+                        p->h_patch_dep_off.push_back((int64_t)p->h_patch_deps.size());
+                        for (int64_t j = ps.dep_off[q]; j < ps.dep_off[q + 1]; j++)
+                            p->h_patch_deps.push_back(pbase + ps.dep_list[(size_t)j]);
                     }
                     if (ne_a) {
                         if (hipMemcpy(p->e_pos + ent_base, ps.entry_pos.data(), sizeof(int32_t) * ne_a, hipMemcpyHostToDevice) != hipSuccess ||
@@ -635,6 +645,10 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             VRT_TRY_FREE(dev_alloc(&p->d_angle_dir, (size_t)A));
             VRT_HIP_TRY_FREE(hipMemcpy(p->d_nlev, nlev.data(), sizeof(int32_t) * nlev.size(), hipMemcpyHostToDevice));
             VRT_HIP_TRY_FREE(hipMemcpy(p->d_angle_dir, adir.data(), sizeof(int32_t) * A, hipMemcpyHostToDevice));
+            if (patch_ok) {
+                p->h_patch_dep_off.push_back((int64_t)p->h_patch_deps.size());
+                p->h_patch_rec2 = rec2;
+            }
             if (patch_ok && n_patches) {
                 VRT_HIP_TRY_FREE(hipMemcpy(p->d_patch_rec, p->h_patch_rec.data(), sizeof(int4) * (size_t)n_patches, hipMemcpyHostToDevice));
                 VRT_HIP_TRY_FREE(hipMemcpy(p->d_patch_rec2, rec2.data(), sizeof(int2) * (size_t)n_patches, hipMemcpyHostToDevice));
@@ -1174,6 +1188,15 @@ int vrt_patch_schedule_get(const vrt_patch_schedule *s, int32_t *layer_patch_off
     return VRT_OK;
 }
 
+int vrt_patch_schedule_get_deps(const vrt_patch_schedule *s, int64_t *dep_off, int32_t *dep_list)
+{
+    if (!s) return fail(VRT_EINVAL, "NULL schedule");
+    const PatchSchedule &p = s->s;
+    if (dep_off) std::copy(p.dep_off.begin(), p.dep_off.end(), dep_off);
+    if (dep_list) std::copy(p.dep_list.begin(), p.dep_list.end(), dep_list);
+    return VRT_OK;
+}
+
 void vrt_patch_schedule_destroy(vrt_patch_schedule *s) { delete s; }
 
 int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out)
@@ -1335,7 +1358,8 @@ int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches)
     VRT_HIP_TRY(hipEventElapsedTime(&t, p->ev0, p->ev1));
     if (ms) *ms = (double)t;
     if (launches) *launches = p->last_launches;
-    return VRT_OK;
+    // the sweep has finished: a chained launch that gave up waiting for a dependency is reported here (or by the next execute)
+    return patch_chain_check(const_cast<vrt_plan *>(p));
 }
 
 int vrt_plan_last_path(const vrt_plan *p) { return p ? p->last_path : 0; }

@@ -81,13 +81,14 @@ struct Tuning {
     int pair_block = 1;           // VRT_PAIR_BLOCK: wavelength pairs of a site kept side by side in the patch path's
                                   //   storage layout, 1 / 2 / 4 / 8 / 16 (vrt_device.h; creation only: the native
                                   //   per-angle alpha of the plan is laid out with it)
-    int patch_pipe = 0;           // VRT_PATCH_PIPE: the software-pipelined kernel for the (1, 1, NT) shapes: 0 off, 1 on,
-                                  //   2 = with fp32 storage only (within the noise everywhere: DESIGN.md section 5)
     int patch_quad = 1;           // VRT_PATCH_QUAD: fp32 storage in blocks of >= 2 pairs, four wavelengths per lane
                                   //   (k_patch_quad; creation only: the native float alpha is laid out with it)
     int patch_lean = 1;           // VRT_PATCH_LEAN: the 64-register form of the (1, 1, NT) kernel (four workgroups per CU;
                                   //   default for two and more wavelength pairs)
-    int patch_duo = 0;            // VRT_PATCH_DUO: fp64 storage, two wavelength pairs per workgroup step (k_patch_duo)
+    int patch_chain = 1;          // VRT_PATCH_CHAIN: every layer inside ONE persistent launch (k_patch_chain) instead of one
+                                  //   launch per layer and direction; 0 = the per-layer launches
+    int chain_pairs = 5;          // VRT_CHAIN_PAIRS: wavelength-pair blocks an item of the chained launch solves
+    int chain_spin = 2048;        // VRT_CHAIN_SPIN: polls (x 1024) after which a waiting workgroup gives up (~2 s)
     int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
     int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)
 };
@@ -221,6 +222,23 @@ struct vrt_plan {
     int32_t *e_pos = nullptr, *e_u1 = nullptr, *e_u2 = nullptr;
     uint32_t *e_vis = nullptr, *e_loc = nullptr;
     double *e_w1 = nullptr, *e_w2 = nullptr, *e_r1 = nullptr, *e_r2 = nullptr;
+    std::vector<int2> h_patch_rec2;      // per patch: levels, active angle
+    std::vector<int64_t> h_patch_dep_off;   // per patch: the patches (plan-wide indices) whose stored intensities it gathers
+    std::vector<int32_t> h_patch_deps;      //   (vrt_patch.cpp: dep_list) -- what the chained launch waits on
+    // chained launch (vrt_patch.hip: k_patch_chain): items per XCD queue, dependency lists, progress words
+    int4 *d_chain_items = nullptr;
+    int32_t *d_chain_deps = nullptr;
+    uint32_t *d_chain_progress = nullptr, *d_chain_ctrl = nullptr;
+    uint32_t *h_chain_status = nullptr, *d_chain_status = nullptr;   // mapped host word: a launch gave up
+    void *d_chain_dev = nullptr, *h_chain_dev_pinned = nullptr;       // the launch's argument block (ChainDev) and its staging copy
+    std::vector<char> h_chain_dev;                                    //   what the device copy holds
+    hipEvent_t chain_dev_ev = nullptr;
+    bool chain_dev_ev_valid = false;
+    size_t chain_progress_cap = 0;
+    int chain_q_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int chain_npair = -1, chain_lgB = -1, chain_nsplit = -1, chain_reduce = -1;
+    int64_t chain_items = 0;
+    uint32_t chain_epoch = 0;
     int32_t *d_patch_work = nullptr;     // work lists of the launches (ensure_patch_work)
     std::vector<int64_t> patch_work_off; //   [group][layer] offsets into it
     int patch_work_groups = 0;
@@ -286,6 +304,8 @@ struct PatchSchedule {
     std::vector<int32_t> entry_pos;         // storage position of the entry's site
     std::vector<uint32_t> entry_vis;        // up to 4 x 8-bit visit levels the patch executes for it, increasing
     std::vector<uint32_t> entry_loc;        // patch-local tile slots of its two upwinds, 16 bits each; 0xFFFF: reads 0
+    std::vector<int64_t> dep_off;           // patches of EARLIER layers whose stored intensities patch q gathers:
+    std::vector<int32_t> dep_list;          //   dep_list[dep_off[q] .. dep_off[q+1]), sorted (chained launch: what q waits for)
     int64_t n_visits = 0;                   // visits executed over all patches (halo visits counted per patch)
     int64_t n_live = 0;                     // live visits of the unsplit schedule
     int64_t max_entries = 0;
@@ -364,5 +384,8 @@ int launch_patch_entries(vrt_plan *p, int a, int64_t first, int64_t count);
 int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angles, const std::vector<int> &group_off);
 int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, int group, int Q, hipStream_t st,
                        bool f32, const PatchReduce *reduce);
+bool patch_chain_possible(const vrt_plan *p, int npair, bool f32);
+int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t st, bool f32, const PatchReduce *reduce);
+int patch_chain_check(vrt_plan *p);
 
 }  // namespace vrt

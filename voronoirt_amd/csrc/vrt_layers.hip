@@ -454,6 +454,30 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             return r > 0;
         };
         sa.level_map = nullptr;
+        // ---- patches, chained: every layer of every angle inside ONE persistent launch (vrt_patch.hip: k_patch_chain) ----
+        const bool chain = patches && patch_chain_possible(p, npair, kF32);
+        if (chain) {
+            // the layout changes of a direction may have run on an internal stream: the launch follows both
+            for (int d = 0; d < 2; d++)
+                for (int gi = 1; gi < G; gi++)
+                    if (use_dir[d] && dir_st[d] == p->step_stream[gi]) {
+                        VRT_HIP_TRY(hipEventRecord(p->step_join[gi], p->step_stream[gi]));
+                        VRT_HIP_TRY(hipStreamWaitEvent(st, p->step_join[gi], 0));
+                    }
+            VRT_HIP_TRY(hipEventRecord(p->ev0, st));
+            PatchReduce red = red_tmpl;
+            if (dJ)
+                for (int d = 0; d < 2; d++) {
+                    red.count[d] = 0;
+                    red.Jd[d] = use_dir[d] ? p->ws_J[d] : nullptr;
+                    for (int a = 0; a < A; a++)
+                        if ((p->dir_of_active[(size_t)a] > 0) == (d == 0)) red.angles[d][red.count[d]++] = a;
+                    fused_dir[d] = use_dir[d];
+                }
+            if ((rc = launch_patch_chain(p, sa.ta, npair, st, kF32, dJ ? &red : nullptr))) return rc;
+            launches = 1;
+            VRT_HIP_TRY(hipEventRecord(p->ev1, st));
+        } else {
         VRT_HIP_TRY(hipEventRecord(p->ev0, st));
         VRT_HIP_TRY(hipEventRecord(p->step_fork, st));
         launches = 0;
@@ -547,6 +571,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             }
         VRT_HIP_TRY(hipGetLastError());
         VRT_HIP_TRY(hipEventRecord(p->ev1, st));
+        }
     } else {
         if constexpr (!kF32) {
             if (debug && hipMalloc((void **)&d_dbg, sizeof(long long) * 4 * (size_t)A * (size_t)nlam) == hipSuccess) ta.dbg = d_dbg;

@@ -127,8 +127,11 @@ void build_patch_schedule(const Direction &dir, bool ascending, int64_t n, int n
         if (live[x]) last_live[tr.site[x]] = (int32_t)x;
     std::vector<int32_t> stamp(T, -1);               // patch that has marked the visit
     std::vector<int32_t> slot_of((size_t)n, -1), in_patch((size_t)n, -1);   // local tile slot of a site / patch it is an entry of
-    std::vector<int32_t> stack, marked, sites, new_marks, new_sites, halo, llw, llr;
+    std::vector<int32_t> stack, marked, sites, new_marks, new_sites, halo, llw, llr, deps;
+    std::vector<int32_t> owner((size_t)n, -1);      // site -> patch that owns it (stores its final intensity); -1: the
+                                                    //   boundary layer and the never-visited last site (nobody stores them)
     int32_t patch_id = 0;
+    out.dep_off.push_back(0);
 
     for (int64_t layer = 2; layer <= nl - 1; layer++) {
         out.layer_patch_off[(size_t)layer] = patch_id;
@@ -224,6 +227,7 @@ void build_patch_schedule(const Direction &dir, bool ascending, int64_t n, int n
                 v |= (uint32_t)lv << sh;
                 nlev = std::max(nlev, lv);
             }
+            deps.clear();
             for (int64_t e = e0; e < (int64_t)out.entry_pos.size(); e++) {
                 const int32_t i = dir.store[(size_t)out.entry_pos[(size_t)e]];
                 uint32_t l[2];
@@ -231,9 +235,18 @@ void build_patch_schedule(const Direction &dir, bool ascending, int64_t n, int n
                     const int32_t u = q == 0 ? up1[i] : up2[i];
                     l[q] = (dir.layer_of[(size_t)u] == layer && in_patch[(size_t)u] == patch_id) ? (uint32_t)slot_of[(size_t)u]
                                                                                                   : 0xFFFFu;
+                    // an upwind in an EARLIER layer is read from memory as the final value its owner patch stored
+                    // (one in a later layer reads as 0, :23): the patches this one waits for when the layers are
+                    // chained inside one launch (vrt_patch.hip: k_patch_chain)
+                    if (dir.layer_of[(size_t)u] < layer && owner[(size_t)u] >= 0) deps.push_back(owner[(size_t)u]);
                 }
                 out.entry_loc[(size_t)e] = l[0] | (l[1] << 16);
             }
+            std::sort(deps.begin(), deps.end());
+            deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
+            out.dep_list.insert(out.dep_list.end(), deps.begin(), deps.end());
+            out.dep_off.push_back((int64_t)out.dep_list.size());
+            for (int32_t j = 0; j < own_cnt; j++) owner[(size_t)dir.store[(size_t)(own_lo + j)]] = patch_id;
             out.patch_own_lo.push_back(own_lo);
             out.patch_own_cnt.push_back(own_cnt);
             out.patch_ent_off.push_back(e0);

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "vrt_device.h"
 #include "vrt_internal.h"
@@ -34,7 +35,6 @@ struct PatchArgs {
     int stride;               // tile slots per pair plane (> largest entry count: + the zero slot)
     int cap;                  // entries per patch at most (K * NT): length of the LDS table arrays
     int quad;                 // fp32 storage: k_patch_quad (two neighbouring pairs of a block per workgroup)
-    int duo;                  // fp64 storage: k_patch_duo (two pairs per step, one level loop)
     int lean;                 // k_patch_lean (64 registers: four workgroups per CU)
     int dbg;                  // timing diagnostics (-DVRT_DIAG build only, WRONG results): 1 no levels, 2 gathers ->
                               //   coalesced centre reads, 4 no weights arithmetic, 8 no stores, 16 / 32 / 64 no upwind gathers
@@ -79,26 +79,42 @@ int launch_patch_entries(vrt_plan *p, int a, int64_t first, int64_t count)
     return VRT_OK;
 }
 
-// exp(-x) for 5e-4 <= x <= 50 to ~2e-13 relative (the parity contract is 1e-10): Cody-Waite reduction as
-// exp_neg (vrt_device.h), Taylor to r^10/10! (remainder 0.3466^11/11! = 2e-13)
+// exp(-x) for 5e-4 <= x <= 50, table-driven: -x = N ln2/32 + r with |r| <= ln2/64, exp(-x) = 2^(N >> 5) T[N & 31] p(r),
+// T[j] = 2^(j/32) from a 32-entry LDS table (one 8-byte read per evaluation, conflict-free: the 32 entries cover the
+// 64 banks once) and p the degree-5 Taylor polynomial (remainder r^6/720 < 2.3e-15).  Against the degree-10 polynomial
+// on |r| <= ln2/2 it replaces: four fused multiply-adds fewer per evaluation, and five of its eleven non-inline fp64
+// constants -- ten scalar registers of a kernel that is short of exactly those.  Relative error ~3e-15 (contract 1e-10).
+__device__ const double kExp2_32[32] = {
+    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237, 1.0905077326652577, 1.1143867425958924,
+    1.1387886347566916, 1.1637248587775775, 1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332,
+    1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832, 1.4142135623730951, 1.4451808069770467,
+    1.4768261459394993, 1.5091644275934228, 1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965,
+    1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072, 1.8340080864093424, 1.8741676341103,
+    1.9152065613971474, 1.9571441241754002};
+__device__ __forceinline__ double *exp2_table()
+{
+    __shared__ double t[32];
+    return t;
+}
+// every patch kernel: fill the table, then a barrier before the first evaluation
+__device__ __forceinline__ void exp2_table_fill()
+{
+    if (threadIdx.x < 32) exp2_table()[threadIdx.x] = kExp2_32[threadIdx.x];
+}
 __device__ __forceinline__ double exp_neg10(double x)
 {
     const double t = -x;
-    const double kf = rint(t * 1.4426950408889634074);
-    double r = fma(-kf, 6.93147180369123816490e-01, t);
-    r = fma(-kf, 1.90821492927058770002e-10, r);
-    double p = 1.0 / 3628800.0;
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
+    const double nf = rint(t * 46.16624130844683);            // N = round(t 32 / ln 2), |N| <= 2309
+    double r = fma(-nf, 0.021660849335603416, t);             // Cody-Waite: ln2/32 = hi (29 bits) + lo
+    r = fma(-nf, 5.689487495325457e-11, r);                   // |r| <= 0.01084
+    const int N = (int)nf;
+    double p = 1.0 / 120.0;
     p = fma(p, r, 1.0 / 24.0);
     p = fma(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(p, (int)kf);
+    return ldexp(p * exp2_table()[N & 31], N >> 5);
 }
 
 // The kernel is bound by its fp64 arithmetic (two exponentials and a dozen weights per site, angle and
@@ -176,7 +192,7 @@ __device__ __forceinline__ void entry_lambda(double rh1, double rh2, double w1, 
 
 // The same, one upwind at a time: `next` (the optical depth the following evaluation starts from) is tied to this
 // one's results by a compiler fence, so that the four evaluations of an entry's pair follow each other instead of
-// being interleaved -- the pipelined kernel holds the next pair's 32 landed registers while it computes.  The
+// being interleaved (the compiler's own order needs 72 registers, this one 64).  The
 // weights w_r are read from the thread's LDS slots where they are used (pw1, pw2), not held.
 template <int MODE>
 __device__ __forceinline__ void entry_terms_seq(double dt1, double dt2, const double *pw1, const double *pw2, bool in1,
@@ -221,13 +237,13 @@ template <> struct Log2Size<float2> { static constexpr int value = 3; };
 
 // blocks [b0, b1) of split number `split`: the steps (Q blocks each) are dealt evenly, the first (steps % nsplit)
 // splits taking one more (26 pairs over 5 splits: 6, 5, 5, 5, 5 -- not 6, 6, 6, 6, 2)
-__device__ __forceinline__ void split_blocks(const PatchArgs &pa, int split, int nblock, int &b0, int &b1)
+__host__ __device__ __forceinline__ void split_blocks(const PatchArgs &pa, int split, int nblock, int &b0, int &b1)
 {
     const int nstep = (nblock + pa.Q - 1) / pa.Q;
     const int base = nstep / pa.nsplit, rem = nstep - base * pa.nsplit;
-    const int s0 = split * base + min(split, rem), s1 = s0 + base + (split < rem ? 1 : 0);
+    const int s0 = split * base + (split < rem ? split : rem), s1 = s0 + base + (split < rem ? 1 : 0);
     b0 = s0 * pa.Q;
-    b1 = min(nblock, s1 * pa.Q);
+    b1 = nblock < s1 * pa.Q ? nblock : s1 * pa.Q;
 }
 
 // ---- reduction role of a patch launch: J_dir of a finished layer (NT x ppb pair elements per block) --------------
@@ -281,9 +297,6 @@ __device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
 #define VRT_WPE_ATTR __attribute__((amdgpu_waves_per_eu(VRT_PATCH_WPE, VRT_PATCH_WPE)))
 #else
 #define VRT_WPE_ATTR
-#endif
-#ifndef VRT_PIPE_ATTR            // the pipelined kernel: 80 VGPRs = three 512-thread workgroups per CU (no scratch at that budget)
-#define VRT_PIPE_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
 #endif
 template <typename T, int AM, int K, int Q, int NT>
 __global__ void __launch_bounds__(NT) VRT_WPE_ATTR
@@ -353,6 +366,8 @@ k_patch_solve(PatchArgs pa)
 #pragma unroll
         for (int qi = 0; qi < Q; qi++) ptile[qi * stride + n_ent] = make_double2(0.0, 0.0);   // the zero slot
     }
+    exp2_table_fill();
+    __syncthreads();
     constexpr int lgT2 = Log2Size<T2>::value;
     for (int bk = b0; bk < b1; bk += Q) {
         // the Q pairs of this step: (element base of the block + sibling, byte shift of a site); a step past the
@@ -472,7 +487,7 @@ k_patch_solve(PatchArgs pa)
 }
 
 
-// ---- what the one-entry-per-thread kernels (k_patch_pipe, k_patch_quad, k_patch_duo) share ----------------------------
+// ---- what the one-entry-per-thread kernels (k_patch_lean, k_patch_quad, k_patch_chain) share --------------------------
 // the work of this workgroup: patch, sibling number inside a pair block, blocks [b0, b1), the patch's record
 struct PatchItem {
     int sib, b0, b1;
@@ -515,7 +530,8 @@ struct EntryTable {
         vis = reinterpret_cast<uint32_t *>(u2 + CAP);
         loc = vis + CAP;
     }
-    __device__ __forceinline__ void park(const PatchArgs &pa, const PatchItem &it, int tid) const
+    template <typename Tables>       // PatchArgs, or any record with its e_* pointers
+    __device__ __forceinline__ void park(const Tables &pa, const PatchItem &it, int tid) const
     {
         const bool ok = tid < it.n_ent;
         const int e = it.ent_off + (ok ? tid : it.n_ent - 1);
@@ -530,127 +546,273 @@ struct EntryTable {
     }
 };
 
-// ---- the default shape (one entry per thread, one pair at a time), software-pipelined ------------------------------
-// A workgroup's pair costs ~15 000 cycles end to end: ~6 000 waiting for the eight gathers of an entry, ~1 500 of
-// arithmetic, ~7 000 in the level loop (a barrier and an LDS round trip per level, ~18 levels on an inclined
-// direction).  Here the gathers of the NEXT pair are issued before the level loop of the current one and land
-// while it runs: their destination registers (32) are live across the loop instead of the arithmetic's
-// temporaries, so the kernel keeps its 3 workgroups per CU.
-template <typename T, int AM> struct PatchRaw {
-    typedef typename Pair<T>::type T2;
-    T2 S_c, S_1, S_2, I_1, I_2, a_c, a_1, a_2;           // AM == VRT_ALPHA_SITE: .x of the alphas only
+// what the pair loop of an item reads besides its entry table: the planes of the item's direction / angle
+struct PairIO {
+    int n;                     // sites (< 2^28 on this path: planes are addressed with 32-bit byte offsets)
+    int npair, lgB, dbg;
+    const void *S;             // S plane set of the item's direction
+    const void *alpha;         // alpha[d] (one opacity per site, or per site and wavelength) or alpha_angle (per angle)
+    void *I;
 };
+template <int AM>
+__device__ __forceinline__ PairIO pair_io(const PatchArgs &pa, int d)
+{
+    PairIO io;
+    io.n = (int)pa.ta.n; io.npair = pa.npair; io.lgB = pa.lgB; io.dbg = kDiag ? pa.dbg : 0;
+    io.S = pa.ta.S[d];
+    io.alpha = AM == VRT_ALPHA_ANGLE_SITE_LAM ? (const void *)pa.ta.alpha_angle : (const void *)pa.ta.alpha[d];
+    io.I = pa.ta.I;
+    return io;
+}
 
-template <typename T, int AM, int NT>
-__global__ void __launch_bounds__(NT) VRT_PIPE_ATTR
-k_patch_pipe(PatchArgs pa)
+// ---- chained launch (k_patch_chain): hand-off of final intensities between workgroups INSIDE one launch ----------------
+// The reference's loop nest is `for layer ... for sweep ... for site` (irregular_ray_tracing.jl:37-80): a layer reads the
+// final intensities of earlier layers.  With one launch per layer that order costs a kernel boundary per layer and a
+// chip that idles while a layer's slowest workgroups finish.  The chained form keeps the SAME items (patch, angle, block
+// of wavelength pairs) and the same arithmetic, but one persistent launch takes them from per-XCD queues in layer
+// order, and the only ordering left is the data's own: patch q waits for the patches that store the earlier-layer
+// upwind intensities it gathers (vrt_patch.cpp: dep_list), wavelength pair by wavelength pair.
+//   producer: the intensities of a pair leave with write-through (sc1) stores; every storing wave drains its stores
+//     (s_waitcnt vmcnt(0)), the workgroup passes a barrier, ONE lane then stores the item's progress word = epoch base +
+//     pairs finished (agent-scope store) -- cdna_hip_programming.md Guideline 16, form R1;
+//   consumer: every wave polls the progress words of the item's dependencies (relaxed agent-scope loads, one lane per
+//     dependency) before it gathers the pair's intensities, and EVERY load of an intensity in this kernel is an sc1
+//     buffer load (never served by a CU's L1).  Nothing else is handed from workgroup to workgroup: S, alpha and the
+//     tables are read-only during the launch, J_dir is only written.
+// A workgroup waits only for items of EARLIER layers, every queue is in layer order and is taken in order, so the
+// oldest unfinished item of the launch never waits: no placement or residency assumption is needed for progress
+// (blocks x, x + 8, ... taking queue x is speed only: neighbouring patches meet in one L2).  Every spin is bounded
+// (ChainDev::spin_limit): on expiry the launch gives up, drains and reports through a host-visible status word.
+typedef unsigned int vrt_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int vrt_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = 16;                    // cache-policy bits of the buffer instructions: sc1 (agent scope)
+constexpr int kChainDepLds = 128;              // dependencies of an item kept in LDS (more: read from the global list)
+constexpr int kChainHeadStride = 32;           // 32-bit words between the queue heads (a 128-byte line each)
+constexpr int kChainAbortWord = 8 * kChainHeadStride;   // ctrl[] index of the give-up word
+
+// What a workgroup keeps in REGISTERS about the chain: nothing.  Scalar registers are the solver's scarcest resource
+// (it needs 72 of the 80 that eight waves per SIMD allow; every further one is spilled into a vector register's lanes,
+// and that register is the 64th of the 64 the solver needs).  The item's chain state -- progress words of its split,
+// epoch base, its own patch, its dependency list, the launch's argument block -- is parked in LDS behind the entry
+// table, and the polls and the publication read it from there into vector registers that are free at that point.
+struct ChainDev;
+// LDS words of the chained launch behind the entry table; then 64 + kChainDepLds dependency slots (patch indices, padded
+// with the item's own patch up to a multiple of 64: every lane of a poll has a word it may load)
+constexpr int kCtlItem = 0, kCtlSelf = 1, kCtlNdep = 2, kCtlDepOff = 3, kCtlArgsLo = 4, kCtlArgsHi = 5, kCtlProgLo = 6, kCtlProgHi = 7,
+              kCtlBase = 8, kCtlWords = 12;
+template <int CAP>
+__device__ __forceinline__ uint32_t *chain_ctl_slots(const EntryTable<CAP> &tab) { return tab.loc + CAP; }
+template <int CAP>
+__device__ __forceinline__ int32_t *chain_dep_slots(const EntryTable<CAP> &tab) { return reinterpret_cast<int32_t *>(tab.loc + CAP + kCtlWords); }
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t *chain_progress(const uint32_t *ctl)
+{
+    return reinterpret_cast<uint32_t *>(((uint64_t)ctl[kCtlProgHi] << 32) | (uint64_t)ctl[kCtlProgLo]);
+}
+// first look at the progress words of the dependencies (lane j: dependency j; lanes beyond the list look at the
+// item's own word and count as satisfied), issued ahead of its use.  `step`: pairs the dependencies must have published
+__device__ __forceinline__ uint32_t chain_peek(const int32_t *s_dep, int step)
+{
+    const uint32_t *ctl = reinterpret_cast<const uint32_t *>(s_dep - kCtlWords);
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t v = ld_agent(chain_progress(ctl) + s_dep[lane]);
+    const uint32_t target = ctl[kCtlBase] + (uint32_t)step;
+    return lane < (int)ctl[kCtlNdep] ? v - target : 0u;       // >= 0 as a signed number: reached (modulo 2^32: earlier launches carry smaller epochs)
+}
+__device__ __forceinline__ void chain_wait_slow(const int32_t *s_dep, int step);
+// returns once every dependency has published `step` pairs; `first`: what chain_peek saw
+__device__ __forceinline__ void chain_wait(const int32_t *s_dep, int step, uint32_t first)
+{
+    const uint32_t *ctl = reinterpret_cast<const uint32_t *>(s_dep - kCtlWords);
+    if (!__all((int)first >= 0 && ctl[kCtlNdep] <= 64u)) chain_wait_slow(s_dep, step);
+    // (no instruction: keeps the compiler from moving the gathers that follow above the poll)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// a pointer the compiler can keep in scalar registers (buffer descriptors must be wave-uniform)
+template <typename P>
+__device__ __forceinline__ P *uniform_ptr(P *p)
+{
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (P *)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+// agent-scope (sc1) accesses of one plane block through a buffer descriptor: base + 32-bit byte offset
+template <typename V> struct BufSc1;
+template <> struct BufSc1<double2> {
+    static __device__ __forceinline__ double2 load(__amdgpu_buffer_rsrc_t rs, unsigned off)
+    {
+        const vrt_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, kAuxSc1);
+        double2 d;
+        __builtin_memcpy(&d, &v, 16);
+        return d;
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, unsigned off, double2 d)
+    {
+        vrt_u32x4 v;
+        __builtin_memcpy(&v, &d, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, kAuxSc1);
+    }
+};
+template <> struct BufSc1<float4> {
+    static __device__ __forceinline__ float4 load(__amdgpu_buffer_rsrc_t rs, unsigned off)
+    {
+        const vrt_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, kAuxSc1);
+        float4 d;
+        __builtin_memcpy(&d, &v, 16);
+        return d;
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, unsigned off, float4 d)
+    {
+        vrt_u32x4 v;
+        __builtin_memcpy(&v, &d, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, kAuxSc1);
+    }
+};
+template <> struct BufSc1<float2> {
+    static __device__ __forceinline__ float2 load(__amdgpu_buffer_rsrc_t rs, unsigned off)
+    {
+        const vrt_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, kAuxSc1);
+        float2 d;
+        __builtin_memcpy(&d, &v, 8);
+        return d;
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, unsigned off, float2 d)
+    {
+        vrt_u32x2 v;
+        __builtin_memcpy(&v, &d, 8);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, 0, kAuxSc1);
+    }
+};
+// descriptor of `bytes` bytes at p (raw buffer, 32-bit offsets; cdna_hip_programming.md T8)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(uniform_ptr(p)), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+// an item's progress word: pairs (steps of its pair loop) whose intensities are stored and drained
+__device__ __forceinline__ void chain_publish(const int32_t *s_dep, int steps_done)
+{
+    const uint32_t *ctl = reinterpret_cast<const uint32_t *>(s_dep - kCtlWords);
+    st_agent(chain_progress(ctl) + ctl[kCtlSelf], ctl[kCtlBase] + (uint32_t)steps_done);
+}
+
+// ---- one pair at a time within 64 registers: FOUR workgroups per CU ---------------------------------------------------
+// No unit of the chip is saturated by the patch kernel; its phases (gathers, arithmetic, level loop) overlap only as
+// far as three 512-thread workgroups per CU allow (72 registers).  This form fits the 64 of a fourth: the three
+// alpha gathers first, the four optical depths from them (the alphas die), then the five S / I gathers in flight
+// while the weights are evaluated one after the other, each folded into its share of the visit as soon as it exists.
+// lean_pairs: the wavelength pairs [it.b0, it.b1) of one item, the patch's entry table parked in `tab`.  CHAIN: inside
+// the chained launch (intensities through sc1 buffer accesses, dependencies polled per pair, progress published).
+#ifndef VRT_LEAN_ATTR
+#define VRT_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+template <typename T, int AM, int NT, bool CHAIN>
+__device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it, const EntryTable<NT> &tab,
+                                           double2 *ptile)
 {
     typedef typename Pair<T>::type T2;
-    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
-    const TileArgs &ta = pa.ta;
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < pa.red.nred) {
-        patch_reduce_role<T, NT>(pa);
-        return;
-    }
-    PatchItem it;
-    if (!patch_item(pa, pa.lgB, it)) return;
-    const int sib = it.sib, b0 = it.b0, b1 = it.b1;
     constexpr int lgT2 = Log2Size<T2>::value;
-    const int64_t n = ta.n;
-    size_t qb;                                               // element base of the pair being loaded
-    int sh;
-    {
+    const unsigned n = (unsigned)pa.n;
+    const int dbg = kDiag ? pa.dbg : 0;
+    const T2 *Sd = reinterpret_cast<const T2 *>(pa.S);
+    const T2 *Ia = reinterpret_cast<const T2 *>(pa.I) + (size_t)it.a * pa.npair * (size_t)n;
+    auto at = [](const T2 *base, unsigned off) { return *reinterpret_cast<const T2 *>(reinterpret_cast<const char *>(base) + off); };
+    const int32_t *s_dep = chain_dep_slots(tab);
+    for (int bk = it.b0; bk < it.b1; bk++) {
         int k0, lw;
-        pair_block_of(b0, pa.npair, pa.lgB, k0, lw);
-        if (sib >= (1 << lw)) return;
-        qb = (size_t)k0 * (size_t)n + (size_t)sib;
-        sh = lw + lgT2;
-    }
-    const int n_ent = it.n_ent, own_lo = it.own_lo, own_cnt = it.own_cnt, nlev = it.nlev, a = it.a, d = it.d;
-    const int lo = it.lo, hi = it.hi;
-    constexpr int CAP = NT;
-    const EntryTable<CAP> tab(ptile, 1);
-    tab.park(pa, it, tid);
-    double *const s_w1 = tab.w1, *const s_w2 = tab.w2, *const s_r1 = tab.r1, *const s_r2 = tab.r2;
-    int *const s_pos = tab.pos, *const s_u1 = tab.u1, *const s_u2 = tab.u2;
-    uint32_t *const s_vis = tab.vis, *const s_loc = tab.loc;
-    if (tid == 0) ptile[n_ent] = make_double2(0.0, 0.0);     // the zero slot
-
-    const T2 *Sd = reinterpret_cast<const T2 *>(ta.S[d]);
-    const T2 *Ia = reinterpret_cast<const T2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n;
-    PatchRaw<T, AM> raw;
-    // the eight gathers of this thread's entry for the pair at element base qb (own slots of LDS: no barrier)
-    auto issue = [&]() {
-        const int p = s_pos[tid], v1 = s_u1[tid], v2 = s_u2[tid];
-        // an upwind's intensity counts when it lies in an EARLIER layer (final); otherwise the gather reads the
-        // never-visited site at storage position n - 1, whose intensity is 0 in every plane (:23)
-        const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
-        const unsigned op = (unsigned)p << sh, o1 = (unsigned)v1 << sh, o2 = (unsigned)v2 << sh;
-        auto at = [](const T2 *base, unsigned off) { return *reinterpret_cast<const T2 *>(reinterpret_cast<const char *>(base) + off); };
-        if constexpr (AM == VRT_ALPHA_SITE) {
-            const T *__restrict__ Al = reinterpret_cast<const T *>(ta.alpha[d]);
-            raw.a_c.x = Al[p]; raw.a_1.x = Al[v1]; raw.a_2.x = Al[v2];
-        } else {
-            const T2 *__restrict__ Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const T2 *>(ta.alpha[d]) + qb
-                                                                  : reinterpret_cast<const T2 *>(ta.alpha_angle) + (size_t)a * pa.npair * (size_t)n + qb;
-            raw.a_c = at(Al, op); raw.a_1 = at(Al, o1); raw.a_2 = at(Al, o2);
+        if constexpr (CHAIN) { k0 = bk; lw = 0; }            // the chained launch: one pair per block, no siblings
+        else {
+            pair_block_of(bk, pa.npair, pa.lgB, k0, lw);
+            if (it.sib >= (1 << lw)) break;                  // block widths only shrink
         }
-        raw.S_c = at(Sd + qb, op); raw.S_1 = at(Sd + qb, o1); raw.S_2 = at(Sd + qb, o2);
-        raw.I_1 = at(Ia + qb, (unsigned)i1 << sh); raw.I_2 = at(Ia + qb, (unsigned)i2 << sh);
-    };
-    issue();
-    for (int bk = b0;; bk++) {
-        // ---- integration coefficients of the entry for the pair that has landed ---------------------------------
+        const size_t qb = (size_t)k0 * (size_t)n + (size_t)(CHAIN ? 0 : it.sib);
+        const int sh = lw + lgT2;
+        uint32_t seen = 0;
+        if constexpr (CHAIN) seen = chain_peek(s_dep, bk - it.b0 + 1);   // in flight beside the alpha gathers
         double2 c, g1, g2;
         {
-            const int v1 = s_u1[tid], v2 = s_u2[tid];
-            const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
-            const double rh1 = 0.5 * s_r1[tid], rh2 = 0.5 * s_r2[tid];  // exact: r (α_c + α_u) / 2 = (r / 2)(α_c + α_u)
-            double2 a_c, a_1, a_2;
-            if constexpr (AM == VRT_ALPHA_SITE) {
-                a_c = make_double2((double)raw.a_c.x, (double)raw.a_c.x);
-                a_1 = make_double2((double)raw.a_1.x, (double)raw.a_1.x);
-                a_2 = make_double2((double)raw.a_2.x, (double)raw.a_2.x);
+            const int p = tab.pos[tid];
+            int v1 = tab.u1[tid], v2 = tab.u2[tid];
+            if (kDiag && (dbg & 2)) { v1 = p; v2 = p; }          // diagnostics: gathers -> coalesced centre reads
+            // ---- the four optical depths: r (alpha_c + alpha_u) / 2 = (r / 2)(alpha_c + alpha_u) ----------------
+            double d1x, d2x, d1y, d2y;
+            {
+                const int av1 = (kDiag && (dbg & 32)) ? p : v1, av2 = (kDiag && (dbg & 32)) ? p : v2;
+                double2 a_c, a_1, a_2;
+                if constexpr (AM == VRT_ALPHA_SITE) {
+                    const T *__restrict__ A1 = reinterpret_cast<const T *>(pa.alpha);
+                    const double c0 = A1[p], c1 = A1[av1], c2 = A1[av2];
+                    a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
+                } else {
+                    const T2 *Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const T2 *>(pa.alpha) + qb
+                                                            : reinterpret_cast<const T2 *>(pa.alpha) + (size_t)it.a * pa.npair * (size_t)n + qb;
+                    a_c = to_d2(at(Al, (unsigned)p << sh)); a_1 = to_d2(at(Al, (unsigned)av1 << sh)); a_2 = to_d2(at(Al, (unsigned)av2 << sh));
+                }
+                const double rh1 = 0.5 * tab.r1[tid], rh2 = 0.5 * tab.r2[tid];
+                d1x = rh1 * (a_c.x + a_1.x); d2x = rh2 * (a_c.x + a_2.x);
+                d1y = rh1 * (a_c.y + a_1.y); d2y = rh2 * (a_c.y + a_2.y);
+            }
+            asm volatile("" : "+v"(d1x), "+v"(d2x), "+v"(d1y), "+v"(d2y) : : "memory");
+            // ---- S and I in flight, the weights one after the other -------------------------------------------------
+            // an upwind's intensity counts when it lies in an EARLIER layer (final); otherwise the gather reads the
+            // never-visited site at storage position n - 1, whose intensity is 0 in every plane (:23)
+            int i1 = v1 < it.lo ? v1 : (int)n - 1, i2 = v2 < it.lo ? v2 : (int)n - 1;
+            if (kDiag && (dbg & 16)) { i1 = (int)n - 1; i2 = (int)n - 1; }
+            const int sv1 = (kDiag && (dbg & 64)) ? p : v1, sv2 = (kDiag && (dbg & 64)) ? p : v2;
+            const T2 rS_c = at(Sd + qb, (unsigned)p << sh), rS_1 = at(Sd + qb, (unsigned)sv1 << sh), rS_2 = at(Sd + qb, (unsigned)sv2 << sh);
+            T2 rI_1, rI_2;
+            if constexpr (CHAIN) {
+                // the patches that store these intensities have published this pair (Guideline 16: poll, then sc1 loads)
+                if (!(kDiag && (dbg & 256))) chain_wait(s_dep, bk - it.b0 + 1, seen);
+                const __amdgpu_buffer_rsrc_t rsI = plane_rsrc(Ia + qb, n << sh);
+                if (kDiag && (dbg & 512)) {
+                    rI_1 = at(Ia + qb, (unsigned)i1 << sh);
+                    rI_2 = at(Ia + qb, (unsigned)i2 << sh);
+                } else {
+                    rI_1 = BufSc1<T2>::load(rsI, (unsigned)i1 << sh);
+                    rI_2 = BufSc1<T2>::load(rsI, (unsigned)i2 << sh);
+                }
             } else {
-                a_c = to_d2(raw.a_c); a_1 = to_d2(raw.a_1); a_2 = to_d2(raw.a_2);
+                rI_1 = at(Ia + qb, (unsigned)i1 << sh);
+                rI_2 = at(Ia + qb, (unsigned)i2 << sh);
             }
-            const double2 S_c = to_d2(raw.S_c), S_1 = to_d2(raw.S_1), S_2 = to_d2(raw.S_2);
-            const double2 I_1 = to_d2(raw.I_1), I_2 = to_d2(raw.I_2);
-            // the four optical depths first (frees the six alpha registers), then one upwind of one wavelength at a time
-            const double d1x = rh1 * (a_c.x + a_1.x), d2x = rh2 * (a_c.x + a_2.x);
-            double d1y = rh1 * (a_c.y + a_1.y), d2y = rh2 * (a_c.y + a_2.y);
-            entry_lambda_seq(d1x, d2x, s_w1 + tid, s_w2 + tid, in1, in2, S_c.x, S_1.x, S_2.x, I_1.x, I_2.x, c.x, g1.x, g2.x, d1y);
-            double sink = 0.0;
-            entry_lambda_seq(d1y, d2y, s_w1 + tid, s_w2 + tid, in1, in2, S_c.y, S_1.y, S_2.y, I_1.y, I_2.y, c.y, g1.y, g2.y, sink);
-        }
-        // ---- the next pair's gathers go out now and land during the level loop ---------------------------------
-        // (compiler fence tied to the coefficients: issued before the arithmetic has consumed the landed pair, the
-        // gathers would need a second set of destination registers)
-        asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(g1.x), "+v"(g1.y), "+v"(g2.x), "+v"(g2.y) : : "memory");
-        const size_t qb_cur = qb;
-        const int sh_cur = sh;
-        bool more = false;
-        if (bk + 1 < b1) {
-            int k0, lw;
-            pair_block_of(bk + 1, pa.npair, pa.lgB, k0, lw);
-            if (sib < (1 << lw)) {
-                more = true;
-                qb = (size_t)k0 * (size_t)n + (size_t)sib;
-                sh = lw + lgT2;
-                issue();
+            const bool in1 = (v1 >= it.lo) & (v1 < it.hi), in2 = (v2 >= it.lo) & (v2 < it.hi);
+            if (kDiag && (dbg & 4)) {                            // diagnostics: no weights arithmetic
+                c = make_double2(d1x + (double)rS_c.x + (double)rS_1.x + (double)rI_1.x, d2y + (double)rS_c.y + (double)rS_2.y + (double)rI_2.y);
+                g1 = make_double2(in1 ? d2x : 0.0, in1 ? d1y : 0.0);
+                g2 = make_double2(in2 ? d1x : 0.0, in2 ? d2y : 0.0);
+            } else {
+                entry_lambda_seq(d1x, d2x, tab.w1 + tid, tab.w2 + tid, in1, in2, (double)rS_c.x, (double)rS_1.x, (double)rS_2.x,
+                                 (double)rI_1.x, (double)rI_2.x, c.x, g1.x, g2.x, d1y);
+                double sink = 0.0;
+                entry_lambda_seq(d1y, d2y, tab.w1 + tid, tab.w2 + tid, in1, in2, (double)rS_c.y, (double)rS_1.y, (double)rS_2.y,
+                                 (double)rI_1.y, (double)rI_2.y, c.y, g1.y, g2.y, sink);
             }
         }
-        asm volatile("" ::: "memory");
         // ---- the patch's Gauss-Seidel levels on the LDS tile ------------------------------------------------------
-        uint32_t vis = s_vis[tid];
-        const uint32_t loc = s_loc[tid];
+        uint32_t vis = tab.vis[tid];
+        const uint32_t loc = tab.loc[tid];
         {
-            double z;                                                    // made here: a hoisted zero would hold four
-            asm volatile("v_mov_b64 %0, 0" : "=v"(z));                   // registers across the whole loop
-            if (tid < n_ent) ptile[tid] = make_double2(z, z);            // I = zero(S), :23
+            double z;
+            asm volatile("v_mov_b64 %0, 0" : "=v"(z));
+            if (tid < it.n_ent) ptile[tid] = make_double2(z, z);         // I = zero(S), :23
         }
+        if constexpr (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous pair's stores have left (its loads are long consumed)
         __syncthreads();
+        if constexpr (CHAIN) {
+            if (bk > it.b0 && tid == 0) chain_publish(s_dep, bk - it.b0);   // ... in every wave: pairs b0 .. bk-1 are published
+        }
+        const int nlev = (kDiag && (dbg & 1)) ? 0 : it.nlev;
         for (int t = 1; t <= nlev; t++) {
             if ((vis & 0xFFu) == (uint32_t)t) {                          // a site's visits come at increasing levels
                 const double2 xv = ptile[loc & 0xFFFFu], yv = ptile[loc >> 16];
@@ -662,15 +824,37 @@ k_patch_pipe(PatchArgs pa)
             }
             __syncthreads();
         }
-        // ---- final intensities of the owned sites --------------------------------------------------------------
-        if (tid < own_cnt) {
-            T2 *I = reinterpret_cast<T2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n + qb_cur;
-            const unsigned off = (unsigned)(own_lo + tid) << sh_cur;
-            *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + off) = from_d2<T>(ptile[tid]);
+        if (tid < it.own_cnt && !(kDiag && (dbg & 8) && ptile[tid].x != 1.2345e300)) {
+            if (CHAIN && !(kDiag && (dbg & 1024))) {
+                const __amdgpu_buffer_rsrc_t rsI = plane_rsrc(Ia + qb, n << sh);
+                BufSc1<T2>::store(rsI, (unsigned)(it.own_lo + tid) << sh, from_d2<T>(ptile[tid]));
+            } else {
+                T2 *I = reinterpret_cast<T2 *>(pa.I) + (size_t)it.a * pa.npair * (size_t)n + qb;
+                *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + ((unsigned)(it.own_lo + tid) << sh)) = from_d2<T>(ptile[tid]);
+            }
         }
-        if (!more) break;
         __syncthreads();                                                 // the tile is rewritten by the next pair
     }
+}
+
+template <typename T, int AM, int NT>
+__global__ void __launch_bounds__(NT) VRT_LEAN_ATTR
+k_patch_lean(PatchArgs pa)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < pa.red.nred) {
+        patch_reduce_role<T, NT>(pa);
+        return;
+    }
+    PatchItem it;
+    if (!patch_item(pa, pa.lgB, it)) return;
+    const EntryTable<NT> tab(ptile, 1);
+    tab.park(pa, it, tid);
+    if (tid == 0) ptile[it.n_ent] = make_double2(0.0, 0.0);  // the zero slot
+    exp2_table_fill();
+    __syncthreads();
+    lean_pairs<T, AM, NT, false>(pair_io<AM>(pa, it.d), it, tab, ptile);
 }
 
 
@@ -678,61 +862,53 @@ k_patch_pipe(PatchArgs pa)
 // With float values a wavelength pair is an 8-byte access, and the patch kernel issues as many memory instructions
 // per wavelength as with doubles: the memory path, which bounds it, sees twice the requests
 // per byte.  In the layout with two (or more) pairs of a site side by side (pair blocks, vrt_device.h) two
-// neighbouring pairs are ONE 16-byte access: this kernel solves both at once -- eight float4 gathers per entry (the
-// three alphas first, then S and I under the weights, as in k_patch_lean), the four evaluations of the weights one
+// neighbouring pairs are ONE 16-byte access: this form solves both at once -- eight float4 gathers per entry (the
+// three alphas first, then S and I under the weights, as in lean_pairs), the four evaluations of the weights one
 // after the other (compiler fences), two planes of the LDS tile walked by one level loop, one float4 store.  Half
 // the memory instructions and half the barriers per wavelength.  (An odd pair count leaves a last block of one pair: the host then launches the pair kernel.)
-template <int AM, int NT>
-__global__ void __launch_bounds__(NT) VRT_PIPE_ATTR
-k_patch_quad(PatchArgs pa)
+// quad_pairs: the pairs 2 sib2, 2 sib2 + 1 of every block among blocks [it.b0, it.b1) of one item (it.sib = sib2).
+template <int AM, int NT, bool CHAIN>
+__device__ __forceinline__ void quad_pairs(const PairIO &pa, const PatchItem &it, const EntryTable<NT> &tab,
+                                           double2 *ptile)
 {
-    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
-    const TileArgs &ta = pa.ta;
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < pa.red.nred) {
-        patch_reduce_role<float, NT>(pa);
-        return;
-    }
-    // workgroup (item, sib2, split): the pairs 2 sib2, 2 sib2 + 1 of every block among blocks b0 .. b1-1
-    PatchItem it;
-    if (!patch_item(pa, pa.lgB - 1, it)) return;
     const int sib2 = it.sib, b0 = it.b0, b1 = it.b1;
-    const int64_t n = ta.n;
-    const int n_ent = it.n_ent, own_lo = it.own_lo, own_cnt = it.own_cnt, nlev = it.nlev, a = it.a, d = it.d;
+    const unsigned n = (unsigned)pa.n;
+    const int n_ent = it.n_ent, own_lo = it.own_lo, own_cnt = it.own_cnt, nlev = it.nlev, a = it.a;
     const int lo = it.lo, hi = it.hi;
     constexpr int CAP = NT;
     double2 *tileA = ptile, *tileB = ptile + (CAP + 1);
-    const EntryTable<CAP> tab(ptile, 2);
-    tab.park(pa, it, tid);
-    double *const s_w1 = tab.w1, *const s_w2 = tab.w2, *const s_r1 = tab.r1, *const s_r2 = tab.r2;
+    double *const s_r1 = tab.r1, *const s_r2 = tab.r2, *const s_w1 = tab.w1, *const s_w2 = tab.w2;
     int *const s_pos = tab.pos, *const s_u1 = tab.u1, *const s_u2 = tab.u2;
     uint32_t *const s_vis = tab.vis, *const s_loc = tab.loc;
-    if (tid == 0) {
-        tileA[n_ent] = make_double2(0.0, 0.0);               // the zero slots
-        tileB[n_ent] = make_double2(0.0, 0.0);
-    }
-    const float2 *Sd = reinterpret_cast<const float2 *>(ta.S[d]);
-    const float2 *Ia = reinterpret_cast<const float2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n;
+    const float2 *Sd = reinterpret_cast<const float2 *>(pa.S);
+    const float2 *Ia = reinterpret_cast<const float2 *>(pa.I) + (size_t)a * pa.npair * (size_t)n;
     auto at4 = [](const float2 *base, unsigned off) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + off); };
+    const int32_t *s_dep = chain_dep_slots(tab);
     for (int bk = b0; bk < b1; bk++) {
         int k0, lw;
-        pair_block_of(bk, pa.npair, pa.lgB, k0, lw);
-        if (2 * sib2 >= (1 << lw)) break;                    // block widths only shrink (and are >= 2: even pair count)
-        const size_t qb = (size_t)k0 * (size_t)n + (size_t)(2 * sib2);
+        if constexpr (CHAIN) { k0 = 2 * bk; lw = 1; }        // the chained launch: blocks of two pairs, no siblings
+        else {
+            pair_block_of(bk, pa.npair, pa.lgB, k0, lw);
+            if (2 * sib2 >= (1 << lw)) break;                // block widths only shrink (and are >= 2: even pair count)
+        }
+        const size_t qb = (size_t)k0 * (size_t)n + (size_t)(CHAIN ? 0 : 2 * sib2);
         const int sh = lw + 3;                               // log2 bytes per site of the block
+        uint32_t seen = 0;
+        if constexpr (CHAIN) seen = chain_peek(s_dep, bk - b0 + 1);
         const int p = s_pos[tid], v1 = s_u1[tid], v2 = s_u2[tid];
-        // ---- the eight optical depths from the three alpha gathers (two gather phases as in k_patch_lean: the
+        // ---- the eight optical depths from the three alpha gathers (two gather phases as in lean_pairs: the
         // alphas are dead before the S / I gathers land) ------------------------------------------------------------
         double d1x, d2x, d1y, d2y, d1z, d2z, d1w, d2w;
         {
             float4 a_c, a_1, a_2;
             if constexpr (AM == VRT_ALPHA_SITE) {
-                const float *__restrict__ A1 = reinterpret_cast<const float *>(ta.alpha[d]);
+                const float *__restrict__ A1 = reinterpret_cast<const float *>(pa.alpha);
                 const float c0 = A1[p], c1 = A1[v1], c2 = A1[v2];
                 a_c = make_float4(c0, c0, c0, c0); a_1 = make_float4(c1, c1, c1, c1); a_2 = make_float4(c2, c2, c2, c2);
             } else {
-                const float2 *Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const float2 *>(ta.alpha[d]) + qb
-                                                            : reinterpret_cast<const float2 *>(ta.alpha_angle) + (size_t)a * pa.npair * (size_t)n + qb;
+                const float2 *Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const float2 *>(pa.alpha) + qb
+                                                            : reinterpret_cast<const float2 *>(pa.alpha) + (size_t)a * pa.npair * (size_t)n + qb;
                 a_c = at4(Al, (unsigned)p << sh); a_1 = at4(Al, (unsigned)v1 << sh); a_2 = at4(Al, (unsigned)v2 << sh);
             }
             const double rh1 = 0.5 * s_r1[tid], rh2 = 0.5 * s_r2[tid];
@@ -748,7 +924,16 @@ k_patch_quad(PatchArgs pa)
             const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
             const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
             const float4 S_c = at4(Sd + qb, (unsigned)p << sh), S_1 = at4(Sd + qb, (unsigned)v1 << sh), S_2 = at4(Sd + qb, (unsigned)v2 << sh);
-            const float4 I_1 = at4(Ia + qb, (unsigned)i1 << sh), I_2 = at4(Ia + qb, (unsigned)i2 << sh);
+            float4 I_1, I_2;
+            if constexpr (CHAIN) {
+                chain_wait(s_dep, bk - b0 + 1, seen);
+                const __amdgpu_buffer_rsrc_t rsI = plane_rsrc(Ia + qb, n << sh);
+                I_1 = BufSc1<float4>::load(rsI, (unsigned)i1 << sh);
+                I_2 = BufSc1<float4>::load(rsI, (unsigned)i2 << sh);
+            } else {
+                I_1 = at4(Ia + qb, (unsigned)i1 << sh);
+                I_2 = at4(Ia + qb, (unsigned)i2 << sh);
+            }
             entry_lambda_seq(d1x, d2x, s_w1 + tid, s_w2 + tid, in1, in2, (double)S_c.x, (double)S_1.x, (double)S_2.x,
                              (double)I_1.x, (double)I_2.x, cA.x, g1A.x, g2A.x, d1y);
             entry_lambda_seq(d1y, d2y, s_w1 + tid, s_w2 + tid, in1, in2, (double)S_c.y, (double)S_1.y, (double)S_2.y,
@@ -770,7 +955,11 @@ k_patch_quad(PatchArgs pa)
                 tileB[tid] = make_double2(z, z);
             }
         }
+        if constexpr (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (CHAIN) {
+            if (bk > b0 && tid == 0) chain_publish(s_dep, bk - b0);
+        }
         for (int t = 1; t <= nlev; t++) {
             if ((vis & 0xFFu) == (uint32_t)t) {
                 const uint32_t l1 = loc & 0xFFFFu, l2 = loc >> 16;
@@ -788,230 +977,263 @@ k_patch_quad(PatchArgs pa)
         }
         // ---- final intensities of the owned sites ---------------------------------------------------------------
         if (tid < own_cnt) {
-            float2 *I = reinterpret_cast<float2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n + qb;
-            char *dst = reinterpret_cast<char *>(I) + ((unsigned)(own_lo + tid) << sh);
             const double2 ra = tileA[tid], rb = tileB[tid];
-            *reinterpret_cast<float4 *>(dst) = make_float4((float)ra.x, (float)ra.y, (float)rb.x, (float)rb.y);
+            const float4 out = make_float4((float)ra.x, (float)ra.y, (float)rb.x, (float)rb.y);
+            if constexpr (CHAIN) {
+                const __amdgpu_buffer_rsrc_t rsI = plane_rsrc(Ia + qb, n << sh);
+                BufSc1<float4>::store(rsI, (unsigned)(own_lo + tid) << sh, out);
+            } else {
+                float2 *I = reinterpret_cast<float2 *>(pa.I) + (size_t)a * pa.npair * (size_t)n + qb;
+                *reinterpret_cast<float4 *>(reinterpret_cast<char *>(I) + ((unsigned)(own_lo + tid) << sh)) = out;
+            }
         }
         __syncthreads();                                     // the tiles are rewritten by the next block
     }
 }
 
-
-// ---- fp64 storage, TWO wavelength pairs per workgroup step ----------------------------------------------------------
-// The level loop (a barrier, an LDS round trip and a handful of scalar / vector instructions per level and wave,
-// ~18 levels on an inclined direction) costs about as many instruction issues as the weights of a pair.  Here two
-// pairs share it: the gathers and the arithmetic of pair A, then those of pair B (so that only one set of eight
-// landed gathers is live at a time: 80 registers hold), then ONE level loop over both tile planes.
+#ifndef VRT_QUAD_ATTR            // 80 VGPRs = three 512-thread workgroups per CU (no scratch at that budget)
+#define VRT_QUAD_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
+#endif
 template <int AM, int NT>
-__global__ void __launch_bounds__(NT) VRT_PIPE_ATTR
-k_patch_duo(PatchArgs pa)
+__global__ void __launch_bounds__(NT) VRT_QUAD_ATTR
+k_patch_quad(PatchArgs pa)
 {
     extern __shared__ __attribute__((aligned(16))) double2 ptile[];
-    const TileArgs &ta = pa.ta;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < pa.red.nred) {
-        patch_reduce_role<double, NT>(pa);
+        patch_reduce_role<float, NT>(pa);
         return;
     }
+    // workgroup (item, sib2, split): the pairs 2 sib2, 2 sib2 + 1 of every block among blocks b0 .. b1-1
     PatchItem it;
-    if (!patch_item(pa, pa.lgB, it)) return;
-    const int sib = it.sib, b0 = it.b0, b1 = it.b1;
-    const int64_t n = ta.n;
-    const int n_ent = it.n_ent, own_lo = it.own_lo, own_cnt = it.own_cnt, nlev = it.nlev, a = it.a, d = it.d;
-    const int lo = it.lo, hi = it.hi;
-    constexpr int CAP = NT;
-    double2 *tileA = ptile, *tileB = ptile + (CAP + 1);
-    const EntryTable<CAP> tab(ptile, 2);
+    if (!patch_item(pa, pa.lgB - 1, it)) return;
+    const EntryTable<NT> tab(ptile, 2);
     tab.park(pa, it, tid);
-    double *const s_w1 = tab.w1, *const s_w2 = tab.w2, *const s_r1 = tab.r1, *const s_r2 = tab.r2;
-    int *const s_pos = tab.pos, *const s_u1 = tab.u1, *const s_u2 = tab.u2;
-    uint32_t *const s_vis = tab.vis, *const s_loc = tab.loc;
     if (tid == 0) {
-        tileA[n_ent] = make_double2(0.0, 0.0);               // the zero slots
-        tileB[n_ent] = make_double2(0.0, 0.0);
+        ptile[it.n_ent] = make_double2(0.0, 0.0);            // the zero slots
+        ptile[NT + 1 + it.n_ent] = make_double2(0.0, 0.0);
     }
-    const double2 *Sd = reinterpret_cast<const double2 *>(ta.S[d]);
-    const double2 *Ia = reinterpret_cast<const double2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n;
-    // gathers + weights of the entry for the pair at element base qb -> (c, g1, g2)
-    auto coefficients = [&](size_t qb, int sh, double2 &c, double2 &g1, double2 &g2) {
-        const int p = s_pos[tid], v1 = s_u1[tid], v2 = s_u2[tid];
-        const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
-        const unsigned op = (unsigned)p << sh, o1 = (unsigned)v1 << sh, o2 = (unsigned)v2 << sh;
-        auto at = [](const double2 *base, unsigned off) { return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + off); };
-        double2 a_c, a_1, a_2;
-        if constexpr (AM == VRT_ALPHA_SITE) {
-            const double *__restrict__ A1 = ta.alpha[d];
-            const double c0 = A1[p], c1 = A1[v1], c2 = A1[v2];
-            a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
-        } else {
-            const double2 *Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const double2 *>(ta.alpha[d]) + qb
-                                                         : reinterpret_cast<const double2 *>(ta.alpha_angle) + (size_t)a * pa.npair * (size_t)n + qb;
-            a_c = at(Al, op); a_1 = at(Al, o1); a_2 = at(Al, o2);
-        }
-        const double2 S_c = at(Sd + qb, op), S_1 = at(Sd + qb, o1), S_2 = at(Sd + qb, o2);
-        const double2 I_1 = at(Ia + qb, (unsigned)i1 << sh), I_2 = at(Ia + qb, (unsigned)i2 << sh);
-        const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
-        const double rh1 = 0.5 * s_r1[tid], rh2 = 0.5 * s_r2[tid];
-        const double d1x = rh1 * (a_c.x + a_1.x), d2x = rh2 * (a_c.x + a_2.x);
-        double d1y = rh1 * (a_c.y + a_1.y), d2y = rh2 * (a_c.y + a_2.y);
-        entry_lambda_seq(d1x, d2x, s_w1 + tid, s_w2 + tid, in1, in2, S_c.x, S_1.x, S_2.x, I_1.x, I_2.x, c.x, g1.x, g2.x, d1y);
-        double sink = 0.0;
-        entry_lambda_seq(d1y, d2y, s_w1 + tid, s_w2 + tid, in1, in2, S_c.y, S_1.y, S_2.y, I_1.y, I_2.y, c.y, g1.y, g2.y, sink);
-    };
-    for (int bk = b0; bk < b1; bk += 2) {
-        int k0, lw;
-        pair_block_of(bk, pa.npair, pa.lgB, k0, lw);
-        if (sib >= (1 << lw)) break;                         // block widths only shrink
-        const size_t qbA = (size_t)k0 * (size_t)n + (size_t)sib;
-        const int shA = lw + 4;
-        bool haveB = bk + 1 < b1;
-        size_t qbB = qbA;
-        int shB = shA;
-        if (haveB) {
-            pair_block_of(bk + 1, pa.npair, pa.lgB, k0, lw);
-            haveB = sib < (1 << lw);
-            if (haveB) { qbB = (size_t)k0 * (size_t)n + (size_t)sib; shB = lw + 4; }
-        }
-        double2 cA, g1A, g2A, cB, g1B, g2B;
-        coefficients(qbA, shA, cA, g1A, g2A);
-        asm volatile("" : "+v"(cA.x), "+v"(cA.y), "+v"(g1A.x), "+v"(g1A.y), "+v"(g2A.x), "+v"(g2A.y) : : "memory");
-        if (haveB) coefficients(qbB, shB, cB, g1B, g2B);
-        else { cB = make_double2(0.0, 0.0); g1B = cB; g2B = cB; }
-        // ---- the patch's Gauss-Seidel levels, both pairs per level -------------------------------------------------
-        uint32_t vis = s_vis[tid];
-        const uint32_t loc = s_loc[tid];
-        {
-            double z;
-            asm volatile("v_mov_b64 %0, 0" : "=v"(z));
-            if (tid < n_ent) {
-                tileA[tid] = make_double2(z, z);             // I = zero(S), :23
-                tileB[tid] = make_double2(z, z);
-            }
-        }
-        __syncthreads();
-        for (int t = 1; t <= nlev; t++) {
-            if ((vis & 0xFFu) == (uint32_t)t) {
-                const uint32_t l1 = loc & 0xFFFFu, l2 = loc >> 16;
-                const double2 xa = tileA[l1], ya = tileA[l2], xb = tileB[l1], yb = tileB[l2];
-                double2 ra, rb;
-                ra.x = fma(g2A.x, ya.x, fma(g1A.x, xa.x, cA.x));
-                ra.y = fma(g2A.y, ya.y, fma(g1A.y, xa.y, cA.y));
-                rb.x = fma(g2B.x, yb.x, fma(g1B.x, xb.x, cB.x));
-                rb.y = fma(g2B.y, yb.y, fma(g1B.y, xb.y, cB.y));
-                tileA[tid] = ra;
-                tileB[tid] = rb;
-                vis >>= 8;
-            }
-            __syncthreads();
-        }
-        if (tid < own_cnt) {
-            double2 *I = reinterpret_cast<double2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n;
-            *reinterpret_cast<double2 *>(reinterpret_cast<char *>(I + qbA) + ((unsigned)(own_lo + tid) << shA)) = tileA[tid];
-            if (haveB) *reinterpret_cast<double2 *>(reinterpret_cast<char *>(I + qbB) + ((unsigned)(own_lo + tid) << shB)) = tileB[tid];
-        }
-        __syncthreads();                                     // the tiles are rewritten by the next step
-    }
+    exp2_table_fill();
+    __syncthreads();
+    quad_pairs<AM, NT, false>(pair_io<AM>(pa, it.d), it, tab, ptile);
 }
 
 
-// ---- one pair at a time within 64 registers: FOUR workgroups per CU ---------------------------------------------------
-// No unit of the chip is saturated by the patch kernel; its phases (gathers, arithmetic, level loop) overlap only as
-// far as three 512-thread workgroups per CU allow (72 registers).  This form fits the 64 of a fourth: the three
-// alpha gathers first, the four optical depths from them (the alphas die), then the five S / I gathers in flight
-// while the weights are evaluated one after the other, each folded into its share of the visit as soon as it exists.
-#ifndef VRT_LEAN_ATTR
-#define VRT_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
-#endif
-template <typename T, int AM, int NT>
-__global__ void __launch_bounds__(NT) VRT_LEAN_ATTR
-k_patch_lean(PatchArgs pa)
+// ---- the chained launch --------------------------------------------------------------------------------------------
+// Items (two int4 each), per XCD queue in layer order:
+//   solve:   A = (first entry, first owned position, entries | owned << 10 | levels << 20, angle | dir << 6 | split << 7 | layer << 16)
+//            B = (first dependency, dependencies, patch, 0)
+//   reduce:  A = (lo, hi, 1 << 31, dir << 6 | split << 7): J_dir of storage positions [lo, hi), pairs of the split
+//            B = (first dependency, dependencies, 0, steps the dependencies must have published)
+//   padding: A = (0, 0, 1 << 30, 0): nothing (the queues advance through the layers in step, see ensure_patch_chain)
+// The launch's arguments live in device memory (ChainDev) and are re-read by every item: a persistent loop around
+// the patch solver must not keep forty kernel arguments alive in scalar registers across it (the solver alone
+// needs 72 of the 80 that eight waves per SIMD allow).
+struct ChainDev {
+    TileArgs ta;
+    int npair, nsplit, cap;
+    const int32_t *e_pos, *e_u1, *e_u2;
+    const uint32_t *e_vis, *e_loc;
+    const double *e_w1, *e_w2, *e_r1, *e_r2;
+    PatchReduce red;           // weights, angle lists ([0] up, [1] down), J_dir planes
+    const int4 *items;
+    int q_off[9];              // items of queue x: [q_off[x], q_off[x + 1])
+    const int32_t *deps;       // dependency lists: patch indices
+    uint32_t *progress;        // [nsplit][n_patches]
+    uint32_t *ctrl;            // queue heads (kChainHeadStride words apart), give-up word
+    uint32_t *host_status;     // mapped host word: non-zero once a spin has expired
+    int64_t n_patches;
+    uint32_t spin_limit;
+    int dbg;                   // timing diagnostics (-DVRT_DIAG build only, WRONG results): the flags of PatchArgs::dbg, and
+                               //   256 no waiting for dependencies, 512 plain (L1-cached) intensity gathers, 1024 plain intensity stores
+};
+
+// uniform (scalar-register) reads of the argument block
+__device__ __forceinline__ int cd_int(const int *p) { return __builtin_amdgcn_readfirstlane(*p); }
+template <typename P>
+__device__ __forceinline__ P *cd_ptr(P *const *p) { return uniform_ptr(*p); }
+
+__device__ __forceinline__ void chain_wait_slow(const int32_t *s_dep, int step)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t *ctl = reinterpret_cast<const uint32_t *>(s_dep - kCtlWords);
+    const ChainDev *cd = reinterpret_cast<const ChainDev *>(((uint64_t)ctl[kCtlArgsHi] << 32) | (uint64_t)ctl[kCtlArgsLo]);
+    uint32_t *abort_word = cd->ctrl + kChainAbortWord;
+    const uint32_t *progress = chain_progress(ctl);
+    const uint32_t target = ctl[kCtlBase] + (uint32_t)step, limit = cd->spin_limit;
+    const int ndep = (int)ctl[kCtlNdep];
+    for (int c0 = 0; c0 < ndep; c0 += 64) {
+        const int j = c0 + lane;
+        // (the LDS slots are padded with the item's own patch; past them the global list is read where it exists)
+        const int dep = j < 64 + kChainDepLds ? s_dep[j] : (j < ndep ? (cd->deps + ctl[kCtlDepOff])[j] : (int)ctl[kCtlSelf]);
+        const uint32_t *w = progress + dep;
+        uint32_t spins = 0;
+        for (;;) {
+            const uint32_t v = ld_agent(w);
+            if (__all(j >= ndep || (int)(v - target) >= 0)) break;
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 127u) == 1u) {
+                if (spins > limit) {                           // give up: the launch drains, the host reports it
+                    st_agent(abort_word, 1u);
+                    __hip_atomic_store(cd->host_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (ld_agent(abort_word) != 0u) return;
+            }
+        }
+    }
+}
+
+// J_dir over storage positions [lo, hi) of direction r for the pair blocks [b0, b1): the reduction of
+// patch_reduce_role, every intensity read by an sc1 load
+template <typename T, int NT, int LGB>
+__device__ __forceinline__ void chain_reduce(const ChainDev *cd, int r, int lo, int hi, int b0, int b1)
 {
     typedef typename Pair<T>::type T2;
-    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
-    const TileArgs &ta = pa.ta;
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < pa.red.nred) {
-        patch_reduce_role<T, NT>(pa);
+    const int64_t nn = cd->ta.n;
+    const int npair = cd_int(&cd->npair);
+    const size_t plane = (size_t)npair * (size_t)nn;
+    T2 *Jd = reinterpret_cast<T2 *>(cd_ptr(&cd->red.Jd[r]));
+    const T2 *I0 = reinterpret_cast<const T2 *>(cd_ptr(&cd->ta.I));
+    const int count = cd_int(&cd->red.count[r]);
+    constexpr int lgT2 = Log2Size<T2>::value;
+    for (int bk = b0; bk < b1; bk++) {
+        const int k0 = bk << LGB;
+        const size_t run = (size_t)(hi - lo) << LGB;
+        const size_t base = (size_t)k0 * (size_t)nn + ((size_t)lo << LGB);
+        for (size_t f = (size_t)tid; f < run; f += NT) {
+            double ax = 0.0, ay = 0.0;
+            for (int j = 0; j < count; j++) {                // the reference's angle order (lambda_iteration.jl:84,102,107)
+                const int a = cd_int(&cd->red.angles[r][j]);
+                const double wa = cd->red.w[a];
+                const __amdgpu_buffer_rsrc_t rs = plane_rsrc(I0 + (size_t)a * plane + base, (unsigned)(run << lgT2));
+                const double2 v = to_d2(BufSc1<T2>::load(rs, (unsigned)(f << lgT2)));
+                ax += wa * v.x;
+                ay += wa * v.y;
+            }
+            Jd[base + f] = from_d2<T>(make_double2(ax, ay));
+        }
+    }
+}
+
+// ONE item per workgroup: the workgroup takes the next ticket of its queue when it starts and ends with its item --
+// the hardware's workgroup dispatcher is the loop (a persistent loop around the solver would have to keep its state
+// in scalar registers the solver needs: 28 of them spilled, and with them a vector register of the 64).  Tickets are
+// taken in order by workgroups that are running, so the argument about progress above holds whatever order the
+// blocks of the grid start in; the grid has exactly one block per item.
+template <typename T, int AM, int NT, bool QUAD>
+__device__ __forceinline__ void chain_item(const ChainDev *cd, uint32_t base, double2 *ptile)
+{
+    const int tid = threadIdx.x;
+    constexpr int PLANES = QUAD ? 2 : 1;
+    constexpr int LGB = QUAD ? 1 : 0;
+    const EntryTable<NT> tab(ptile, PLANES);
+    uint32_t *s_ctl = chain_ctl_slots(tab);
+    int32_t *s_dep = chain_dep_slots(tab);
+    exp2_table_fill();
+    if (tid == 0) {
+        // next item of this block's queue, in order (blocks x, x + 8, ... share an XCD: speed only); an exhausted
+        // queue -> the next one (load balance at the end)
+        uint32_t *ctrl = cd->ctrl;
+        int q = (int)(blockIdx.x & 7u), idx = -1;
+        for (int tries = 0; tries < 8; tries++) {
+            const int o0 = cd->q_off[q], len = cd->q_off[q + 1] - o0;
+            const uint32_t t = len > 0 ? __hip_atomic_fetch_add(ctrl + q * kChainHeadStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : 0u;
+            if (len > 0 && t < (uint32_t)len) { idx = o0 + (int)t; break; }
+            q = (q + 1) & 7;
+        }
+        s_ctl[kCtlItem] = (uint32_t)idx;
+        s_ctl[kCtlArgsLo] = (uint32_t)(uint64_t)cd;
+        s_ctl[kCtlArgsHi] = (uint32_t)((uint64_t)cd >> 32);
+    }
+    __syncthreads();
+    const int idx = __builtin_amdgcn_readfirstlane((int)s_ctl[kCtlItem]);
+    if (idx < 0) return;
+    const int4 *items = cd->items;
+    const int4 A4 = items[2 * (size_t)idx], B4 = items[2 * (size_t)idx + 1];
+    const int Ax = __builtin_amdgcn_readfirstlane(A4.x), Ay = __builtin_amdgcn_readfirstlane(A4.y);
+    const uint32_t Az = (uint32_t)__builtin_amdgcn_readfirstlane(A4.z), Aw = (uint32_t)__builtin_amdgcn_readfirstlane(A4.w);
+    const int Bx = __builtin_amdgcn_readfirstlane(B4.x), By = __builtin_amdgcn_readfirstlane(B4.y);
+    const int Bz = __builtin_amdgcn_readfirstlane(B4.z), Bw = __builtin_amdgcn_readfirstlane(B4.w);
+    if (Az & 0x40000000u) return;                            // padding: every queue holds as many items of a layer as the longest
+    {
+        // dependency slots: the list (its first kChainDepLds entries), padded with the item's own patch to a multiple of 64
+        const int32_t *deps = cd->deps;
+        const int padded = min(kChainDepLds + 64, (By + 63) / 64 * 64 + (By == 0 ? 64 : 0));
+        for (int j = tid; j < padded; j += NT) s_dep[j] = j < By ? deps[Bx + j] : Bz;
+    }
+    const int d = (int)((Aw >> 6) & 1u), split = (int)((Aw >> 7) & 0x1FFu);
+    const int npair = cd_int(&cd->npair);
+    int b0, b1;
+    {
+        // blocks [b0, b1) of the split: dealt evenly as split_blocks does (Q = 1)
+        const int nblock = npair >> LGB, nsplit = cd_int(&cd->nsplit);
+        const int per = nblock / nsplit, rem = nblock - per * nsplit;
+        b0 = split * per + (split < rem ? split : rem);
+        b1 = b0 + per + (split < rem ? 1 : 0);
+    }
+    if (tid == 0) {                                          // (read behind the barrier that publishes the dependency list)
+        const uint64_t prog = (uint64_t)(cd->progress + (size_t)split * (size_t)cd->n_patches);
+        s_ctl[kCtlSelf] = (uint32_t)Bz;
+        s_ctl[kCtlNdep] = (uint32_t)By;
+        s_ctl[kCtlDepOff] = (uint32_t)Bx;
+        s_ctl[kCtlProgLo] = (uint32_t)prog;
+        s_ctl[kCtlProgHi] = (uint32_t)(prog >> 32);
+        s_ctl[kCtlBase] = base;
+    }
+    if (Az >> 31) {                                          // ---- J_dir of a finished range ----------------------------
+        __syncthreads();                                     // the dependency list is in LDS
+        chain_wait(s_dep, Bw, chain_peek(s_dep, Bw));
+        chain_reduce<T, NT, LGB>(cd, d, Ax, Ay, b0, b1);
         return;
     }
     PatchItem it;
-    if (!patch_item(pa, pa.lgB, it)) return;
-    constexpr int lgT2 = Log2Size<T2>::value;
-    const int64_t n = ta.n;
-    constexpr int CAP = NT;
-    const EntryTable<CAP> tab(ptile, 1);
-    tab.park(pa, it, tid);
-    if (tid == 0) ptile[it.n_ent] = make_double2(0.0, 0.0);  // the zero slot
-    const T2 *Sd = reinterpret_cast<const T2 *>(ta.S[it.d]);
-    const T2 *Ia = reinterpret_cast<const T2 *>(ta.I) + (size_t)it.a * pa.npair * (size_t)n;
-    auto at = [](const T2 *base, unsigned off) { return *reinterpret_cast<const T2 *>(reinterpret_cast<const char *>(base) + off); };
-    for (int bk = it.b0; bk < it.b1; bk++) {
-        int k0, lw;
-        pair_block_of(bk, pa.npair, pa.lgB, k0, lw);
-        if (it.sib >= (1 << lw)) break;                      // block widths only shrink
-        const size_t qb = (size_t)k0 * (size_t)n + (size_t)it.sib;
-        const int sh = lw + lgT2;
-        double2 c, g1, g2;
-        {
-            const int p = tab.pos[tid], v1 = tab.u1[tid], v2 = tab.u2[tid];
-            // ---- the four optical depths: r (alpha_c + alpha_u) / 2 = (r / 2)(alpha_c + alpha_u) ----------------
-            double d1x, d2x, d1y, d2y;
-            {
-                double2 a_c, a_1, a_2;
-                if constexpr (AM == VRT_ALPHA_SITE) {
-                    const T *__restrict__ A1 = reinterpret_cast<const T *>(ta.alpha[it.d]);
-                    const double c0 = A1[p], c1 = A1[v1], c2 = A1[v2];
-                    a_c = make_double2(c0, c0); a_1 = make_double2(c1, c1); a_2 = make_double2(c2, c2);
-                } else {
-                    const T2 *Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const T2 *>(ta.alpha[it.d]) + qb
-                                                            : reinterpret_cast<const T2 *>(ta.alpha_angle) + (size_t)it.a * pa.npair * (size_t)n + qb;
-                    a_c = to_d2(at(Al, (unsigned)p << sh)); a_1 = to_d2(at(Al, (unsigned)v1 << sh)); a_2 = to_d2(at(Al, (unsigned)v2 << sh));
-                }
-                const double rh1 = 0.5 * tab.r1[tid], rh2 = 0.5 * tab.r2[tid];
-                d1x = rh1 * (a_c.x + a_1.x); d2x = rh2 * (a_c.x + a_2.x);
-                d1y = rh1 * (a_c.y + a_1.y); d2y = rh2 * (a_c.y + a_2.y);
-            }
-            asm volatile("" : "+v"(d1x), "+v"(d2x), "+v"(d1y), "+v"(d2y) : : "memory");
-            // ---- S and I in flight, the weights one after the other -------------------------------------------------
-            // an upwind's intensity counts when it lies in an EARLIER layer (final); otherwise the gather reads the
-            // never-visited site at storage position n - 1, whose intensity is 0 in every plane (:23)
-            const int i1 = v1 < it.lo ? v1 : (int)n - 1, i2 = v2 < it.lo ? v2 : (int)n - 1;
-            const T2 rS_c = at(Sd + qb, (unsigned)p << sh), rS_1 = at(Sd + qb, (unsigned)v1 << sh), rS_2 = at(Sd + qb, (unsigned)v2 << sh);
-            const T2 rI_1 = at(Ia + qb, (unsigned)i1 << sh), rI_2 = at(Ia + qb, (unsigned)i2 << sh);
-            const bool in1 = (v1 >= it.lo) & (v1 < it.hi), in2 = (v2 >= it.lo) & (v2 < it.hi);
-            entry_lambda_seq(d1x, d2x, tab.w1 + tid, tab.w2 + tid, in1, in2, (double)rS_c.x, (double)rS_1.x, (double)rS_2.x,
-                             (double)rI_1.x, (double)rI_2.x, c.x, g1.x, g2.x, d1y);
-            double sink = 0.0;
-            entry_lambda_seq(d1y, d2y, tab.w1 + tid, tab.w2 + tid, in1, in2, (double)rS_c.y, (double)rS_1.y, (double)rS_2.y,
-                             (double)rI_1.y, (double)rI_2.y, c.y, g1.y, g2.y, sink);
-        }
-        // ---- the patch's Gauss-Seidel levels on the LDS tile ------------------------------------------------------
-        uint32_t vis = tab.vis[tid];
-        const uint32_t loc = tab.loc[tid];
-        {
-            double z;
-            asm volatile("v_mov_b64 %0, 0" : "=v"(z));
-            if (tid < it.n_ent) ptile[tid] = make_double2(z, z);         // I = zero(S), :23
-        }
-        __syncthreads();
-        for (int t = 1; t <= it.nlev; t++) {
-            if ((vis & 0xFFu) == (uint32_t)t) {                          // a site's visits come at increasing levels
-                const double2 xv = ptile[loc & 0xFFFFu], yv = ptile[loc >> 16];
-                double2 r;
-                r.x = fma(g2.x, yv.x, fma(g1.x, xv.x, c.x));
-                r.y = fma(g2.y, yv.y, fma(g1.y, xv.y, c.y));
-                ptile[tid] = r;
-                vis >>= 8;
-            }
-            __syncthreads();
-        }
-        if (tid < it.own_cnt) {
-            T2 *I = reinterpret_cast<T2 *>(ta.I) + (size_t)it.a * pa.npair * (size_t)n + qb;
-            *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + ((unsigned)(it.own_lo + tid) << sh)) = from_d2<T>(ptile[tid]);
-        }
-        __syncthreads();                                                 // the tile is rewritten by the next pair
+    it.sib = 0; it.b0 = b0; it.b1 = b1;
+    it.ent_off = Ax; it.own_lo = Ay;
+    it.n_ent = (int)(Az & 0x3FFu); it.own_cnt = (int)((Az >> 10) & 0x3FFu); it.nlev = (int)((Az >> 20) & 0xFFu);
+    it.a = (int)(Aw & 63u); it.d = d;
+    {
+        const int layer = (int)(Aw >> 16);
+        const int32_t *lay = cd->ta.lay[d];
+        it.lo = __builtin_amdgcn_readfirstlane(lay[layer - 1]);
+        it.hi = __builtin_amdgcn_readfirstlane(lay[layer]);
     }
+    PairIO pa;
+    pa.n = cd_int(reinterpret_cast<const int *>(&cd->ta.n));                     // n < 2^28
+    pa.npair = npair;
+    pa.lgB = LGB;
+    pa.dbg = kDiag ? cd_int(&cd->dbg) : 0;
+    pa.S = cd_ptr(&cd->ta.S[d]);
+    pa.I = cd_ptr(&cd->ta.I);
+    pa.alpha = AM == VRT_ALPHA_ANGLE_SITE_LAM ? (const void *)cd_ptr(&cd->ta.alpha_angle) : (const void *)cd_ptr(&cd->ta.alpha[d]);
+    tab.park(*cd, it, tid);
+    if (tid == 0) {
+        ptile[it.n_ent] = make_double2(0.0, 0.0);            // the zero slot(s)
+        if (QUAD) ptile[NT + 1 + it.n_ent] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();                                         // the dependency list is in LDS
+    if constexpr (QUAD) quad_pairs<AM, NT, true>(pa, it, tab, ptile);
+    else lean_pairs<T, AM, NT, true>(pa, it, tab, ptile);
+    // the last pair: every storing wave drains, then ONE lane publishes the finished item
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) chain_publish(s_dep, b1 - b0);
+}
+
+template <typename T, int AM, int NT>
+__global__ void __launch_bounds__(NT) VRT_LEAN_ATTR
+k_patch_chain(const ChainDev *cd, uint32_t base)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
+    chain_item<T, AM, NT, false>(cd, base, ptile);
+}
+template <int AM, int NT>
+__global__ void __launch_bounds__(NT) VRT_QUAD_ATTR
+k_patch_chain_quad(const ChainDev *cd, uint32_t base)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
+    chain_item<float, AM, NT, true>(cd, base, ptile);
 }
 
 // the instantiated launch shapes (entries per thread, pairs at a time, threads)
@@ -1019,7 +1241,7 @@ k_patch_lean(PatchArgs pa)
     X(1, 1, 256) X(1, 1, 512) X(1, 1, 1024) X(2, 1, 256) X(2, 1, 512) X(1, 2, 256) X(1, 2, 512) X(1, 2, 1024) X(2, 2, 512)
 
 template <typename T, int AM>
-static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa, bool pipe)
+static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa)
 {
     if constexpr (sizeof(T) == 4) {
         if (pa.quad) {
@@ -1031,29 +1253,11 @@ static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t
             }
         }
     }
-    if constexpr (sizeof(T) == 8) {
-        if (pa.duo && K == 1 && Q == 2 && !(kDiag && pa.dbg)) {
-            switch (NT) {
-            case 256: hipLaunchKernelGGL((k_patch_duo<AM, 256>), grid, dim3(256), lds, st, pa); return VRT_OK;
-            case 512: hipLaunchKernelGGL((k_patch_duo<AM, 512>), grid, dim3(512), lds, st, pa); return VRT_OK;
-            case 1024: hipLaunchKernelGGL((k_patch_duo<AM, 1024>), grid, dim3(1024), lds, st, pa); return VRT_OK;
-            default: break;
-            }
-        }
-    }
-    if (pa.lean && K == 1 && Q == 1 && !(kDiag && pa.dbg)) {
+    if (pa.lean && K == 1 && Q == 1) {
         switch (NT) {
         case 256: hipLaunchKernelGGL((k_patch_lean<T, AM, 256>), grid, dim3(256), lds, st, pa); return VRT_OK;
         case 512: hipLaunchKernelGGL((k_patch_lean<T, AM, 512>), grid, dim3(512), lds, st, pa); return VRT_OK;
         case 1024: hipLaunchKernelGGL((k_patch_lean<T, AM, 1024>), grid, dim3(1024), lds, st, pa); return VRT_OK;
-        default: break;
-        }
-    }
-    if (pipe && K == 1 && Q == 1 && !(kDiag && pa.dbg)) {
-        switch (NT) {
-        case 256: hipLaunchKernelGGL((k_patch_pipe<T, AM, 256>), grid, dim3(256), lds, st, pa); return VRT_OK;
-        case 512: hipLaunchKernelGGL((k_patch_pipe<T, AM, 512>), grid, dim3(512), lds, st, pa); return VRT_OK;
-        case 1024: hipLaunchKernelGGL((k_patch_pipe<T, AM, 1024>), grid, dim3(1024), lds, st, pa); return VRT_OK;
         default: break;
         }
     }
@@ -1065,12 +1269,12 @@ static int launch_shape(int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t
 }
 
 template <typename T>
-static int launch_mode(int am, int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa, bool pipe)
+static int launch_mode(int am, int K, int Q, int NT, dim3 grid, size_t lds, hipStream_t st, const PatchArgs &pa)
 {
     switch (am) {
-    case VRT_ALPHA_SITE: return launch_shape<T, VRT_ALPHA_SITE>(K, Q, NT, grid, lds, st, pa, pipe);
-    case VRT_ALPHA_SITE_LAM: return launch_shape<T, VRT_ALPHA_SITE_LAM>(K, Q, NT, grid, lds, st, pa, pipe);
-    default: return launch_shape<T, VRT_ALPHA_ANGLE_SITE_LAM>(K, Q, NT, grid, lds, st, pa, pipe);
+    case VRT_ALPHA_SITE: return launch_shape<T, VRT_ALPHA_SITE>(K, Q, NT, grid, lds, st, pa);
+    case VRT_ALPHA_SITE_LAM: return launch_shape<T, VRT_ALPHA_SITE_LAM>(K, Q, NT, grid, lds, st, pa);
+    default: return launch_shape<T, VRT_ALPHA_ANGLE_SITE_LAM>(K, Q, NT, grid, lds, st, pa);
     }
 }
 
@@ -1172,8 +1376,6 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     // count is even (every block then holds >= 2 pairs and every plane starts 16-byte aligned; else the pair kernel)
     pa.quad = (f32 && pa.lgB >= 1 && p->patch_K == 1 && p->tune.patch_quad != 0 && (npair & 1) == 0) ? 1 : 0;
     if (pa.quad) Q = 1;
-    pa.duo = (!f32 && p->tune.patch_duo != 0 && p->patch_K == 1 && Q == 1 && npair >= 2) ? 1 : 0;
-    if (pa.duo) Q = 2;
     // (a lone pair per workgroup is a latency chain: the plain kernel's single gather phase is 3 % shorter there)
     pa.lean = (p->tune.patch_lean != 0 && p->patch_K == 1 && Q == 1 && !pa.quad && npair >= 2) ? 1 : 0;
     const int lgS = pa.lgB - pa.quad;                          // log2 of the sibling workgroups per block
@@ -1199,10 +1401,280 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     pa.e_w1 = p->e_w1; pa.e_w2 = p->e_w2; pa.e_r1 = p->e_r1; pa.e_r2 = p->e_r2;
     const dim3 grid((unsigned)(pa.red.nred + (w1 - w0) * pa.ngrp));
     const size_t lds = (size_t)(pa.quad ? 2 : Q) * (size_t)pa.stride * sizeof(double2) + (size_t)pa.cap * (4 * sizeof(double) + 5 * sizeof(int32_t));
-    const bool pipe = p->tune.patch_pipe == 1 || (p->tune.patch_pipe == 2 && f32);
-    const int rc = f32 ? launch_mode<float>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa, pipe)
-                       : launch_mode<double>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa, pipe);
+    const int rc = f32 ? launch_mode<float>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa)
+                       : launch_mode<double>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa);
     return rc;
+}
+
+// ---- the chained launch: host side ------------------------------------------------------------------------------------
+// (1 << lgS) sibling workgroups per pair block exist only in the pair-block layouts (VRT_PAIR_BLOCK > 1 with doubles,
+// an odd pair count with floats): those, the other kernel shapes and thread counts keep the per-layer launches.
+bool patch_chain_possible(const vrt_plan *p, int npair, bool f32)
+{
+    if (!p->patch_ok || p->tune.patch_chain == 0 || p->patch_K != 1 || p->patch_NT != 512) return false;
+    const int lgB = native_lg(p, f32);
+    const bool quad = f32 && lgB >= 1 && p->tune.patch_quad != 0 && (npair & 1) == 0;
+    if (lgB - (quad ? 1 : 0) != 0) return false;
+    if (!f32 && p->tune.patch_lean == 0) return false;             // VRT_PATCH_LEAN=0 asks for the 72-register kernel
+    if (p->tile_max_layers >= 65535 || p->A > 63) return false;    // item encoding
+    return true;
+}
+
+static int chain_nsplit(const vrt_plan *p, int nblock)
+{
+    const int per = std::max(1, p->tune.chain_pairs);
+    return std::max(1, std::min({(nblock + per / 2) / per, nblock, 511}));
+}
+
+// Items of the chained launch for `npair` pairs in blocks of 2^lgB, `nsplit` items per patch: eight queues (XCD x
+// takes queue x first), each in layer order: the solve items of a layer's patches -- sorted by (first owned position,
+// angle) and cut into 8 runs as the per-layer work lists are, the splits of a patch next to each other -- followed
+// by the J_dir items of the layer before (lagged: their dependencies have then long been claimed).
+static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool with_reduce)
+{
+    if (p->d_chain_items && p->chain_npair == npair && p->chain_lgB == lgB && p->chain_nsplit == nsplit &&
+        p->chain_reduce == (with_reduce ? 1 : 0))
+        return VRT_OK;
+    const vrt_grid *g = p->g;
+    const int maxL = p->tile_max_layers, A = p->A;
+    const int64_t n = g->n, n_patches = p->n_patches;
+    const int nblock = pair_block_count(npair, lgB);
+    if ((int64_t)nsplit * n_patches >= ((int64_t)1 << 31)) return fail(VRT_EINVAL, "too many (split, patch) progress words");
+    PatchArgs sp;                     // split_blocks reads nsplit and Q only
+    sp.nsplit = nsplit;
+    sp.Q = 1;
+    std::vector<int> steps((size_t)nsplit);
+    for (int s = 0; s < nsplit; s++) {
+        int b0, b1;
+        split_blocks(sp, s, nblock, b0, b1);
+        steps[(size_t)s] = b1 - b0;
+    }
+    std::vector<int4> q[8];
+    std::vector<int32_t> rdeps;       // dependency lists of the J_dir items (patch ids), appended behind the patches' own
+    const size_t dep_base = p->h_patch_deps.size();
+    std::vector<std::pair<int64_t, int32_t>> items;
+    std::vector<int> dir_angles[2];
+    for (int a = 0; a < A; a++) dir_angles[p->dir_of_active[(size_t)a] > 0 ? 0 : 1].push_back(a);
+    // first owned position of each XCD run of (layer, direction): J_dir items follow the patches of their positions
+    std::vector<int32_t> run_start((size_t)(maxL + 2) * 2 * 8, 0);
+    auto first_of = [&](int a, int layer) { return p->h_patch_first[(size_t)a * (size_t)(maxL + 2) + (size_t)layer]; };
+    // Every queue holds the same number of items per (layer, direction) segment (padding items end at once), so the
+    // queues advance through the layers in step however the blocks of the grid are dealt to them: the blocks
+    // x, x + 8, ... take queue x in order, a workgroup only waits for items of EARLIER layers, and with static
+    // block -> XCD dealing (what the hardware does) the slots an XCD frees go to its own queue's next items.
+    auto level_queues = [&]() {
+        size_t longest = 0;
+        for (int x = 0; x < 8; x++) longest = std::max(longest, q[x].size());
+        for (int x = 0; x < 8; x++)
+            while (q[x].size() < longest) {
+                q[x].push_back(make_int4(0, 0, 0x40000000, 0));
+                q[x].push_back(make_int4(0, 0, 0, 0));
+            }
+    };
+    auto emit_reduce = [&](int layer) {
+        if (!with_reduce) return;
+        for (int d = 0; d < 2; d++) {
+            const Direction &dir = d == 0 ? g->up : g->down;
+            const int Ld = (int)dir.reduced.size() - 1;
+            if (dir_angles[d].empty() || layer < 1 || layer > Ld) continue;
+            const int64_t lo = dir.reduced[(size_t)layer - 1] - 1;
+            const int64_t hi = layer == Ld ? n : dir.reduced[(size_t)layer] - 1;      // + the never-visited last site (I = 0)
+            const int32_t *rs = run_start.data() + ((size_t)layer * 2 + (size_t)d) * 8;
+            constexpr int64_t R = 512;
+            for (int64_t clo = lo; clo < hi; clo += R) {
+                const int64_t chi = std::min(hi, clo + R);
+                int x = 0;
+                if (layer >= 2) { while (x < 7 && rs[x + 1] <= clo) x++; }
+                else x = (int)std::min<int64_t>(7, 8 * (clo - lo) / std::max<int64_t>(1, hi - lo));
+                const size_t d0 = rdeps.size();
+                if (layer >= 2)
+                    for (int a : dir_angles[d])
+                        for (int32_t pq = first_of(a, layer); pq < first_of(a, layer + 1); pq++) {
+                            const int4 &rec = p->h_patch_rec[(size_t)pq];
+                            if (rec.z < chi && rec.z + rec.w > clo) rdeps.push_back(pq);
+                        }
+                for (int s = 0; s < nsplit; s++) {
+                    q[x].push_back(make_int4((int)clo, (int)chi, (int)0x80000000u, (d << 6) | (s << 7)));
+                    q[x].push_back(make_int4((int)(dep_base + d0), (int)(rdeps.size() - d0), 0, steps[(size_t)s]));
+                }
+            }
+        }
+    };
+    for (int layer = 2; layer <= maxL; layer++) {
+        for (int d = 0; d < 2; d++) {
+            items.clear();
+            for (size_t j = 0; j < dir_angles[d].size(); j++) {
+                const int a = dir_angles[d][j];
+                for (int32_t pq = first_of(a, layer); pq < first_of(a, layer + 1); pq++)
+                    items.push_back({(int64_t)p->h_patch_rec[(size_t)pq].z * 64 + (int64_t)j, pq});
+            }
+            std::sort(items.begin(), items.end());
+            const size_t m = items.size();
+            int32_t *rs = run_start.data() + ((size_t)layer * 2 + (size_t)d) * 8;
+            for (int x = 0; x < 8; x++) {
+                const size_t t0 = m * (size_t)x / 8, t1 = m * (size_t)(x + 1) / 8;
+                rs[x] = t0 < m ? p->h_patch_rec[(size_t)items[t0].second].z : INT32_MAX;
+                for (size_t t = t0; t < t1; t++) {
+                    const int32_t pq = items[t].second;
+                    const int4 &rec = p->h_patch_rec[(size_t)pq];
+                    const int2 &rec2 = p->h_patch_rec2[(size_t)pq];
+                    const int64_t o0 = p->h_patch_dep_off[(size_t)pq], o1 = p->h_patch_dep_off[(size_t)pq + 1];
+                    for (int s = 0; s < nsplit; s++) {
+                        q[x].push_back(make_int4(rec.x, rec.z, rec.y | (rec.w << 10) | (rec2.x << 20),
+                                                 rec2.y | (d << 6) | (s << 7) | (layer << 16)));
+                        q[x].push_back(make_int4((int)o0, (int)(o1 - o0), pq, 0));
+                    }
+                }
+            }
+            level_queues();
+        }
+        emit_reduce(layer - 1);
+        level_queues();
+    }
+    emit_reduce(maxL);
+    if (maxL < 2) emit_reduce(1);
+    level_queues();
+    std::vector<int4> all;
+    for (int x = 0; x < 8; x++) {
+        p->chain_q_off[x] = (int)(all.size() / 2);
+        all.insert(all.end(), q[x].begin(), q[x].end());
+        std::vector<int4>().swap(q[x]);
+    }
+    p->chain_q_off[8] = (int)(all.size() / 2);
+    if (all.size() / 2 >= (size_t)INT32_MAX) return fail(VRT_EINVAL, "too many items for the chained launch");
+    std::vector<int32_t> deps(p->h_patch_deps);
+    deps.insert(deps.end(), rdeps.begin(), rdeps.end());
+    if (p->d_chain_items) { (void)hipFree(p->d_chain_items); p->d_chain_items = nullptr; }
+    if (p->d_chain_deps) { (void)hipFree(p->d_chain_deps); p->d_chain_deps = nullptr; }
+    VRT_HIP_TRY(hipMalloc((void **)&p->d_chain_items, sizeof(int4) * std::max<size_t>(all.size(), 1)));
+    VRT_HIP_TRY(hipMalloc((void **)&p->d_chain_deps, sizeof(int32_t) * std::max<size_t>(deps.size(), 1)));
+    VRT_HIP_TRY(hipMemcpy(p->d_chain_items, all.data(), sizeof(int4) * all.size(), hipMemcpyHostToDevice));
+    VRT_HIP_TRY(hipMemcpy(p->d_chain_deps, deps.data(), sizeof(int32_t) * deps.size(), hipMemcpyHostToDevice));
+    const size_t words = (size_t)nsplit * (size_t)std::max<int64_t>(n_patches, 1);
+    if (words > p->chain_progress_cap) {
+        if (p->d_chain_progress) { (void)hipFree(p->d_chain_progress); p->d_chain_progress = nullptr; }
+        p->chain_progress_cap = 0;
+        VRT_HIP_TRY(hipMalloc((void **)&p->d_chain_progress, sizeof(uint32_t) * words));
+        p->chain_progress_cap = words;
+    }
+    // a new item set: the progress words start from zero (an epoch counts launches of ONE item set)
+    VRT_HIP_TRY(hipMemset(p->d_chain_progress, 0, sizeof(uint32_t) * p->chain_progress_cap));
+    p->chain_epoch = 0;
+    if (!p->d_chain_ctrl) VRT_HIP_TRY(hipMalloc((void **)&p->d_chain_ctrl, sizeof(uint32_t) * (kChainAbortWord + 4)));
+    if (!p->h_chain_status) {
+        VRT_HIP_TRY(hipHostMalloc((void **)&p->h_chain_status, 64, hipHostMallocMapped));
+        *p->h_chain_status = 0;
+        VRT_HIP_TRY(hipHostGetDevicePointer((void **)&p->d_chain_status, p->h_chain_status, 0));
+    }
+    p->chain_npair = npair;
+    p->chain_lgB = lgB;
+    p->chain_nsplit = nsplit;
+    p->chain_reduce = with_reduce ? 1 : 0;
+    p->chain_items = (int64_t)(all.size() / 2);
+    return VRT_OK;
+}
+
+template <typename T, int AM>
+static int launch_chain_mode(bool quad, int64_t items, size_t lds, hipStream_t st, const ChainDev *cd, uint32_t base)
+{
+    constexpr int NT = 512;
+    if constexpr (sizeof(T) == 4) {
+        if (quad) {
+            hipLaunchKernelGGL((k_patch_chain_quad<AM, NT>), dim3((unsigned)items), dim3(NT), lds, st, cd, base);
+            return VRT_OK;
+        }
+    }
+    hipLaunchKernelGGL((k_patch_chain<T, AM, NT>), dim3((unsigned)items), dim3(NT), lds, st, cd, base);
+    return VRT_OK;
+}
+
+// ONE launch for every layer of every active angle (and J_dir of both directions when `reduce` is given: its weights,
+// angle lists [0] = up, [1] = down and J_dir planes)
+int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t st, bool f32, const PatchReduce *reduce)
+{
+    // a give-up of an EARLIER chained launch of this plan (its results were wrong) is reported here at the latest
+    if (p->h_chain_status && *p->h_chain_status) {
+        *p->h_chain_status = 0;
+        return fail(VRT_ENODEVICE, "an earlier chained patch launch of this plan gave up waiting for a dependency (results invalid); VRT_PATCH_CHAIN=0 selects the per-layer launches");
+    }
+    const int lgB = native_lg(p, f32);
+    const bool quad = f32 && lgB >= 1 && p->tune.patch_quad != 0 && (npair & 1) == 0;
+    const int nblock = pair_block_count(npair, lgB);
+    const int nsplit = chain_nsplit(p, nblock);
+    int rc;
+    if ((rc = ensure_patch_chain(p, npair, lgB, nsplit, reduce != nullptr))) return rc;
+    if (p->chain_items == 0) return VRT_OK;
+    static_assert(std::is_trivially_copyable<ChainDev>::value, "ChainDev is uploaded byte for byte");
+    ChainDev h;
+    std::memset(&h, 0, sizeof(h));
+    h.ta = ta;
+    h.npair = npair;
+    h.nsplit = nsplit;
+    h.cap = p->patch_cap;
+    h.e_pos = p->e_pos; h.e_u1 = p->e_u1; h.e_u2 = p->e_u2;
+    h.e_vis = p->e_vis; h.e_loc = p->e_loc;
+    h.e_w1 = p->e_w1; h.e_w2 = p->e_w2; h.e_r1 = p->e_r1; h.e_r2 = p->e_r2;
+    if (reduce) h.red = *reduce;
+    h.items = p->d_chain_items;
+    for (int x = 0; x <= 8; x++) h.q_off[x] = p->chain_q_off[x];
+    h.deps = p->d_chain_deps;
+    h.progress = p->d_chain_progress;
+    h.ctrl = p->d_chain_ctrl;
+    h.host_status = p->d_chain_status;
+    h.n_patches = p->n_patches;
+    h.spin_limit = (uint32_t)std::max(1, p->tune.chain_spin) << 10;
+    h.dbg = kDiag ? p->tune.debug_flags : 0;
+    // the argument block travels only when it has changed (stream-ordered: behind the launches that read the old one)
+    if (!p->d_chain_dev) VRT_HIP_TRY(hipMalloc((void **)&p->d_chain_dev, sizeof(ChainDev)));
+    if (p->h_chain_dev.size() != sizeof(ChainDev) || std::memcmp(p->h_chain_dev.data(), &h, sizeof(h)) != 0) {
+        if (!p->h_chain_dev_pinned) VRT_HIP_TRY(hipHostMalloc((void **)&p->h_chain_dev_pinned, sizeof(ChainDev), hipHostMallocDefault));
+        // the pinned staging copy may still be in flight for an earlier launch: wait for that copy only
+        if (p->chain_dev_ev_valid) VRT_HIP_TRY(hipEventSynchronize(p->chain_dev_ev));
+        std::memcpy(p->h_chain_dev_pinned, &h, sizeof(h));
+        VRT_HIP_TRY(hipMemcpyAsync(p->d_chain_dev, p->h_chain_dev_pinned, sizeof(h), hipMemcpyHostToDevice, st));
+        if (!p->chain_dev_ev) VRT_HIP_TRY(hipEventCreateWithFlags(&p->chain_dev_ev, hipEventDisableTiming));
+        VRT_HIP_TRY(hipEventRecord(p->chain_dev_ev, st));
+        p->chain_dev_ev_valid = true;
+        p->h_chain_dev.assign(reinterpret_cast<const char *>(&h), reinterpret_cast<const char *>(&h) + sizeof(h));
+    }
+    // epochs count the launches of this item set; stale words compare as "behind" while epochs differ by < 2^22
+    p->chain_epoch++;
+    if ((p->chain_epoch & 0x3FFFFFu) == 0u) {
+        VRT_HIP_TRY(hipMemsetAsync(p->d_chain_progress, 0, sizeof(uint32_t) * p->chain_progress_cap, st));
+        p->chain_epoch = 1;
+    }
+    const uint32_t base = p->chain_epoch << 8;
+    VRT_HIP_TRY(hipMemsetAsync(p->d_chain_ctrl, 0, sizeof(uint32_t) * (kChainAbortWord + 4), st));
+    const size_t lds = (size_t)(quad ? 2 : 1) * (size_t)(p->patch_cap + 1) * sizeof(double2) + (size_t)p->patch_cap * (4 * sizeof(double) + 5 * sizeof(int32_t)) +
+                       sizeof(uint32_t) * (kCtlWords + 64 + kChainDepLds);
+    const ChainDev *cd = reinterpret_cast<const ChainDev *>(p->d_chain_dev);
+    switch (ta.alpha_mode) {
+    case VRT_ALPHA_SITE:
+        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_SITE>(quad, p->chain_items, lds, st, cd, base)
+                 : launch_chain_mode<double, VRT_ALPHA_SITE>(quad, p->chain_items, lds, st, cd, base);
+        break;
+    case VRT_ALPHA_SITE_LAM:
+        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_SITE_LAM>(quad, p->chain_items, lds, st, cd, base)
+                 : launch_chain_mode<double, VRT_ALPHA_SITE_LAM>(quad, p->chain_items, lds, st, cd, base);
+        break;
+    default:
+        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_ANGLE_SITE_LAM>(quad, p->chain_items, lds, st, cd, base)
+                 : launch_chain_mode<double, VRT_ALPHA_ANGLE_SITE_LAM>(quad, p->chain_items, lds, st, cd, base);
+        break;
+    }
+    if (rc) return rc;
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+// VRT_OK, or the give-up of a chained launch that has finished since the last check (introspection; no synchronisation)
+int patch_chain_check(vrt_plan *p)
+{
+    if (p->h_chain_status && *p->h_chain_status) {
+        *p->h_chain_status = 0;
+        return fail(VRT_ENODEVICE, "a chained patch launch gave up waiting for a dependency (results invalid)");
+    }
+    return VRT_OK;
 }
 
 }  // namespace vrt
