@@ -186,9 +186,10 @@ int vrt_plan_last_path(const vrt_plan *p);
  *   VRT_PATCH_Q, VRT_PATCH_TARGET              wavelength pairs at a time / workgroups per launch of the patch kernel
  *   VRT_PATCH_K, VRT_PATCH_NT, VRT_PATCH_OWN   entries per thread, threads, owned sites per patch (creation only)
  *   VRT_PATCH_LEAN = 0 | 1                     the 64-register patch kernel, four workgroups per CU (default 1)
- *   VRT_PATCH_CHAIN = 0 | 1                    every layer inside one launch, ordered by the data's own dependencies
- *                                              (default 1; 0 = one launch per layer and direction)
- *   VRT_CHAIN_PAIRS, VRT_CHAIN_SPIN            wavelength-pair blocks per item of the chained launch (default 5); polls
+ *   VRT_PATCH_CHAIN = 0 | 1 | 2                every layer inside ONE launch, ordered by the data's own dependencies: never
+ *                                              (one launch per layer and direction), wherever the kernel exists, auto
+ *                                              (default: where a layer alone cannot fill the chip)
+ *   VRT_CHAIN_PAIRS, VRT_CHAIN_SPIN            wavelength-pair blocks per item of the chained launch at most (default 9); polls
  *                                              (x 1024) after which a waiting workgroup gives up (default 2048)
  *   VRT_PATCH_QUAD = 0 | 1                     fp32 storage: four wavelengths per lane (creation only; default 1)
  *   VRT_PAIR_BLOCK = 1 | 2 | 4 | 8 | 16        wavelength pairs of a site side by side in the patch path's planes and

@@ -25,8 +25,7 @@ RTOL = 1e-10        # north star, fp64
 RTOL_F32 = 5e-6     # fp32 storage against the fp64 oracle
 
 
-def _rel(a, b):
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+from oracle.parity import rel as _rel     # element-wise: |a - b| < tol (|b| + smallest non-zero |b|) for EVERY element
 
 
 def _fields(pos, bounds, nlam, seed, alpha0=1e-2):

@@ -14,8 +14,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-10
 
 
-def _rel(a, b):
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+from oracle.parity import rel as _rel     # element-wise: |a - b| < tol (|b| + smallest non-zero |b|) for EVERY element
 
 
 @pytest.fixture(scope="module")

@@ -50,3 +50,98 @@ for ai in angles:
               f"live/site {ps['live_visits'] / own_sites:4.2f} max entries {ps['max_entries']:5d} "
               f"mean {ent.mean():6.0f} nlev mean {ps['patch_nlev'].mean():4.1f} max {ps['patch_nlev'].max():3d} "
               f"({time.time() - t0:.1f} s)", flush=True)
+
+
+def barrier_stats(ps, order_fn=None, wave=64):
+    """Level-loop barriers a patch needs when only CROSS-wave hazards are fenced: a barrier before level t is
+    needed when a visit of level t reads a tile slot of another wave written since the last barrier (RAW), or
+    overwrites its own slot that another wave has read since the last barrier (WAR).  order_fn(patch entries) ->
+    permutation of the entries (thread assignment); None = the schedule's own order.  Returns (levels, barriers
+    needed, fraction of in-patch read-from edges inside one wave) summed over the patches."""
+    eo = ps["patch_ent_off"]
+    tot_lev = tot_bar = 0
+    edges = same = 0
+    for q in range(ps["patches"]):
+        e0, e1 = int(eo[q]), int(eo[q + 1])
+        ne = e1 - e0
+        vis = ps["entry_vis"][e0:e1]
+        loc = ps["entry_loc"][e0:e1]
+        l1, l2 = (loc & 0xFFFF).astype(np.int64), (loc >> 16).astype(np.int64)
+        perm = np.arange(ne) if order_fn is None else order_fn(vis, l1, l2)
+        thread_of = np.empty(ne, dtype=np.int64)
+        thread_of[perm] = np.arange(ne)                       # entry -> thread
+        wv = thread_of // wave
+        nlev = int(ps["patch_nlev"][q])
+        written_since = np.zeros(ne, dtype=bool)              # slot written since the last barrier
+        readers_since = [set() for _ in range(ne)]            # waves that read the slot since the last barrier
+        bars = 0
+        for t in range(1, nlev + 1):
+            hit = np.nonzero(((vis & 0xFF) == t) | (((vis >> 8) & 0xFF) == t) | (((vis >> 16) & 0xFF) == t) | ((vis >> 24) == t))[0]
+            need = False
+            for e in hit:
+                for s in (l1[e], l2[e]):
+                    if s == 0xFFFF:
+                        continue
+                    edges += 1
+                    same += wv[s] == wv[e]
+                    if wv[s] != wv[e] and written_since[s]:
+                        need = True
+                if any(w != wv[e] for w in readers_since[e]):
+                    need = True
+            if need:
+                bars += 1
+                written_since[:] = False
+                readers_since = [set() for _ in range(ne)]
+            for e in hit:
+                for s in (l1[e], l2[e]):
+                    if s != 0xFFFF:
+                        readers_since[s].add(wv[e])
+            written_since[hit] = True
+        tot_lev += nlev
+        tot_bar += bars
+    return tot_lev, tot_bar, same / max(edges, 1)
+
+
+def cluster_order(vis, l1, l2):
+    """entries grouped with their in-patch upwinds: depth-first along the read-from edges, roots by first visit level"""
+    ne = vis.size
+    children = [[] for _ in range(ne)]
+    for e in range(ne):
+        for s in (l1[e], l2[e]):
+            if s != 0xFFFF and s != e:
+                children[s].append(e)
+    seen = np.zeros(ne, dtype=bool)
+    out = []
+    for r in np.argsort(vis & 0xFF, kind="stable"):
+        if seen[r]:
+            continue
+        stack = [r]
+        while stack:
+            e = stack.pop()
+            if seen[e]:
+                continue
+            seen[e] = True
+            out.append(e)
+            stack.extend(c for c in children[e] if not seen[c])
+    return np.array(out, dtype=np.int64)
+
+
+if os.environ.get("PROBE_BARRIERS"):
+    for ai in angles:
+        k = orc.direction(th[ai], ph[ai])
+        up = orc.upwind_table(so, k)[0]
+        d = 1 if th[ai] > 90 else -1
+        ps = vrt.api.build_patch_schedule(hs, d, up, 3, 512, 512)
+        # a sample of the patches (the analysis is a Python loop)
+        keep = np.linspace(0, ps["patches"] - 1, min(ps["patches"], int(os.environ.get("PROBE_SAMPLE", "200")))).astype(int)
+        sub = dict(ps)
+        sub["patches"] = keep.size
+        eo = ps["patch_ent_off"]
+        sub["patch_ent_off"] = np.concatenate([[0], np.cumsum((eo[keep + 1] - eo[keep]))])
+        sub["patch_nlev"] = ps["patch_nlev"][keep]
+        sub["entry_vis"] = np.concatenate([ps["entry_vis"][eo[q]:eo[q + 1]] for q in keep])
+        sub["entry_loc"] = np.concatenate([ps["entry_loc"][eo[q]:eo[q + 1]] for q in keep])
+        for name, fn in (("schedule order", None), ("clustered", cluster_order)):
+            lev, bar, frac = barrier_stats(sub, fn)
+            print(f"angle {ai:2d} theta {th[ai]:6.1f} {name:15s}: levels/patch {lev / keep.size:5.1f} cross-wave barriers/patch "
+                  f"{bar / keep.size:5.1f} in-wave edges {frac:5.3f}", flush=True)

@@ -57,7 +57,7 @@ int tuning_set(Tuning &t, const char *name, const char *value, bool created)
         {"VRT_PATCH_OWN", &t.patch_own, 0, 65535, true}, {"VRT_PATCH_Q", &t.patch_Q, 1, 4, false},
         {"VRT_PATCH_TARGET", &t.patch_target, 1, 1 << 20, false}, {"VRT_PAIR_BLOCK", &t.pair_block, 1, 16, true},
         {"VRT_PATCH_QUAD", &t.patch_quad, 0, 1, true}, {"VRT_PATCH_LEAN", &t.patch_lean, 0, 1, false},
-        {"VRT_PATCH_CHAIN", &t.patch_chain, 0, 1, false}, {"VRT_CHAIN_PAIRS", &t.chain_pairs, 1, 256, false},
+        {"VRT_PATCH_CHAIN", &t.patch_chain, 0, 2, false}, {"VRT_CHAIN_PAIRS", &t.chain_pairs, 1, 256, false},
         {"VRT_CHAIN_SPIN", &t.chain_spin, 1, 1 << 20, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
         {"VRT_DEBUG_SKIP_LEVELS", &t.debug_skip_levels, 0, 1, false}, {"VRT_TILE_DEBUG", &t.tile_debug, 0, 1, false},
     };
@@ -276,17 +276,15 @@ static int ensure_level_schedule(vrt_plan *p)
         unsigned hw = std::thread::hardware_concurrency();
         int nthr = (int)std::min<unsigned>(hw ? hw : 4, 16);
         nthr = std::max(1, std::min(nthr, std::max(A, 1)));
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthr; t++)
-            pool.emplace_back([&, t]() {
+        if (!run_workers(nthr, [&](int t) {
                 for (int a = t; a < A; a += nthr) {
                     const bool up = p->dir_of_active[(size_t)a] > 0;
                     build_angle_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
                                          p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n,
                                          sched[(size_t)a]);
                 }
-            });
-        for (auto &th : pool) th.join();
+            }))
+            return fail(VRT_ENOMEM, "out of host memory while building the level schedule");
     }
     int64_t max_levels = 0, total = 0;
     for (int a = 0; a < A; a++) {
@@ -471,9 +469,8 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         unsigned hw = std::thread::hardware_concurrency();
         int nthr = (int)std::min<unsigned>(hw ? hw : 4, 16);
         nthr = std::max(1, std::min(nthr, A));
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthr; t++)
-            pool.emplace_back([&, t]() {
+        // (every schedule build holds a visit trace of up to n_sweeps n entries and a dozen n-sized arrays)
+        if (!run_workers(nthr, [&](int t) {
                 for (int a = t; a < A; a += nthr) {
                     const bool up = p->dir_of_active[(size_t)a] > 0;
                     build_layer_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
@@ -486,8 +483,10 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                                              patch_own, p->patch_cap, psched[(size_t)a]);
                     }
                 }
-            });
-        for (auto &th : pool) th.join();
+            })) {
+            free_plan(p);
+            return fail(VRT_ENOMEM, "out of host memory while building the sweep schedules");
+        }
     }
     for (int a = 0; a < A; a++) {
         if (lsched[(size_t)a].bad_site >= 0) {

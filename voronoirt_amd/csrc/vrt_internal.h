@@ -3,9 +3,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "voronoirt.h"
@@ -35,6 +37,39 @@ struct DeviceScope {
     DeviceScope(const DeviceScope &) = delete;
     DeviceScope &operator=(const DeviceScope &) = delete;
 };
+
+// Runs body(t) for t = 0 .. count-1 on `count` host threads.  A worker must not throw (an exception that leaves a
+// std::thread's function is std::terminate for the whole host process -- Julia or Python): every body runs inside a
+// try block, and a thread that cannot be created has its share done by the calling thread.  Returns false when a
+// body threw (std::bad_alloc in practice: the callers report VRT_ENOMEM).
+template <typename Body>
+inline bool run_workers(int count, Body body)
+{
+    std::vector<char> threw((size_t)std::max(count, 1), 0);
+    auto guarded = [&](int t) {
+        try {
+            body(t);
+        } catch (...) {
+            threw[(size_t)t] = 1;
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        pool.reserve((size_t)std::max(count, 1));
+    } catch (...) {
+    }
+    for (int t = 0; t < count; t++) {
+        try {
+            pool.emplace_back(guarded, t);
+        } catch (...) {
+            guarded(t);
+        }
+    }
+    for (auto &th : pool) th.join();
+    for (int t = 0; t < count; t++)
+        if (threw[(size_t)t]) return false;
+    return true;
+}
 
 constexpr int kMaxAngles = 64;          // active angles per plan (kernel-argument weight table)
 constexpr int64_t kMaxGuess = 70;       // read_cell's neighbour cap, voronoi_utils.jl:42
@@ -85,9 +120,10 @@ struct Tuning {
                                   //   (k_patch_quad; creation only: the native float alpha is laid out with it)
     int patch_lean = 1;           // VRT_PATCH_LEAN: the 64-register form of the (1, 1, NT) kernel (four workgroups per CU;
                                   //   default for two and more wavelength pairs)
-    int patch_chain = 1;          // VRT_PATCH_CHAIN: every layer inside ONE persistent launch (k_patch_chain) instead of one
-                                  //   launch per layer and direction; 0 = the per-layer launches
-    int chain_pairs = 5;          // VRT_CHAIN_PAIRS: wavelength-pair blocks an item of the chained launch solves
+    int patch_chain = 2;          // VRT_PATCH_CHAIN: every layer inside ONE chained launch (k_patch_chain) instead of one launch
+                                  //   per layer and direction: 0 never, 1 wherever it exists, 2 = auto: where a layer
+                                  //   alone cannot fill the chip (patch_chain_possible)
+    int chain_pairs = 9;          // VRT_CHAIN_PAIRS: wavelength-pair blocks an item of the chained launch solves at most
     int chain_spin = 2048;        // VRT_CHAIN_SPIN: polls (x 1024) after which a waiting workgroup gives up (~2 s)
     int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
     int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)

@@ -16,22 +16,28 @@
 #include <new>
 #include <thread>
 
-#include <rccl/rccl.h>
-
 #include "vrt_internal.h"
 
 using namespace vrt;
 
 namespace {
 
+// The few RCCL entry points this file calls, declared here: librccl is dlopen'ed on first use, and the library builds
+// (and serves one device) on a ROCm installation without the RCCL development headers.  The values are NCCL's ABI.
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr int ncclDouble = 8, ncclSum = 0;
+
 struct Rccl {
     void *lib = nullptr;
-    decltype(&ncclCommInitAll) CommInitAll = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclAllReduce) AllReduce = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool load()
     {
         if (lib) return true;
@@ -43,10 +49,11 @@ struct Rccl {
         CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
         AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        Reduce = (decltype(Reduce))dlsym(lib, "ncclReduce");
         GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-        return CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd && GetErrorString;
+        return CommInitAll && CommDestroy && AllReduce && Reduce && GroupStart && GroupEnd && GetErrorString;
     }
 };
 
@@ -150,9 +157,7 @@ int vrt_multi_create(int n_devices, const int *devices, int64_t n, const double 
                 if (devices[e] == devices[d]) mm->distinct = false;
         }
         // one grid + all-angle plan per device, built concurrently (plan creation is host-side schedule work)
-        std::vector<std::thread> pool;
-        for (int d = 0; d < n_devices; d++)
-            pool.emplace_back([&, d]() {
+        if (!run_workers(n_devices, [&](int d) {
                 Member &me = mm->m[(size_t)d];
                 me.rc = vrt_grid_create(n, pos_zxy, nbr, D1, bounds, me.device, &me.grid);
                 if (!me.rc) me.rc = vrt_plan_create_ex(me.grid, n_angles, k, mm->dirs.data(), n_sweeps, &me.plan_all);
@@ -160,8 +165,10 @@ int vrt_multi_create(int n_devices, const int *devices, int64_t n, const double 
                                hipStreamCreateWithFlags(&me.stream, hipStreamNonBlocking) != hipSuccess))
                     me.rc = fail(VRT_ENODEVICE, "cannot create a stream");
                 if (me.rc) me.err = vrt_last_error();
-            });
-        for (auto &t : pool) t.join();
+            })) {
+            multi_free(mm);
+            return fail(VRT_ENOMEM, "out of host memory while creating the per-device plans");
+        }
         for (const Member &me : mm->m)
             if (me.rc) {
                 const int rc = me.rc;
@@ -265,6 +272,7 @@ int vrt_multi_execute(vrt_multi *mm, int64_t nlam, int64_t ld, const double *S, 
                 if (shard == 2) {
                     if ((me.rc = ensure(me.dJ, me.cJ, (size_t)n * (size_t)nlam))) { me.err = vrt_last_error(); return; }
                     chk(hipMemsetAsync(me.dJ, 0, w8 * (size_t)n * (size_t)nlam, st), "hipMemsetAsync");
+                    chk(hipStreamSynchronize(st), "hipStreamSynchronize");      // another member's stream reads these zeros
                 }
                 return;
             }
@@ -316,24 +324,27 @@ int vrt_multi_execute(vrt_multi *mm, int64_t nlam, int64_t ld, const double *S, 
                 chk(hipMemcpy2DAsync(J + l0, w8 * (size_t)ld, me.dJ, w8 * (size_t)nb, w8 * (size_t)nb, (size_t)n, hipMemcpyDeviceToHost, st), "download J");
             chk(hipStreamSynchronize(st), "hipStreamSynchronize");
         };
-        std::vector<std::thread> pool;
-        for (int d = 0; d < W; d++) pool.emplace_back(work, d);
-        for (auto &t : pool) t.join();
+        if (!run_workers(W, work)) return fail(VRT_ENOMEM, "out of host memory in a device worker");
         for (const Member &me : mm->m)
             if (me.rc) return fail(me.rc, "device " + std::to_string(me.device) + ": " + me.err);
         if (shard == 2) {
-            // J = Σ over the devices' partial sums: ONE all-reduce over xGMI (or, on a shared device, adds)
+            // J = Σ over the devices' partial sums, wanted on ONE device only (the host array is filled from device 0):
+            // one RCCL reduce to rank 0 over xGMI -- half the bytes of an all-reduce -- or, on a shared device, adds
             const size_t cnt = (size_t)n * (size_t)nlam;
             if (!mm->comms.empty()) {
+                // (nothing may return between GroupStart and GroupEnd: an open group poisons every later call)
                 ncclResult_t r = mm->rccl.GroupStart();
-                for (int d = 0; d < W && r == ncclSuccess; d++) {
+                hipError_t he = hipSuccess;
+                for (int d = 0; d < W && r == ncclSuccess && he == hipSuccess; d++) {
                     Member &me = mm->m[(size_t)d];
-                    VRT_HIP_TRY(hipSetDevice(me.device));
-                    r = mm->rccl.AllReduce(me.dJ, me.dJ, cnt, ncclDouble, ncclSum, mm->comms[(size_t)d], me.stream);
+                    he = hipSetDevice(me.device);
+                    if (he == hipSuccess)
+                        r = mm->rccl.Reduce(me.dJ, me.dJ, cnt, ncclDouble, ncclSum, 0, mm->comms[(size_t)d], me.stream);
                 }
                 const ncclResult_t r2 = mm->rccl.GroupEnd();
+                if (he != hipSuccess) return fail(VRT_ENODEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he));
                 if (r != ncclSuccess || r2 != ncclSuccess)
-                    return fail(VRT_ENODEVICE, std::string("ncclAllReduce: ") + mm->rccl.GetErrorString(r != ncclSuccess ? r : r2));
+                    return fail(VRT_ENODEVICE, std::string("ncclReduce: ") + mm->rccl.GetErrorString(r != ncclSuccess ? r : r2));
                 for (Member &me : mm->m) {
                     VRT_HIP_TRY(hipSetDevice(me.device));
                     VRT_HIP_TRY(hipStreamSynchronize(me.stream));

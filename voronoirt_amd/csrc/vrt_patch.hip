@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1020,15 +1021,14 @@ k_patch_quad(PatchArgs pa)
 
 
 // ---- the chained launch --------------------------------------------------------------------------------------------
-// Items (two int4 each), per XCD queue in layer order:
+// Items (three int4 each), per XCD queue in layer order:
 //   solve:   A = (first entry, first owned position, entries | owned << 10 | levels << 20, angle | dir << 6 | split << 7 | layer << 16)
-//            B = (first dependency, dependencies, patch, 0)
+//            B = (first dependency, dependencies, patch, 0)     C = (lo, hi: storage positions of the patch's layer)
 //   reduce:  A = (lo, hi, 1 << 31, dir << 6 | split << 7): J_dir of storage positions [lo, hi), pairs of the split
 //            B = (first dependency, dependencies, 0, steps the dependencies must have published)
 //   padding: A = (0, 0, 1 << 30, 0): nothing (the queues advance through the layers in step, see ensure_patch_chain)
-// The launch's arguments live in device memory (ChainDev) and are re-read by every item: a persistent loop around
-// the patch solver must not keep forty kernel arguments alive in scalar registers across it (the solver alone
-// needs 72 of the 80 that eight waves per SIMD allow).
+// The launch's arguments (ChainDev) are kernel arguments; a copy in device memory serves the give-up path, which
+// reaches it through a pointer parked in LDS (nothing of the chain lives in registers across the solver).
 struct ChainDev {
     TileArgs ta;
     int npair, nsplit, cap;
@@ -1045,7 +1045,7 @@ struct ChainDev {
     int64_t n_patches;
     uint32_t spin_limit;
     int dbg;                   // timing diagnostics (-DVRT_DIAG build only, WRONG results): the flags of PatchArgs::dbg, and
-                               //   256 no waiting for dependencies, 512 plain (L1-cached) intensity gathers, 1024 plain intensity stores
+                               //   256 no waiting for dependencies, 512 plain (L1-cached) intensity gathers, 1024 plain intensity stores, 2048 no pair loop
 };
 
 // uniform (scalar-register) reads of the argument block
@@ -1086,16 +1086,17 @@ __device__ __forceinline__ void chain_wait_slow(const int32_t *s_dep, int step)
 // J_dir over storage positions [lo, hi) of direction r for the pair blocks [b0, b1): the reduction of
 // patch_reduce_role, every intensity read by an sc1 load
 template <typename T, int NT, int LGB>
-__device__ __forceinline__ void chain_reduce(const ChainDev *cd, int r, int lo, int hi, int b0, int b1)
+__device__ __forceinline__ void chain_reduce(const ChainDev &cd, int r, int lo, int hi, int b0, int b1)
 {
     typedef typename Pair<T>::type T2;
     const int tid = threadIdx.x;
-    const int64_t nn = cd->ta.n;
-    const int npair = cd_int(&cd->npair);
+    if (kDiag && (cd.dbg & 128)) return;
+    const int64_t nn = cd.ta.n;
+    const int npair = cd.npair;
     const size_t plane = (size_t)npair * (size_t)nn;
-    T2 *Jd = reinterpret_cast<T2 *>(cd_ptr(&cd->red.Jd[r]));
-    const T2 *I0 = reinterpret_cast<const T2 *>(cd_ptr(&cd->ta.I));
-    const int count = cd_int(&cd->red.count[r]);
+    T2 *Jd = reinterpret_cast<T2 *>(cd.red.Jd[r]);
+    const T2 *I0 = reinterpret_cast<const T2 *>(cd.ta.I);
+    const int count = cd.red.count[r];
     constexpr int lgT2 = Log2Size<T2>::value;
     for (int bk = b0; bk < b1; bk++) {
         const int k0 = bk << LGB;
@@ -1104,8 +1105,8 @@ __device__ __forceinline__ void chain_reduce(const ChainDev *cd, int r, int lo, 
         for (size_t f = (size_t)tid; f < run; f += NT) {
             double ax = 0.0, ay = 0.0;
             for (int j = 0; j < count; j++) {                // the reference's angle order (lambda_iteration.jl:84,102,107)
-                const int a = cd_int(&cd->red.angles[r][j]);
-                const double wa = cd->red.w[a];
+                const int a = cd.red.angles[r][j];
+                const double wa = cd.red.w[a];
                 const __amdgpu_buffer_rsrc_t rs = plane_rsrc(I0 + (size_t)a * plane + base, (unsigned)(run << lgT2));
                 const double2 v = to_d2(BufSc1<T2>::load(rs, (unsigned)(f << lgT2)));
                 ax += wa * v.x;
@@ -1122,7 +1123,7 @@ __device__ __forceinline__ void chain_reduce(const ChainDev *cd, int r, int lo, 
 // taken in order by workgroups that are running, so the argument about progress above holds whatever order the
 // blocks of the grid start in; the grid has exactly one block per item.
 template <typename T, int AM, int NT, bool QUAD>
-__device__ __forceinline__ void chain_item(const ChainDev *cd, uint32_t base, double2 *ptile)
+__device__ __forceinline__ void chain_item(const ChainDev &ca, const ChainDev *cd, uint32_t base, double2 *ptile)
 {
     const int tid = threadIdx.x;
     constexpr int PLANES = QUAD ? 2 : 1;
@@ -1134,10 +1135,10 @@ __device__ __forceinline__ void chain_item(const ChainDev *cd, uint32_t base, do
     if (tid == 0) {
         // next item of this block's queue, in order (blocks x, x + 8, ... share an XCD: speed only); an exhausted
         // queue -> the next one (load balance at the end)
-        uint32_t *ctrl = cd->ctrl;
+        uint32_t *ctrl = ca.ctrl;
         int q = (int)(blockIdx.x & 7u), idx = -1;
         for (int tries = 0; tries < 8; tries++) {
-            const int o0 = cd->q_off[q], len = cd->q_off[q + 1] - o0;
+            const int o0 = ca.q_off[q], len = ca.q_off[q + 1] - o0;
             const uint32_t t = len > 0 ? __hip_atomic_fetch_add(ctrl + q * kChainHeadStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                        : 0u;
             if (len > 0 && t < (uint32_t)len) { idx = o0 + (int)t; break; }
@@ -1150,8 +1151,8 @@ __device__ __forceinline__ void chain_item(const ChainDev *cd, uint32_t base, do
     __syncthreads();
     const int idx = __builtin_amdgcn_readfirstlane((int)s_ctl[kCtlItem]);
     if (idx < 0) return;
-    const int4 *items = cd->items;
-    const int4 A4 = items[2 * (size_t)idx], B4 = items[2 * (size_t)idx + 1];
+    const int4 *items = ca.items;
+    const int4 A4 = items[3 * (size_t)idx], B4 = items[3 * (size_t)idx + 1], C4 = items[3 * (size_t)idx + 2];
     const int Ax = __builtin_amdgcn_readfirstlane(A4.x), Ay = __builtin_amdgcn_readfirstlane(A4.y);
     const uint32_t Az = (uint32_t)__builtin_amdgcn_readfirstlane(A4.z), Aw = (uint32_t)__builtin_amdgcn_readfirstlane(A4.w);
     const int Bx = __builtin_amdgcn_readfirstlane(B4.x), By = __builtin_amdgcn_readfirstlane(B4.y);
@@ -1159,22 +1160,22 @@ __device__ __forceinline__ void chain_item(const ChainDev *cd, uint32_t base, do
     if (Az & 0x40000000u) return;                            // padding: every queue holds as many items of a layer as the longest
     {
         // dependency slots: the list (its first kChainDepLds entries), padded with the item's own patch to a multiple of 64
-        const int32_t *deps = cd->deps;
+        const int32_t *deps = ca.deps;
         const int padded = min(kChainDepLds + 64, (By + 63) / 64 * 64 + (By == 0 ? 64 : 0));
         for (int j = tid; j < padded; j += NT) s_dep[j] = j < By ? deps[Bx + j] : Bz;
     }
     const int d = (int)((Aw >> 6) & 1u), split = (int)((Aw >> 7) & 0x1FFu);
-    const int npair = cd_int(&cd->npair);
+    const int npair = ca.npair;
     int b0, b1;
     {
         // blocks [b0, b1) of the split: dealt evenly as split_blocks does (Q = 1)
-        const int nblock = npair >> LGB, nsplit = cd_int(&cd->nsplit);
+        const int nblock = npair >> LGB, nsplit = ca.nsplit;
         const int per = nblock / nsplit, rem = nblock - per * nsplit;
         b0 = split * per + (split < rem ? split : rem);
         b1 = b0 + per + (split < rem ? 1 : 0);
     }
     if (tid == 0) {                                          // (read behind the barrier that publishes the dependency list)
-        const uint64_t prog = (uint64_t)(cd->progress + (size_t)split * (size_t)cd->n_patches);
+        const uint64_t prog = (uint64_t)(ca.progress + (size_t)split * (size_t)ca.n_patches);
         s_ctl[kCtlSelf] = (uint32_t)Bz;
         s_ctl[kCtlNdep] = (uint32_t)By;
         s_ctl[kCtlDepOff] = (uint32_t)Bx;
@@ -1185,7 +1186,7 @@ __device__ __forceinline__ void chain_item(const ChainDev *cd, uint32_t base, do
     if (Az >> 31) {                                          // ---- J_dir of a finished range ----------------------------
         __syncthreads();                                     // the dependency list is in LDS
         chain_wait(s_dep, Bw, chain_peek(s_dep, Bw));
-        chain_reduce<T, NT, LGB>(cd, d, Ax, Ay, b0, b1);
+        chain_reduce<T, NT, LGB>(ca, d, Ax, Ay, b0, b1);
         return;
     }
     PatchItem it;
@@ -1193,26 +1194,23 @@ __device__ __forceinline__ void chain_item(const ChainDev *cd, uint32_t base, do
     it.ent_off = Ax; it.own_lo = Ay;
     it.n_ent = (int)(Az & 0x3FFu); it.own_cnt = (int)((Az >> 10) & 0x3FFu); it.nlev = (int)((Az >> 20) & 0xFFu);
     it.a = (int)(Aw & 63u); it.d = d;
-    {
-        const int layer = (int)(Aw >> 16);
-        const int32_t *lay = cd->ta.lay[d];
-        it.lo = __builtin_amdgcn_readfirstlane(lay[layer - 1]);
-        it.hi = __builtin_amdgcn_readfirstlane(lay[layer]);
-    }
+    it.lo = __builtin_amdgcn_readfirstlane(C4.x);
+    it.hi = __builtin_amdgcn_readfirstlane(C4.y);
     PairIO pa;
-    pa.n = cd_int(reinterpret_cast<const int *>(&cd->ta.n));                     // n < 2^28
+    pa.n = (int)ca.ta.n;                                     // n < 2^28
     pa.npair = npair;
     pa.lgB = LGB;
-    pa.dbg = kDiag ? cd_int(&cd->dbg) : 0;
-    pa.S = cd_ptr(&cd->ta.S[d]);
-    pa.I = cd_ptr(&cd->ta.I);
-    pa.alpha = AM == VRT_ALPHA_ANGLE_SITE_LAM ? (const void *)cd_ptr(&cd->ta.alpha_angle) : (const void *)cd_ptr(&cd->ta.alpha[d]);
-    tab.park(*cd, it, tid);
+    pa.dbg = kDiag ? ca.dbg : 0;
+    pa.S = ca.ta.S[d];
+    pa.I = ca.ta.I;
+    pa.alpha = AM == VRT_ALPHA_ANGLE_SITE_LAM ? (const void *)ca.ta.alpha_angle : (const void *)ca.ta.alpha[d];
+    tab.park(ca, it, tid);
     if (tid == 0) {
         ptile[it.n_ent] = make_double2(0.0, 0.0);            // the zero slot(s)
         if (QUAD) ptile[NT + 1 + it.n_ent] = make_double2(0.0, 0.0);
     }
     __syncthreads();                                         // the dependency list is in LDS
+    if (kDiag && (ca.dbg & 2048)) it.b1 = it.b0;             // diagnostics: the item's overhead alone
     if constexpr (QUAD) quad_pairs<AM, NT, true>(pa, it, tab, ptile);
     else lean_pairs<T, AM, NT, true>(pa, it, tab, ptile);
     // the last pair: every storing wave drains, then ONE lane publishes the finished item
@@ -1223,17 +1221,17 @@ __device__ __forceinline__ void chain_item(const ChainDev *cd, uint32_t base, do
 
 template <typename T, int AM, int NT>
 __global__ void __launch_bounds__(NT) VRT_LEAN_ATTR
-k_patch_chain(const ChainDev *cd, uint32_t base)
+k_patch_chain(ChainDev ca, const ChainDev *cd, uint32_t base)
 {
     extern __shared__ __attribute__((aligned(16))) double2 ptile[];
-    chain_item<T, AM, NT, false>(cd, base, ptile);
+    chain_item<T, AM, NT, false>(ca, cd, base, ptile);
 }
 template <int AM, int NT>
 __global__ void __launch_bounds__(NT) VRT_QUAD_ATTR
-k_patch_chain_quad(const ChainDev *cd, uint32_t base)
+k_patch_chain_quad(ChainDev ca, const ChainDev *cd, uint32_t base)
 {
     extern __shared__ __attribute__((aligned(16))) double2 ptile[];
-    chain_item<float, AM, NT, true>(cd, base, ptile);
+    chain_item<float, AM, NT, true>(ca, cd, base, ptile);
 }
 
 // the instantiated launch shapes (entries per thread, pairs at a time, threads)
@@ -1417,13 +1415,26 @@ bool patch_chain_possible(const vrt_plan *p, int npair, bool f32)
     if (lgB - (quad ? 1 : 0) != 0) return false;
     if (!f32 && p->tune.patch_lean == 0) return false;             // VRT_PATCH_LEAN=0 asks for the 72-register kernel
     if (p->tile_max_layers >= 65535 || p->A > 63) return false;    // item encoding
-    return true;
+    if (p->tune.patch_chain == 1) return true;
+    // auto: the chained launch where a layer alone cannot fill the chip -- its items cost ~5 us more than those of a
+    // per-layer launch (ticket, item record, the final drain before the progress word), which pays while the per-layer
+    // launches are bound by their 286-launch chain (C2 0.85 -> 0.54 ms, 1 M sites x 7 wavelengths 2.10 -> 1.73 ms)
+    // and not when the pair loops saturate the chip (C4 7.5 -> 8.4 ms).  Measured crossover:
+    // patches of a layer (both directions) x wavelength-pair blocks ~ 1500.  fp32 storage: on request only.
+    if (f32) return false;
+    const double per_layer = (double)p->n_patches / (double)std::max(1, p->tile_max_layers);
+    return per_layer * (double)pair_block_count(npair, lgB) <= 1536.0;
 }
 
+// Items per patch: enough that ONE layer (both directions) offers about as many items as the chip holds workgroups
+// (1024: a workgroup takes its item in queue order and, if the item's layer is not ready, waits for it while holding
+// its place -- items of a later layer started early are slots spent waiting), and at most VRT_CHAIN_PAIRS blocks each
 static int chain_nsplit(const vrt_plan *p, int nblock)
 {
     const int per = std::max(1, p->tune.chain_pairs);
-    return std::max(1, std::min({(nblock + per / 2) / per, nblock, 511}));
+    const double per_layer = (double)p->n_patches / (double)std::max(1, p->tile_max_layers);
+    const int fill = (int)std::ceil(1024.0 / std::max(1.0, per_layer));
+    return std::max(1, std::min({std::max((nblock + per - 1) / per, fill), nblock, 511}));
 }
 
 // Items of the chained launch for `npair` pairs in blocks of 2^lgB, `nsplit` items per patch: eight queues (XCD x
@@ -1469,6 +1480,7 @@ static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool 
             while (q[x].size() < longest) {
                 q[x].push_back(make_int4(0, 0, 0x40000000, 0));
                 q[x].push_back(make_int4(0, 0, 0, 0));
+                q[x].push_back(make_int4(0, 0, 0, 0));
             }
     };
     auto emit_reduce = [&](int layer) {
@@ -1496,12 +1508,15 @@ static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool 
                 for (int s = 0; s < nsplit; s++) {
                     q[x].push_back(make_int4((int)clo, (int)chi, (int)0x80000000u, (d << 6) | (s << 7)));
                     q[x].push_back(make_int4((int)(dep_base + d0), (int)(rdeps.size() - d0), 0, steps[(size_t)s]));
+                    q[x].push_back(make_int4(0, 0, 0, 0));
                 }
             }
         }
     };
     for (int layer = 2; layer <= maxL; layer++) {
         for (int d = 0; d < 2; d++) {
+            const Direction &dir = d == 0 ? g->up : g->down;
+            if (layer > (int)dir.reduced.size() - 1) continue;
             items.clear();
             for (size_t j = 0; j < dir_angles[d].size(); j++) {
                 const int a = dir_angles[d][j];
@@ -1523,6 +1538,7 @@ static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool 
                         q[x].push_back(make_int4(rec.x, rec.z, rec.y | (rec.w << 10) | (rec2.x << 20),
                                                  rec2.y | (d << 6) | (s << 7) | (layer << 16)));
                         q[x].push_back(make_int4((int)o0, (int)(o1 - o0), pq, 0));
+                        q[x].push_back(make_int4((int)(dir.reduced[(size_t)layer - 1] - 1), (int)(dir.reduced[(size_t)layer] - 1), 0, 0));
                     }
                 }
             }
@@ -1536,12 +1552,12 @@ static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool 
     level_queues();
     std::vector<int4> all;
     for (int x = 0; x < 8; x++) {
-        p->chain_q_off[x] = (int)(all.size() / 2);
+        p->chain_q_off[x] = (int)(all.size() / 3);
         all.insert(all.end(), q[x].begin(), q[x].end());
         std::vector<int4>().swap(q[x]);
     }
-    p->chain_q_off[8] = (int)(all.size() / 2);
-    if (all.size() / 2 >= (size_t)INT32_MAX) return fail(VRT_EINVAL, "too many items for the chained launch");
+    p->chain_q_off[8] = (int)(all.size() / 3);
+    if (all.size() / 3 >= (size_t)INT32_MAX) return fail(VRT_EINVAL, "too many items for the chained launch");
     std::vector<int32_t> deps(p->h_patch_deps);
     deps.insert(deps.end(), rdeps.begin(), rdeps.end());
     if (p->d_chain_items) { (void)hipFree(p->d_chain_items); p->d_chain_items = nullptr; }
@@ -1570,21 +1586,21 @@ static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool 
     p->chain_lgB = lgB;
     p->chain_nsplit = nsplit;
     p->chain_reduce = with_reduce ? 1 : 0;
-    p->chain_items = (int64_t)(all.size() / 2);
+    p->chain_items = (int64_t)(all.size() / 3);
     return VRT_OK;
 }
 
 template <typename T, int AM>
-static int launch_chain_mode(bool quad, int64_t items, size_t lds, hipStream_t st, const ChainDev *cd, uint32_t base)
+static int launch_chain_mode(bool quad, int64_t items, size_t lds, hipStream_t st, const ChainDev &h, const ChainDev *cd, uint32_t base)
 {
     constexpr int NT = 512;
     if constexpr (sizeof(T) == 4) {
         if (quad) {
-            hipLaunchKernelGGL((k_patch_chain_quad<AM, NT>), dim3((unsigned)items), dim3(NT), lds, st, cd, base);
+            hipLaunchKernelGGL((k_patch_chain_quad<AM, NT>), dim3((unsigned)items), dim3(NT), lds, st, h, cd, base);
             return VRT_OK;
         }
     }
-    hipLaunchKernelGGL((k_patch_chain<T, AM, NT>), dim3((unsigned)items), dim3(NT), lds, st, cd, base);
+    hipLaunchKernelGGL((k_patch_chain<T, AM, NT>), dim3((unsigned)items), dim3(NT), lds, st, h, cd, base);
     return VRT_OK;
 }
 
@@ -1650,16 +1666,16 @@ int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t s
     const ChainDev *cd = reinterpret_cast<const ChainDev *>(p->d_chain_dev);
     switch (ta.alpha_mode) {
     case VRT_ALPHA_SITE:
-        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_SITE>(quad, p->chain_items, lds, st, cd, base)
-                 : launch_chain_mode<double, VRT_ALPHA_SITE>(quad, p->chain_items, lds, st, cd, base);
+        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_SITE>(quad, p->chain_items, lds, st, h, cd, base)
+                 : launch_chain_mode<double, VRT_ALPHA_SITE>(quad, p->chain_items, lds, st, h, cd, base);
         break;
     case VRT_ALPHA_SITE_LAM:
-        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_SITE_LAM>(quad, p->chain_items, lds, st, cd, base)
-                 : launch_chain_mode<double, VRT_ALPHA_SITE_LAM>(quad, p->chain_items, lds, st, cd, base);
+        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_SITE_LAM>(quad, p->chain_items, lds, st, h, cd, base)
+                 : launch_chain_mode<double, VRT_ALPHA_SITE_LAM>(quad, p->chain_items, lds, st, h, cd, base);
         break;
     default:
-        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_ANGLE_SITE_LAM>(quad, p->chain_items, lds, st, cd, base)
-                 : launch_chain_mode<double, VRT_ALPHA_ANGLE_SITE_LAM>(quad, p->chain_items, lds, st, cd, base);
+        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_ANGLE_SITE_LAM>(quad, p->chain_items, lds, st, h, cd, base)
+                 : launch_chain_mode<double, VRT_ALPHA_ANGLE_SITE_LAM>(quad, p->chain_items, lds, st, h, cd, base);
         break;
     }
     if (rc) return rc;
