@@ -13,6 +13,10 @@
  *                           comes back; prints the history, J, S_new and the populations.  The per-site
  *                           inputs (what Λ_voronoi derives before its loop) are read from a binary file
  *                           the test writes, as the Julia driver would hand over its arrays.
+ *   scenario 4 (argv[1]=4, the same inputs file with head[3] = number of device handles): that loop across
+ *                           several GPUs of the node (vrt_multi_create + vrt_multi_lambda_*): wavelength blocks per
+ *                           device, ONE all-reduce of the rate-integral shares per iteration; devices from
+ *                           VRT_DEVICES ("0,1,2,3"), else head[3] handles on device 0 (one-GPU rehearsal).
  * Build:
  *   gcc -std=c99 -I include examples/c_caller.c -o c_caller -L voronoirt_amd -lvrt_hip \
  *       -Wl,-rpath,$PWD/voronoirt_amd -lm
@@ -86,7 +90,8 @@ static double *rd(FILE *f, size_t count)
     return a;
 }
 
-static int scenario_lambda(vrt_grid *g, int n, const char *path)
+static int scenario_lambda(vrt_grid *g, int n, const char *path, const double *pos, const int64_t *nbr, int64_t D1,
+                           const double *bounds)
 {
     enum { NA = 12 };
     FILE *f = fopen(path, "rb");
@@ -128,6 +133,45 @@ static int scenario_lambda(vrt_grid *g, int n, const char *path)
         vrt_direction(UL7N12[a][1], UL7N12[a][2], k + 3 * a);
         dirs[a] = UL7N12[a][1] > 90 ? 1 : (UL7N12[a][1] < 90 ? -1 : 0);
     }
+    double *J = malloc(sizeof(double) * (size_t)nlam * (size_t)n), *S = malloc(sizeof(double) * (size_t)nlam * (size_t)n);
+    double *P = malloc(sizeof(double) * 3 * (size_t)n);
+    double diff = 1.0;
+    int64_t i = 0;
+    if (head[3] > 0) {
+        /* scenario 4: the same loop across several devices of the node (vrt_multi_lambda_*): wavelength blocks per
+         * device, per iteration ONE all-reduce of the rate-integral shares.  Devices from VRT_DEVICES ("0,1,2,3"),
+         * else head[3] handles on device 0 (a rehearsal on a one-GPU box) */
+        int devices[64], nd = 0;
+        const char *env = getenv("VRT_DEVICES");
+        if (env && *env)
+            for (const char *q = env; *q && nd < 64;) {
+                devices[nd++] = atoi(q);
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+        else
+            for (; nd < head[3] && nd < 64; nd++) devices[nd] = 0;
+        vrt_multi *mm = NULL;
+        vrt_multi_lambda *ms = NULL;
+        if (vrt_multi_create(nd, devices, n, pos, nbr, D1, bounds, NA, k, dirs, 3, &mm) || vrt_multi_lambda_create(mm, &lc, w, &ms)) {
+            fprintf(stderr, "vrt_multi_lambda_create: %s\n", vrt_last_error());
+            return 1;
+        }
+        while (diff > eps_conv && i < maxiter) {
+            if (vrt_multi_lambda_iterate(ms, &diff)) {
+                fprintf(stderr, "vrt_multi_lambda_iterate: %s\n", vrt_last_error());
+                return 1;
+            }
+            printf("hist %lld %.17g\n", (long long)(i + 1), diff);
+            i++;
+        }
+        if (vrt_multi_lambda_get(ms, J, S, P, NULL, NULL)) {
+            fprintf(stderr, "vrt_multi_lambda_get: %s\n", vrt_last_error());
+            return 1;
+        }
+        vrt_multi_lambda_destroy(ms);
+        vrt_multi_destroy(mm);
+    } else {
     vrt_plan *plan = NULL;
     vrt_lambda *ses = NULL;
     if (vrt_plan_create_ex(g, NA, k, dirs, 3, &plan) || vrt_lambda_create(plan, &lc, w, &ses)) {
@@ -135,8 +179,6 @@ static int scenario_lambda(vrt_grid *g, int n, const char *path)
         return 1;
     }
     /* Λ_voronoi: while criterion(S_new, S_old, ϵ, i, maxiter) ... (lambda_iteration.jl:253); the criterion starts at 1 */
-    double diff = 1.0;
-    int64_t i = 0;
     while (diff > eps_conv && i < maxiter) {
         if (vrt_lambda_iterate(ses, &diff)) {
             fprintf(stderr, "vrt_lambda_iterate: %s\n", vrt_last_error());
@@ -145,18 +187,17 @@ static int scenario_lambda(vrt_grid *g, int n, const char *path)
         printf("hist %lld %.17g\n", (long long)(i + 1), diff);
         i++;
     }
-    double *J = malloc(sizeof(double) * (size_t)nlam * (size_t)n), *S = malloc(sizeof(double) * (size_t)nlam * (size_t)n);
-    double *P = malloc(sizeof(double) * 3 * (size_t)n);
     if (vrt_lambda_get(ses, J, S, P, NULL, NULL)) {
         fprintf(stderr, "vrt_lambda_get: %s\n", vrt_last_error());
         return 1;
+    }
+    vrt_lambda_destroy(ses);
+    vrt_plan_destroy(plan);
     }
     for (int s = 0; s < n; s++)
         for (int64_t l = 0; l < nlam; l++)
             printf("JS %d %lld %.17g %.17g\n", s + 1, (long long)(l + 1), J[l + nlam * s], S[l + nlam * s]);
     for (int s = 0; s < n; s++) printf("P %d %.17g %.17g %.17g\n", s + 1, P[s], P[s + n], P[s + 2 * n]);
-    vrt_lambda_destroy(ses);
-    vrt_plan_destroy(plan);
     return 0;
 }
 
@@ -196,8 +237,8 @@ int main(int argc, char **argv)
         vrt_grid_destroy(g);
         return rc;
     }
-    if (argc > 2 && atoi(argv[1]) == 3) {
-        int rc = scenario_lambda(g, N, argv[2]);
+    if (argc > 2 && (atoi(argv[1]) == 3 || atoi(argv[1]) == 4)) {      /* 4: head[3] of the inputs file > 0 -> several devices */
+        int rc = scenario_lambda(g, N, argv[2], pos, nbr, D1, bounds);
         vrt_grid_destroy(g);
         return rc;
     }

@@ -368,6 +368,28 @@ int vrt_multi_set_shard(vrt_multi *m, const char *mode);
 int vrt_multi_last_shard(const vrt_multi *m);
 int vrt_multi_uses_rccl(const vrt_multi *m);
 void vrt_multi_destroy(vrt_multi *m);
+/* vrt_plan_execute_line for the node (the body of J_λ_voronoi, line method, src/lambda_iteration.jl:72-111, from host
+ * arrays): the wavelengths go to the devices in contiguous blocks, every device makes the per-angle α_tot of ITS
+ * wavelengths itself (it never exists on the host and never crosses PCIe) and owns whole rows J[l, :]: no exchange.
+ * Arguments as vrt_plan_execute_line. */
+int vrt_multi_execute_line(vrt_multi *m, int64_t nlam, int64_t ld, const double *lambda, double lambda0, double c0,
+                           const double *velocity, const double *doppler_width, const double *gamma,
+                           const double *line_strength, const double *alpha_cont, const double *S, const double *I0_up,
+                           const double *I0_down, const double *weights, double *J);
+/* The Λ-iteration session of vrt_lambda_* across the devices of a vrt_multi (BASELINE configs[3];
+ * src/lambda_iteration.jl:205-300).  Every device owns a contiguous block of the wavelengths and a copy of the per-site
+ * state; per iteration it runs, for its wavelengths, the line terms, α_tot of every angle, the sweep, S_new with its
+ * share of the convergence maximum, and its share of the six λ-integrals of the radiative rates (src/rates.jl:154-201,
+ * regrouped per wavelength: Σ_l W_l f_l).  The shares are summed by ONE RCCL all-reduce of 6 n doubles -- J never
+ * travels -- and every device solves the statistical equilibrium of every site itself
+ * (src/populations.jl:191-221).  Results equal the one-device session's to the rounding of that regrouping (1e-12).
+ * vrt_multi_lambda_get assembles J and S_new (n, nlam) from the devices' blocks; populations (n, 3), R (3, 3, n) and γ [n]
+ * come from the first device.  Destroy the session before its vrt_multi. */
+typedef struct vrt_multi_lambda vrt_multi_lambda;
+int vrt_multi_lambda_create(vrt_multi *m, const vrt_line_case *lc, const double *weights, vrt_multi_lambda **out);
+int vrt_multi_lambda_iterate(vrt_multi_lambda *s, double *max_rel_change);
+int vrt_multi_lambda_get(vrt_multi_lambda *s, double *J, double *S, double *populations, double *R, double *gamma);
+void vrt_multi_lambda_destroy(vrt_multi_lambda *s);
 
 /* ---- rates + populations of the Λ-iteration epilogue on the device --------
  * calculate_R (src/rates.jl:154-201: Rij / Rji λ-trapezoids :226-364, σij with the site's static

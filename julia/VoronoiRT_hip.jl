@@ -8,7 +8,9 @@
 #     α_tot (nλ, n, n_angles) are made on the device and never exist on the host,
 #   * `Λ_voronoi` (src/lambda_iteration.jl:205-300) over vrt_lambda_create / _iterate / _get: the loop's
 #     state lives on the device, per iteration only the criterion's scalar comes back (plus the
-#     populations and S_new the reference checkpoints), and
+#     populations and S_new the reference checkpoints); with ENV["VRT_DEVICES"] = "0,1,...,7" the same loop
+#     runs across those GPUs (vrt_multi_create + vrt_multi_lambda_*: wavelength blocks per device, one RCCL
+#     all-reduce of the rate-integral shares per iteration), and
 #   * `Delaunay_upII` / `Delaunay_downII` (src/irregular_ray_tracing.jl:15-82, :96-163) for the
 #     direct call sites in compare_searchlight.jl (:113,129,434),
 #   * `short_characteristics_up/down` (src/characteristics.jl:19-95, :110-180).
@@ -17,7 +19,8 @@
 #
 # Julia is not available in the build image: this file is shipped UNTESTED by execution.
 # examples/c_caller.c plays exactly the callers written below -- same arrays, same call sequences:
-# scenario 2 the batched J_λ_voronoi, scenario 3 the Λ_voronoi loop -- and is checked against the
+# scenario 2 the batched J_λ_voronoi, scenario 3 the Λ_voronoi loop, scenario 4 that loop across several
+# device handles -- and is checked against the
 # oracle on the GPU (tests/test_gpu_parity.py).
 #
 # Unitful quantities are bit-identical to Float64 in memory, so `ustrip.(x)` gives the plain
@@ -30,10 +33,18 @@
 module VoronoiRTHip
 
 using Unitful
+using Libdl
 import ..VoronoiRT
 import ..VoronoiRT: VoronoiSites, HydrogenicLine, read_quadrature
 
 const libvrt = get(ENV, "VRT_LIB", joinpath(@__DIR__, "..", "voronoirt_amd", "libvrt_hip.so"))
+
+# entry points chosen at run time (one device or several: Λ below) are called through dlsym'd function pointers
+const LIBVRT_HANDLE = Ref{Ptr{Cvoid}}(C_NULL)
+function libvrt_handle()
+    LIBVRT_HANDLE[] == C_NULL && (LIBVRT_HANDLE[] = dlopen(libvrt))
+    return LIBVRT_HANDLE[]
+end
 
 vrt_error() = unsafe_string(ccall((:vrt_last_error, libvrt), Cstring, ()))
 check(rc::Cint) = rc == 0 ? nothing : error("libvrt_hip error $rc: $(vrt_error())")
@@ -81,6 +92,38 @@ function plan_handle(sites::VoronoiSites, quadrature::String, n_sweeps::Int)
             check(ccall((:vrt_plan_create_ex, libvrt), Cint,
                         (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Cint}, Cint, Ref{Ptr{Cvoid}}),
                         g, n_angles, k, dirs, n_sweeps, out))
+        end
+        out[]
+    end
+end
+
+# ---- several GPUs of the node from this one Julia process: ENV["VRT_DEVICES"] = "0,1,2,3,4,5,6,7" -------------
+# (vrt_multi_*: a grid + plan per device and an in-process RCCL communicator; the Λ-iteration then runs as
+# vrt_multi_lambda_*: wavelength blocks per device, ONE all-reduce of the rate-integral shares per iteration)
+vrt_devices() = haskey(ENV, "VRT_DEVICES") && !isempty(ENV["VRT_DEVICES"]) ?
+                Cint[parse(Cint, d) for d in split(ENV["VRT_DEVICES"], ",")] : Cint[]
+
+const MULTIS = Dict{Tuple{UInt,String,Int},Ptr{Cvoid}}()
+
+function multi_handle(sites::VoronoiSites, quadrature::String, n_sweeps::Int)
+    get!(MULTIS, (objectid(sites), quadrature, n_sweeps)) do
+        devices = vrt_devices()
+        pos = Matrix{Float64}(ustrip.(u"m", sites.positions))
+        bounds = Float64[ustrip(u"m", b) for b in (sites.z_min, sites.z_max, sites.x_min,
+                                                   sites.x_max, sites.y_min, sites.y_max)]
+        nbr = Matrix{Int64}(sites.neighbours)
+        weights, θ, ϕ, n_angles = read_quadrature(quadrature)
+        k = Matrix{Float64}(undef, 3, n_angles)
+        for i in 1:n_angles
+            k[:, i] = direction(θ[i], ϕ[i])
+        end
+        dirs = Cint[θ[i] > 90 ? 1 : (θ[i] < 90 ? -1 : 0) for i in 1:n_angles]
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve devices pos bounds nbr k dirs begin
+            check(ccall((:vrt_multi_create, libvrt), Cint,
+                        (Cint, Ptr{Cint}, Int64, Ptr{Float64}, Ptr{Int64}, Int64, Ptr{Float64}, Int64, Ptr{Float64},
+                         Ptr{Cint}, Cint, Ref{Ptr{Cvoid}}),
+                        length(devices), devices, sites.n, pos, nbr, size(nbr, 2), bounds, n_angles, k, dirs, n_sweeps, out))
         end
         out[]
     end
@@ -252,7 +295,13 @@ function Λ(ϵ::AbstractFloat, maxiter::Integer, sites::VoronoiSites, line::Hydr
     # αline_λ = strength_const (n_1 B_ij - n_2 B_ji) φ: the two coefficients per unit density, from αline_λ itself
     a_i = line_strength(line, [0.0u"m^-3"], [1.0u"m^-3"])[1]
     a_j = -line_strength(line, [1.0u"m^-3"], [0.0u"m^-3"])[1]
-    plan = plan_handle(sites, quadrature, 3)
+    # one device: vrt_lambda_* on the plan; ENV["VRT_DEVICES"] lists several: vrt_multi_lambda_* (same arguments)
+    multi = length(vrt_devices()) > 1
+    plan = multi ? multi_handle(sites, quadrature, 3) : plan_handle(sites, quadrature, 3)
+    f_create = multi ? :vrt_multi_lambda_create : :vrt_lambda_create
+    f_iterate = multi ? :vrt_multi_lambda_iterate : :vrt_lambda_iterate
+    f_get = multi ? :vrt_multi_lambda_get : :vrt_lambda_get
+    f_destroy = multi ? :vrt_multi_lambda_destroy : :vrt_lambda_destroy
     ses = Ref{Ptr{Cvoid}}(C_NULL)
     J = Matrix{Float64}(undef, nλ, n); S = Matrix{Float64}(undef, nλ, n); pops = Matrix{Float64}(undef, n, 3)
     GC.@preserve λ vel ΔD γs γu αc εv T atom B_0 lte Cm planck2 σ1 σ2 w begin
@@ -262,17 +311,17 @@ function Λ(ϵ::AbstractFloat, maxiter::Integer, sites::VoronoiSites, line::Hydr
                           1.0, a_i, a_j,
                           ustrip(u"m^3", hc / (4 * π * line.λ0) * line.Bij),     # σ_constant of σij, rates.jl:398: x profile [1/m] = m^2
                           ustrip(u"m*K", hc / VoronoiRT.k_B), pref_ij, pref_ji))
-        check(ccall((:vrt_lambda_create, libvrt), Cint, (Ptr{Cvoid}, Ref{LineCase}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+        check(ccall(dlsym(libvrt_handle(), f_create), Cint, (Ptr{Cvoid}, Ref{LineCase}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
                     plan, lc, w, ses))
     end
     i = 0
     diff = Ref{Float64}(1.0)                  # criterion(S_new = B_0, S_old = 0) = |1 - 0/B| = 1, :325-349
     VoronoiRT.write_to_file(diff[], i + 1, DATA)
     while diff[] > ϵ && i < maxiter
-        @time check(ccall((:vrt_lambda_iterate, libvrt), Cint, (Ptr{Cvoid}, Ref{Float64}), ses[], diff))
+        @time check(ccall(dlsym(libvrt_handle(), f_iterate), Cint, (Ptr{Cvoid}, Ref{Float64}), ses[], diff))
         isnan(diff[]) && println("NaN DIFF!")
         println("   Rel. diff.: $(diff[])")
-        GC.@preserve S pops check(ccall((:vrt_lambda_get, libvrt), Cint,
+        GC.@preserve S pops check(ccall(dlsym(libvrt_handle(), f_get), Cint,
                                         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                                         ses[], C_NULL, S, pops, C_NULL, C_NULL))
         VoronoiRT.write_to_file(pops * 1u"m^-3", DATA)                    # the checkpoint, :280-281
@@ -280,10 +329,10 @@ function Λ(ϵ::AbstractFloat, maxiter::Integer, sites::VoronoiSites, line::Hydr
         i += 1
         VoronoiRT.write_to_file(diff[], i + 1, DATA)                      # convergence history, :346
     end
-    GC.@preserve J S pops check(ccall((:vrt_lambda_get, libvrt), Cint,
+    GC.@preserve J S pops check(ccall(dlsym(libvrt_handle(), f_get), Cint,
                                       (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                                       ses[], J, S, pops, C_NULL, C_NULL))
-    ccall((:vrt_lambda_destroy, libvrt), Cvoid, (Ptr{Cvoid},), ses[])
+    ccall(dlsym(libvrt_handle(), f_destroy), Cvoid, (Ptr{Cvoid},), ses[])
     println(i == maxiter ? "Did not converge inside scope" : "Converged in $i iterations")
     return J * I_unit, S * I_unit, α_cont, pops * 1u"m^-3"
 end

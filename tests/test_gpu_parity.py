@@ -515,7 +515,7 @@ def test_layers_of_20000_and_30000_sites_run_on_the_patch_kernel(monkeypatch, a,
     assert _rel(J, ref) < RTOL
     plan.set_option("VRT_PATH", "levels")
     J2, _ = plan.execute(S, al, weights=w, I0_up=I0)
-    assert plan.last_path == "levels" and _rel(J2, J) < 5e-12
+    assert plan.last_path == "levels" and _rel(J2, J) < 5e-11
     plan.set_option("VRT_PATH", "steps")                      # no layer-step kernel holds such a layer
     with pytest.raises(vrt.VrtError):
         plan.execute(S, al, weights=w, I0_up=I0)
@@ -710,10 +710,13 @@ def test_plain_c_caller_plays_J_lambda_voronoi(tmp_path):
     assert _rel(got, ref) < RTOL
 
 
-def test_plain_c_caller_plays_Lambda_voronoi(tmp_path):
+@pytest.mark.parametrize("handles", [0, 2])
+def test_plain_c_caller_plays_Lambda_voronoi(tmp_path, handles):
     """Scenario 3 of examples/c_caller.c is the caller julia/VoronoiRT_hip.jl's Λ_voronoi is: the reference's loop
     (src/lambda_iteration.jl:205-300) over vrt_lambda_create / _iterate / _get with host arrays -- library-owned
-    device state, one call per iteration, γ following the populations.  Against the same loop driven by the oracle."""
+    device state, one call per iteration, γ following the populations.  Scenario 4 (handles = 2) is the same loop
+    across the devices of a node, vrt_multi_create + vrt_multi_lambda_* (here: two handles on device 0).  Against the
+    same loop driven by the oracle."""
     import subprocess
     from test_physics import _lambda_case, _oracle_lambda_iteration
     exe = _build_c_caller(tmp_path)
@@ -723,7 +726,7 @@ def test_plain_c_caller_plays_Lambda_voronoi(tmp_path):
     nlam = case.lam.size
     blob = tmp_path / "lambda_inputs.bin"
     with open(blob, "wb") as f:
-        np.array([n, nlam, maxiter, 0], dtype=np.int64).tofile(f)
+        np.array([n, nlam, maxiter, handles], dtype=np.int64).tofile(f)
         np.asarray(case.blocks, dtype=np.int64).tofile(f)
         np.array([case.lambda0, case.c0, case.strength_const, case.Bij, case.Bji, case.sigma_bb_const, case.hc_over_kB,
                   case.pref_ij, case.pref_ji]).tofile(f)
@@ -731,7 +734,7 @@ def test_plain_c_caller_plays_Lambda_voronoi(tmp_path):
                   case.temperature, case.atom_density, case.B0, case.lte, case.C, case.planck2, case.sigma_bf1,
                   case.sigma_bf2):
             np.ascontiguousarray(a, dtype=np.float64).tofile(f)
-    out = subprocess.run([str(exe), "3", str(blob)], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([str(exe), "4" if handles else "3", str(blob)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     hist, J, S, P = [], np.zeros((n, nlam)), np.zeros((n, nlam)), np.zeros((3, n))
     for ln in out.stdout.strip().splitlines():
@@ -785,6 +788,18 @@ def test_multi_device_object_of_the_c_abi(voro_small, devices):
             assert np.array_equal(J1, Jl)
             plan.close()
             hs.close()
+    # the wavelength count changes from call to call (the chained launch's item sets are rebuilt every time) while the
+    # handles' launches share the chip: every J still right (regression: progress words zeroed on the null stream)
+    cases = {}
+    for nlam in (1, 2, 3):
+        S = 1 + rng.random((n, nlam))
+        al = 5 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+        I0u = rng.random((so.layers_up[1] - 1, nlam))
+        cases[nlam] = (S, al, I0u, orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0u, nthreads=4))
+    for rep in range(24):
+        S, al, I0u, ref = cases[(1, 3, 2, 3, 1, 2, 2)[rep % 7]]
+        mp.set_shard("angle" if rep % 3 else "lambda")
+        assert _rel(mp.execute(S, al, w, I0_up=I0u), ref) < RTOL, rep
     mp.close()
     with pytest.raises(vrt.VrtError):
         vrt.MultiDevicePlan(pos, nbr, bounds, vrt.quadrature_directions(th, ph), dirs=dirs, devices=(0, 97))

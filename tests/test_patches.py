@@ -62,7 +62,9 @@ def test_patches_J_matches_oracle_and_steps(grids, name, own, nlam, monkeypatch)
         plan.set_option("VRT_PATH", "steps")
         J2, I2 = plan.execute(S, al, weights=w, I0_up=I0u, I0_down=I0d, want_I=True)
         assert plan.last_path == "steps"
-        assert _rel(I, I2) < 5e-12 and _rel(J, J2) < 5e-12       # exp() of the patch kernel: 2e-13 (contract 1e-10)
+        # (element-wise; where an optical depth sits within rounding of 5e-4 the two paths may take different
+        # branches of linear_weights, which differ by Δτ³/6 = 2e-11 there: functions.jl:484-500)
+        assert _rel(I, I2) < 5e-11 and _rel(J, J2) < 5e-11
         # the never-visited last site of each direction keeps I = 0 (voronoi_utils.jl:266)
         for a_i in range(nq):
             last = (so.perm_up if th[a_i] > 90 else so.perm_down)[-1] - 1

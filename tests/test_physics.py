@@ -440,3 +440,37 @@ def test_gpu_J_line_from_host_arrays(voro_small):
     ref = orc.J_voronoi(w, th, ph, S, alpha, so, I0_up=case.B0[bottom], nthreads=8)
     assert np.abs(J - ref).max() < 1e-10 * np.abs(ref).max()
     hs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [(0,), (0, 0), (0, 0, 0)])
+def test_gpu_multi_device_lambda_session_and_line_entry(voro_small, devices):
+    """vrt_multi_lambda_* (BASELINE configs[3]: Λ-iteration across the devices of a node) and vrt_multi_execute_line:
+    wavelength blocks per device handle, every handle makes the α_tot of its own wavelengths and its share of the six
+    rate integrals, ONE all-reduce of the shares (6 n doubles; handles on one device: kernel adds), the statistical
+    equilibrium solved by every handle.  J and S_new of a block are produced by exactly one handle from replicated
+    populations; the rate integrals are regrouped per wavelength (Σ_l W_l f_l instead of the trapezoid segments), so the
+    session equals the one-device session to rounding (1e-12) and the oracle-driven loop like it does (1e-9)."""
+    pos, nbr, bounds = voro_small
+    so = orc.make_sites(pos, nbr, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+    case = _lambda_case(pos, bounds, 11)
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    dirs = [1 if t > 90 else -1 for t in th]
+    mp = vrt.MultiDevicePlan(pos, nbr, bounds, vrt.quadrature_directions(th, ph), dirs=dirs, devices=devices)
+    J, S, pops, hist = mp.lambda_iteration(0.0, 4, case, w)
+    J1, S1, pops1, hist1 = vrt.Lambda_voronoi_host(0.0, 4, hs, case, "ul7n12.dat")
+    assert len(hist) == 4 and np.allclose(hist, hist1, rtol=1e-12)
+    assert _rel(J, J1) < 1e-12 and _rel(S, S1) < 1e-12 and _rel(pops, pops1) < 1e-12
+    J_ref, S_ref, pops_ref, hist_ref = _oracle_lambda_iteration(case, so, "ul7n12.dat", 4)
+    assert np.abs(J - J_ref).max() < 1e-9 * np.abs(J_ref).max() and np.abs(pops / pops_ref - 1).max() < 1e-9
+    assert mp.lambda_iteration(1.0, 10, case, w)[3] == []          # the criterion starts at 1 (lambda_iteration.jl:325-349)
+    # J_λ_voronoi of the line case from host arrays, wavelength blocks over the handles: each block bit for bit what the
+    # one-handle entry gives (every wavelength is solved by exactly one handle)
+    rng = np.random.default_rng(2)
+    pp = case.lte * (1 + 0.2 * rng.random(case.lte.shape))
+    Sx = case.B0 * (1 + 0.3 * rng.random(case.B0.shape))
+    Jl = mp.execute_line(Sx, pp, case, w, so.perm_up, int(so.layers_up[1] - 1))
+    assert np.array_equal(Jl, vrt.J_lambda_voronoi_line(Sx, pp, hs, case, "ul7n12.dat"))
+    mp.close()
+    hs.close()

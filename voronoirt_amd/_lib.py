@@ -88,6 +88,12 @@ PROTOTYPES = {
     "vrt_multi_last_shard": (ctypes.c_int, [vp]),
     "vrt_multi_uses_rccl": (ctypes.c_int, [vp]),
     "vrt_multi_destroy": (None, [vp]),
+    "vrt_multi_execute_line": (ctypes.c_int, [vp, c_i64, c_i64, p_dbl, c_dbl, c_dbl, p_dbl, p_dbl, p_dbl, p_dbl, p_dbl, p_dbl,
+                                              p_dbl, p_dbl, p_dbl, p_dbl]),
+    "vrt_multi_lambda_create": (ctypes.c_int, [vp, ctypes.POINTER(LineCaseStruct), p_dbl, ctypes.POINTER(vp)]),
+    "vrt_multi_lambda_iterate": (ctypes.c_int, [vp, p_dbl]),
+    "vrt_multi_lambda_get": (ctypes.c_int, [vp, p_dbl, p_dbl, p_dbl, p_dbl, p_dbl]),
+    "vrt_multi_lambda_destroy": (None, [vp]),
     "vrt_rates_populations_dev": (ctypes.c_int, [vp, c_i64, c_i64, p_dbl, p_i64, vp, p_dbl, c_dbl, c_dbl, vp, vp,
                                                  c_dbl, p_dbl, p_dbl, vp, vp, c_dbl, c_dbl, c_dbl, vp, vp, vp,
                                                  vp, vp]),

@@ -423,6 +423,51 @@ class MultiDevicePlan:
                                             _d(w), _d(J)))
         return J
 
+    def execute_line(self, S, populations, case, weights, perm_up, n1: int) -> np.ndarray:
+        """`vrt_multi_execute_line`: J_λ_voronoi of the line case from host arrays, wavelength blocks over the devices,
+        every device making the per-angle α_tot of its own wavelengths (`case`: a LineCase; I_0 = B_0 of the bottom
+        layer, lambda_iteration.jl:99-101)."""
+        S = _f64(S)
+        n, nlam = S.shape
+        pops = np.asarray(populations)
+        gamma = _f64(case.gamma(pops))
+        strength = _f64(case.strength_const * (pops[0] * case.Bij - pops[1] * case.Bji))
+        lam, vel, dop, ac = _f64(case.lam), _f64(case.velocity), _f64(case.doppler), _f64(case.alpha_cont)
+        I0 = _f64(np.asarray(case.B0)[np.asarray(perm_up)[:n1] - 1])
+        J = np.zeros((n, nlam))
+        check(_lib.load().vrt_multi_execute_line(self._h, nlam, nlam, _d(lam), float(case.lambda0), float(case.c0), _d(vel),
+                                                 _d(dop), _d(gamma), _d(strength), _d(ac), _d(S), _d(I0), None,
+                                                 _d(_f64(weights)), _d(J)))
+        return J
+
+    def lambda_iteration(self, eps_conv: float, maxiter: int, case, weights):
+        """Λ_voronoi (src/lambda_iteration.jl:205-300) across the devices (`vrt_multi_lambda_*`): wavelength blocks per
+        device, one all-reduce of the rate-integral shares per iteration.  Returns (J, S_new, populations (3, n), history)."""
+        L = _lib.load()
+        lc, keep = case.c_struct()
+        h = ctypes.c_void_p()
+        check(L.vrt_multi_lambda_create(self._h, ctypes.byref(lc), _d(_f64(weights)), ctypes.byref(h)))
+        n, nlam = self.n, int(keep["lam"].size)
+        history, diff, i = [], 1.0, 0
+        try:
+            while diff > eps_conv and i < maxiter:
+                d = ctypes.c_double()
+                check(L.vrt_multi_lambda_iterate(h, ctypes.byref(d)))
+                diff = d.value
+                history.append(diff)
+                i += 1
+                if diff != diff:
+                    import warnings
+                    warnings.warn(f"lambda_iteration: NaN DIFF! at iteration {i} -- stopping, results are not converged")
+            J, S, pops = np.zeros((n, nlam)), np.zeros((n, nlam)), np.zeros((3, n))
+            check(L.vrt_multi_lambda_get(h, _d(J), _d(S), _d(pops), None, None))
+            if i == 0:
+                S[:] = keep["B0"]
+                pops[:] = keep["lte"]
+            return J, S, pops, history
+        finally:
+            L.vrt_multi_lambda_destroy(h)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             _lib.load().vrt_multi_destroy(self._h)

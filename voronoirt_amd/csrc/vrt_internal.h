@@ -271,6 +271,7 @@ struct vrt_plan {
     hipEvent_t chain_dev_ev = nullptr;
     bool chain_dev_ev_valid = false;
     size_t chain_progress_cap = 0;
+    bool chain_progress_fresh = false;   // allocated since the last launch: zero it on the launch stream
     int chain_q_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int chain_npair = -1, chain_lgB = -1, chain_nsplit = -1, chain_reduce = -1;
     int64_t chain_items = 0;
@@ -388,6 +389,13 @@ int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_
                              const double *d_temperature, const double *d_lte, double hc_over_kB,
                              double pref_ij, double pref_ji, const double *d_C, const double *d_atom_density,
                              double *d_R, double *d_populations, hipStream_t st);
+
+int launch_rates_partial(vrt_grid *g, int64_t nlam, int64_t l0, int64_t l1, int64_t ld, const int64_t blocks[6],
+                         const double *d_small, const double *dJ, double lambda0, double c0, const double *d_doppler,
+                         const double *d_gamma, double sigma_bb_const, const double *d_temperature, const double *d_lte,
+                         double hc_over_kB, double pref_ij, double pref_ji, double *d_shares, hipStream_t st);
+int launch_populations_from_shares(vrt_grid *g, const double *d_shares, const double *d_C, const double *d_atom_density,
+                                   double *d_R, double *d_populations, hipStream_t st);
 
 // ---- entry-point internals shared with vrt_lambda.cpp (vrt_api.cpp) ---------------------------------
 int use_device(int device);

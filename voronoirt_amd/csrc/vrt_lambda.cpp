@@ -40,6 +40,7 @@ int upload(double **d, const double *h, size_t count, hipStream_t st)
 
 struct vrt_lambda {
     vrt_plan *p = nullptr;
+    int device = 0;                     // of the plan's grid (kept here: destroying the session must not look into a plan that may be gone)
     int64_t n = 0, nlam = 0;
     int64_t blocks[6] = {0, 0, 0, 0, 0, 0};
     double lambda0 = 0, c0 = 0, strength_const = 0, Bij = 0, Bji = 0, sigma_bb_const = 0, hc_over_kB = 0, pref_ij = 0,
@@ -184,6 +185,7 @@ int vrt_lambda_create(vrt_plan *p, const vrt_line_case *lc, const double *weight
         vrt_lambda *s = new (std::nothrow) vrt_lambda();
         if (!s) return fail(VRT_ENOMEM, "out of host memory");
         s->p = p;
+        s->device = g->device;
         s->n = g->n;
         s->nlam = nlam;
         for (int q = 0; q < 6; q++) s->blocks[q] = lc->blocks[q];
@@ -309,7 +311,7 @@ int vrt_lambda_get(vrt_lambda *s, double *J, double *S, double *populations, dou
 void vrt_lambda_destroy(vrt_lambda *s)
 {
     DeviceScope scope;
-    if (s && s->p && s->p->g) (void)hipSetDevice(s->p->g->device);
+    if (s) (void)hipSetDevice(s->device);
     lambda_free(s);
 }
 

@@ -586,7 +586,16 @@ __device__ __forceinline__ PairIO pair_io(const PatchArgs &pa, int d)
 // (ChainDev::spin_limit): on expiry the launch gives up, drains and reports through a host-visible status word.
 typedef unsigned int vrt_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int vrt_u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kAuxSc1 = 16;                    // cache-policy bits of the buffer instructions: sc1 (agent scope)
+// cache-policy bits of the buffer instructions that move intensities between workgroups: sc0 | sc1 (system scope).
+// sc1 alone (agent scope) bypasses the reading CU's L1 but is served by the reading XCD's L2, and a 128-byte line of an
+// intensity plane is shared by the patches either side of a patch or layer boundary: a reader that pulled the line
+// into its L2 when one half was final sees the OTHER half stale afterwards (observed: three chained launches sharing the
+// chip, 1 wrong J in 90 -- MI355X_MICROARCH.md's hand-off table asks for whole lines per store for the same reason).
+// System-scope accesses are not served from an XCD's L2 copy.
+#ifndef VRT_CHAIN_AUX
+#define VRT_CHAIN_AUX 17
+#endif
+constexpr int kAuxSc1 = VRT_CHAIN_AUX;
 constexpr int kChainDepLds = 128;              // dependencies of an item kept in LDS (more: read from the global list)
 constexpr int kChainHeadStride = 32;           // 32-bit words between the queue heads (a 128-byte line each)
 constexpr int kChainAbortWord = 8 * kChainHeadStride;   // ctrl[] index of the give-up word
@@ -1075,7 +1084,9 @@ __device__ __forceinline__ void chain_wait_slow(const int32_t *s_dep, int step)
             if ((++spins & 127u) == 1u) {
                 if (spins > limit) {                           // give up: the launch drains, the host reports it
                     st_agent(abort_word, 1u);
-                    __hip_atomic_store(cd->host_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    uint32_t *hs = cd->host_status;            // (the item that waited; kept short: this path shares the solver's registers)
+                    __hip_atomic_store(hs + 1, ctl[kCtlItem], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(hs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 if (ld_agent(abort_word) != 0u) return;
             }
@@ -1572,10 +1583,10 @@ static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool 
         p->chain_progress_cap = 0;
         VRT_HIP_TRY(hipMalloc((void **)&p->d_chain_progress, sizeof(uint32_t) * words));
         p->chain_progress_cap = words;
+        p->chain_progress_fresh = true;
     }
-    // a new item set: the progress words start from zero (an epoch counts launches of ONE item set)
-    VRT_HIP_TRY(hipMemset(p->d_chain_progress, 0, sizeof(uint32_t) * p->chain_progress_cap));
-    p->chain_epoch = 0;
+    // (epochs keep counting across item sets: a word of an earlier set compares as "behind" whatever it meant there;
+    // freshly allocated words are zeroed on the launch stream, ahead of the first launch that polls them)
     if (!p->d_chain_ctrl) VRT_HIP_TRY(hipMalloc((void **)&p->d_chain_ctrl, sizeof(uint32_t) * (kChainAbortWord + 4)));
     if (!p->h_chain_status) {
         VRT_HIP_TRY(hipHostMalloc((void **)&p->h_chain_status, 64, hipHostMallocMapped));
@@ -1609,10 +1620,7 @@ static int launch_chain_mode(bool quad, int64_t items, size_t lds, hipStream_t s
 int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t st, bool f32, const PatchReduce *reduce)
 {
     // a give-up of an EARLIER chained launch of this plan (its results were wrong) is reported here at the latest
-    if (p->h_chain_status && *p->h_chain_status) {
-        *p->h_chain_status = 0;
-        return fail(VRT_ENODEVICE, "an earlier chained patch launch of this plan gave up waiting for a dependency (results invalid); VRT_PATCH_CHAIN=0 selects the per-layer launches");
-    }
+    if (int rc0 = patch_chain_check(p)) return rc0;
     const int lgB = native_lg(p, f32);
     const bool quad = f32 && lgB >= 1 && p->tune.patch_quad != 0 && (npair & 1) == 0;
     const int nblock = pair_block_count(npair, lgB);
@@ -1655,9 +1663,11 @@ int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t s
     }
     // epochs count the launches of this item set; stale words compare as "behind" while epochs differ by < 2^22
     p->chain_epoch++;
-    if ((p->chain_epoch & 0x3FFFFFu) == 0u) {
+    if ((p->chain_epoch & 0x3FFFFFu) == 0u || p->chain_progress_fresh) {
+        // stream-ordered (the plan's streams do not synchronise with the null stream)
         VRT_HIP_TRY(hipMemsetAsync(p->d_chain_progress, 0, sizeof(uint32_t) * p->chain_progress_cap, st));
-        p->chain_epoch = 1;
+        if ((p->chain_epoch & 0x3FFFFFu) == 0u) p->chain_epoch = 1;
+        p->chain_progress_fresh = false;
     }
     const uint32_t base = p->chain_epoch << 8;
     VRT_HIP_TRY(hipMemsetAsync(p->d_chain_ctrl, 0, sizeof(uint32_t) * (kChainAbortWord + 4), st));
@@ -1687,8 +1697,13 @@ int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t s
 int patch_chain_check(vrt_plan *p)
 {
     if (p->h_chain_status && *p->h_chain_status) {
+        volatile uint32_t *hs = p->h_chain_status;
+        char msg[384];
+        std::snprintf(msg, sizeof(msg),
+                      "a chained patch launch gave up waiting for a dependency of item %u (the results of that execute are "
+                      "invalid; VRT_PATCH_CHAIN=0 selects the per-layer launches)", hs[1]);
         *p->h_chain_status = 0;
-        return fail(VRT_ENODEVICE, "a chained patch launch gave up waiting for a dependency (results invalid)");
+        return fail(VRT_ENODEVICE, msg);
     }
     return VRT_OK;
 }

@@ -220,6 +220,33 @@ __device__ __forceinline__ void solve2(const double A[4], const double b[2], dou
     x[0] = (b0 - a01 * x[1]) / a00;
 }
 
+// R of site i out, its statistical equilibrium solved (n_levels = 2, populations.jl:191-221)
+__device__ __forceinline__ void populations_from_rates(const RatesArgs &ra, int64_t i, const double R[9])
+{
+    const int64_t n = ra.n;
+    double P[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        ra.R[9 * (size_t)i + q] = R[q];
+        P[q] = R[q] + ra.C[9 * (size_t)i + q];                                           // populations.jl:195
+    }
+    // statistical equilibrium, n_levels = 2 (populations.jl:205-219)
+#define PP(r, c) P[((r) - 1) + 3 * ((c) - 1)]
+    const double N = ra.atom_density[i];
+    double A[4], b[2], x[2];
+    A[0] = PP(1, 2) + PP(2, 1) + PP(2, 3);
+    A[2] = PP(1, 2) - PP(3, 2);
+    A[3] = PP(1, 3) + PP(3, 1) + PP(3, 2);
+    A[1] = PP(1, 3) - PP(2, 3);
+    b[0] = N * PP(1, 2);
+    b[1] = N * PP(1, 3);
+#undef PP
+    solve2(A, b, x);
+    ra.populations[i + n] = x[0];
+    ra.populations[i + 2 * n] = x[1];
+    ra.populations[i] = N - (x[0] + x[1]);
+}
+
 __global__ void __launch_bounds__(256)
 k_rates_populations(RatesArgs ra)
 {
@@ -274,38 +301,75 @@ k_rates_populations(RatesArgs ra)
         R[0 + 3 * 1] = rij;
         R[1 + 3 * 0] = rji;
     }
-    double P[9];
-#pragma unroll
-    for (int q = 0; q < 9; q++) {
-        ra.R[9 * (size_t)i + q] = R[q];
-        P[q] = R[q] + ra.C[9 * (size_t)i + q];                                           // populations.jl:195
-    }
-    // statistical equilibrium, n_levels = 2 (populations.jl:205-219)
-#define PP(r, c) P[((r) - 1) + 3 * ((c) - 1)]
-    const double N = ra.atom_density[i];
-    double A[4], b[2], x[2];
-    A[0] = PP(1, 2) + PP(2, 1) + PP(2, 3);
-    A[2] = PP(1, 2) - PP(3, 2);
-    A[3] = PP(1, 3) + PP(3, 1) + PP(3, 2);
-    A[1] = PP(1, 3) - PP(2, 3);
-    b[0] = N * PP(1, 2);
-    b[1] = N * PP(1, 3);
-#undef PP
-    solve2(A, b, x);
-    ra.populations[i + n] = x[0];
-    ra.populations[i + 2 * n] = x[1];
-    ra.populations[i] = N - (x[0] + x[1]);
+    populations_from_rates(ra, i, R);
 }
 
-int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_t blocks[6],
-                             const double *d_small /* lambda | planck2 | sigma_bf1 | sigma_bf2 */,
-                             const double *dJ, double lambda0, double c0, const double *d_doppler,
-                             const double *d_gamma, double sigma_bb_const, const double *d_temperature,
-                             const double *d_lte, double hc_over_kB, double pref_ij, double pref_ji,
-                             const double *d_C, const double *d_atom_density, double *d_R,
-                             double *d_populations, hipStream_t st)
+// ---- the same split over wavelength blocks (several devices: vrt_multi_lambda_*, vrt_multi.cpp) -------------------------
+// A device that owns the wavelengths [l0, l1) forms ITS share of the six λ-integrals of a site: the trapezoid sums of
+// k_rates_populations regrouped per wavelength, Σ_l W_l f_l with W_l = (λ_l - λ_l-1) [l > lo] + (λ_l+1 - λ_l) [l < hi - 1]
+// inside each block [lo, hi) -- the same terms, summed in another order (1e-15 relative per term).  The shares are
+// summed across the devices (ONE all-reduce of 6 n doubles: no J travels), then every device solves
+// the statistical equilibrium of every site itself (k_populations_from_shares).
+// shares[q][i], q = (bf1 ij, bf1 ji, bf2 ij, bf2 ji, bb ij, bb ji); J: this device's columns, (l1 - l0) per site
+__global__ void __launch_bounds__(256)
+k_rates_partial(RatesArgs ra, int64_t l0, int64_t l1, double *__restrict__ shares)
 {
-    RatesArgs ra;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = ra.n;
+    if (i >= n) return;
+    const double *__restrict__ Ji = ra.J + (size_t)i * (size_t)ra.ld - l0;      // indexed by the GLOBAL wavelength
+    const double T = ra.temperature[i];
+    for (int tr = 0; tr < 3; tr++) {                                              // bf level 1, bf level 2, bb
+        const int64_t lo = ra.blocks[tr < 2 ? 2 * (tr + 1) : 0], hi = ra.blocks[tr < 2 ? 2 * (tr + 1) + 1 : 1];
+        const double n_ratio = tr < 2 ? ra.lte[i + n * tr] / ra.lte[i + n * 2] : ra.lte[i] / ra.lte[i + n];
+        const double *__restrict__ sig = tr == 0 ? ra.sigma_bf1 : ra.sigma_bf2;
+        const double dD = ra.doppler[i], gm = ra.gamma[i];
+        double rij = 0.0, rji = 0.0;
+        for (int64_t l = lo > l0 ? lo : l0; l < (hi < l1 ? hi : l1); l++) {
+            const double lam = ra.lambda[l], Jl = Ji[l];
+            double s;
+            if (tr < 2) s = sig[l - lo];
+            else {
+                const double a = gm * (lam * lam) / (4.0 * kPi * ra.c0 * dD);
+                const double v = (lam - ra.lambda0) / dD;                                // rates.jl:408
+                s = ra.sigma_bb_const * (humlicek_w4_re(v, a) / (sqrt(kPi) * dD));
+            }
+            const double G = n_ratio * exp(-ra.hc_over_kB / (lam * T));                 // Gij, rates.jl:473
+            double W = 0.0;
+            if (l > lo) W += lam - ra.lambda[l - 1];
+            if (l < hi - 1) W += ra.lambda[l + 1] - lam;
+            rij += (lam * s * Jl) * W;                                                   // rates.jl:236-237, :262-263
+            rji += (s * G * lam * (ra.planck2[l] + Jl)) * W;                             // :312-313, :357-358
+        }
+        shares[(size_t)(2 * tr) * (size_t)n + (size_t)i] = ra.pref_ij * rij;
+        shares[(size_t)(2 * tr + 1) * (size_t)n + (size_t)i] = ra.pref_ji * rji;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_populations_from_shares(RatesArgs ra, const double *__restrict__ shares)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = ra.n;
+    if (i >= n) return;
+    double R[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) R[q] = 0.0;
+    for (int level = 1; level <= 2; level++) {
+        R[(level - 1) + 3 * 2] = shares[(size_t)(2 * (level - 1)) * (size_t)n + (size_t)i];
+        R[2 + 3 * (level - 1)] = shares[(size_t)(2 * (level - 1) + 1) * (size_t)n + (size_t)i];
+    }
+    R[0 + 3 * 1] = shares[(size_t)4 * (size_t)n + (size_t)i];
+    R[1 + 3 * 0] = shares[(size_t)5 * (size_t)n + (size_t)i];
+    populations_from_rates(ra, i, R);
+}
+
+static void fill_rates_args(RatesArgs &ra, vrt_grid *g, int64_t nlam, int64_t ld, const int64_t blocks[6], const double *d_small,
+                            const double *dJ, double lambda0, double c0, const double *d_doppler, const double *d_gamma,
+                            double sigma_bb_const, const double *d_temperature, const double *d_lte, double hc_over_kB,
+                            double pref_ij, double pref_ji, const double *d_C, const double *d_atom_density, double *d_R,
+                            double *d_populations)
+{
     ra.n = g->n; ra.nlam = nlam; ra.ld = ld;
     for (int q = 0; q < 6; q++) ra.blocks[q] = blocks[q];
     ra.lambda = d_small;
@@ -317,6 +381,47 @@ int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_
     ra.pref_ij = pref_ij; ra.pref_ji = pref_ji;
     ra.doppler = d_doppler; ra.gamma = d_gamma; ra.temperature = d_temperature; ra.lte = d_lte;
     ra.C = d_C; ra.atom_density = d_atom_density; ra.R = d_R; ra.populations = d_populations;
+}
+
+// this device's share of the rate integrals: wavelengths [l0, l1) of the FULL wavelength arrays in d_small
+// (λ | planck2 | σ_bf1 | σ_bf2 for all nlam wavelengths); dJ holds those columns only (ld values per site)
+int launch_rates_partial(vrt_grid *g, int64_t nlam, int64_t l0, int64_t l1, int64_t ld, const int64_t blocks[6],
+                         const double *d_small, const double *dJ, double lambda0, double c0, const double *d_doppler,
+                         const double *d_gamma, double sigma_bb_const, const double *d_temperature, const double *d_lte,
+                         double hc_over_kB, double pref_ij, double pref_ji, double *d_shares, hipStream_t st)
+{
+    RatesArgs ra;
+    fill_rates_args(ra, g, nlam, ld, blocks, d_small, dJ, lambda0, c0, d_doppler, d_gamma, sigma_bb_const, d_temperature, d_lte,
+                    hc_over_kB, pref_ij, pref_ji, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(k_rates_partial, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, st, ra, l0, l1, d_shares);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+// R (9 n) and the populations (3 n) from the summed shares
+int launch_populations_from_shares(vrt_grid *g, const double *d_shares, const double *d_C, const double *d_atom_density,
+                                   double *d_R, double *d_populations, hipStream_t st)
+{
+    RatesArgs ra;
+    const int64_t zero[6] = {0, 0, 0, 0, 0, 0};
+    fill_rates_args(ra, g, 0, 0, zero, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, d_C, d_atom_density,
+                    d_R, d_populations);
+    hipLaunchKernelGGL(k_populations_from_shares, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, st, ra, d_shares);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_t blocks[6],
+                             const double *d_small /* lambda | planck2 | sigma_bf1 | sigma_bf2 */,
+                             const double *dJ, double lambda0, double c0, const double *d_doppler,
+                             const double *d_gamma, double sigma_bb_const, const double *d_temperature,
+                             const double *d_lte, double hc_over_kB, double pref_ij, double pref_ji,
+                             const double *d_C, const double *d_atom_density, double *d_R,
+                             double *d_populations, hipStream_t st)
+{
+    RatesArgs ra;
+    fill_rates_args(ra, g, nlam, ld, blocks, d_small, dJ, lambda0, c0, d_doppler, d_gamma, sigma_bb_const, d_temperature, d_lte,
+                    hc_over_kB, pref_ij, pref_ji, d_C, d_atom_density, d_R, d_populations);
     hipLaunchKernelGGL(k_rates_populations, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, st, ra);
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
