@@ -446,7 +446,6 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
     p->h_up1.swap(up1);
     p->h_up2.swap(up2);
     std::vector<LayerSchedule> lsched((size_t)A);
-    std::vector<std::vector<int32_t>> sorted_self((size_t)A);   // thread assignment of k_step_levels
     std::vector<PatchSchedule> psched((size_t)A);                // fused patch path (vrt_patch.cpp)
     {
         // shape of the patch kernel: K entries per thread x NT threads = largest dependency cone of a patch
@@ -477,7 +476,6 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                                          p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n,
                                          lsched[(size_t)a]);
                     if (lsched[(size_t)a].ok) {
-                        build_sorted_slots(up ? g->up : g->down, n, lsched[(size_t)a].vis, sorted_self[(size_t)a]);
                         build_patch_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
                                              p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n,
                                              patch_own, p->patch_cap, psched[(size_t)a]);
@@ -547,15 +545,8 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             VRT_TRY_FREE(dev_alloc(&p->t_r2, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_vis, tab));
             VRT_TRY_FREE(dev_alloc(&p->t_loc, tab));
-            if (tile_ok) {
-                VRT_TRY_FREE(dev_alloc(&p->t_self, tab));
-                VRT_TRY_FREE(dev_alloc(&p->t_vis_s, tab));
-                VRT_TRY_FREE(dev_alloc(&p->t_loc_s, tab));
-                VRT_TRY_FREE(dev_alloc(&p->t_gpos, tab));
-                VRT_TRY_FREE(dev_alloc(&p->t_rank_s, tab));
-                VRT_TRY_FREE(dev_alloc(&p->t_loc_ss, tab));
-                if (max_layer <= 4096) VRT_TRY_FREE(dev_alloc(&p->t_code_ss, tab));
-            }
+            // (the sorted-slot tables of the steps / tiles paths are built when one of those paths first runs:
+            // ensure_step_tables -- the default patch path needs none of them)
             const int maxL = (int)std::max(g->up.reduced.size(), g->down.reduced.size()) - 1;
             p->tile_max_layers = maxL;
             if (patch_ok) {
@@ -586,14 +577,6 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                 hipError_t e = hipMemcpy(d_vis_site, lsched[(size_t)a].vis.data(), sizeof(uint32_t) * n,
                                          hipMemcpyHostToDevice);
                 int rc2 = e == hipSuccess ? launch_permute_table(p, a, d_vis_site) : VRT_ENODEVICE;
-                if (!rc2 && tile_ok) {     // sorted thread assignment of the layer-step level kernel
-                    if (hipMemcpy(p->t_self + (size_t)a * n, sorted_self[(size_t)a].data(), sizeof(int32_t) * n,
-                                  hipMemcpyHostToDevice) != hipSuccess)
-                        rc2 = VRT_ENODEVICE;
-                    if (!rc2) rc2 = launch_sorted_tables(p, a);
-                    if (!rc2) rc2 = launch_gpos(p, a);
-                }
-                std::vector<int32_t>().swap(sorted_self[(size_t)a]);
                 if (!rc2 && patch_ok) {    // patch records + entry tables of this angle
                     PatchSchedule &ps = psched[(size_t)a];
                     const size_t np_a = ps.patch_own_lo.size(), ne_a = ps.entry_pos.size();
@@ -659,6 +642,50 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
     *out = p;
     return VRT_OK;
 }
+
+}  // namespace vrt (reopened below)
+
+// Sorted-slot tables of the steps / tiles paths (thread assignment of their level kernels, compact coupling lists),
+// built when one of those paths first runs on the plan: they cost seven [A][n] device arrays and a host pass per
+// angle that the default patch path never needs (plan creation at C4 size: 0.95 -> 0.6 s).
+int vrt::ensure_step_tables(vrt_plan *p)
+{
+    using namespace vrt;
+    if (p->step_tables_ready) return VRT_OK;
+    if (!p->tile_ok) return fail(VRT_EINVAL, "the grid does not fit the steps / tiles kernels");
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const int A = p->A, n_sweeps = p->n_sweeps;
+    const size_t tab = (size_t)A * (size_t)n;
+    int rc;
+    if ((rc = dev_alloc(&p->t_self, tab)) || (rc = dev_alloc(&p->t_vis_s, tab)) || (rc = dev_alloc(&p->t_loc_s, tab)) ||
+        (rc = dev_alloc(&p->t_gpos, tab)) || (rc = dev_alloc(&p->t_rank_s, tab)) || (rc = dev_alloc(&p->t_loc_ss, tab)))
+        return rc;
+    if (p->tile_max_layer_size <= 4096 && (rc = dev_alloc(&p->t_code_ss, tab))) return rc;
+    std::vector<std::vector<int32_t>> sorted_self((size_t)A);
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nthr = std::max(1, std::min<int>((int)std::min<unsigned>(hw ? hw : 4, 16), A));
+    if (!run_workers(nthr, [&](int t) {
+            for (int a = t; a < A; a += nthr) {
+                const bool up = p->dir_of_active[(size_t)a] > 0;
+                LayerSchedule ls;
+                build_layer_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps, p->h_up1.data() + (size_t)a * n,
+                                     p->h_up2.data() + (size_t)a * n, ls);
+                build_sorted_slots(up ? g->up : g->down, n, ls.vis, sorted_self[(size_t)a]);
+            }
+        }))
+        return fail(VRT_ENOMEM, "out of host memory while building the layer-step tables");
+    for (int a = 0; a < A; a++) {
+        VRT_HIP_TRY(hipMemcpy(p->t_self + (size_t)a * n, sorted_self[(size_t)a].data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        std::vector<int32_t>().swap(sorted_self[(size_t)a]);
+        if ((rc = launch_sorted_tables(p, a)) || (rc = launch_gpos(p, a))) return rc;
+    }
+    VRT_HIP_TRY(hipStreamSynchronize(g->stream));
+    p->step_tables_ready = true;
+    return VRT_OK;
+}
+
+namespace vrt {
 
 static int ensure(double *&buf, size_t &cap, size_t count)
 {

@@ -211,6 +211,7 @@ struct vrt_plan {
     size_t stage_cap[6] = {0, 0, 0, 0, 0, 0};
     // layer paths (vrt_layers.hip, vrt_tables.hip): tables in storage order, per-layer level counts
     bool tile_ok = false;
+    bool step_tables_ready = false;      // t_self ... t_code_ss exist (ensure_step_tables)
     int tile_K = 8;                      // sites per thread of the 1024-thread workgroup
     int tile_max_layers = 0;
     int64_t tile_max_layer_size = 0;
@@ -404,6 +405,7 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, co
                        hipStream_t st, bool f32 = false);
 
 // ---- layer paths (vrt_tables.hip, vrt_layers.hip) ----------------------------------------------------------
+int ensure_step_tables(vrt_plan *p);     // sorted-slot tables of the steps / tiles paths, on first use (vrt_api.cpp)
 int launch_permute_table(vrt_plan *p, int a, const uint32_t *d_vis_site);
 int launch_sorted_tables(vrt_plan *p, int a);
 int launch_gpos(vrt_plan *p, int a);

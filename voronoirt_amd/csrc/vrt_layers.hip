@@ -274,6 +274,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     ta.alpha_mode = alpha_mode;
     ta.max_layers = p->tile_max_layers;
     ta.tile_stride = (int)((std::max<int64_t>(p->tile_max_layer_size, 1) + 2) & ~(int64_t)1);   // + the zero slot
+    if (!patches && (rc = ensure_step_tables(p))) return rc;        // (their pointers are read just below)
     if (!steps && (rc = build_task_map(p, (int)nlam, st))) return rc;
     ta.task_map = p->d_task_map;
     ta.angle_dir = p->d_angle_dir;
