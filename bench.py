@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E vendor peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r3"
+PROFILE_ROUND = "r4"
 
 WORKLOADS = {
     # name: (a, c, quadrature, nlam, alpha per angle, seed)   -- SURVEY.md 8d, BASELINE.md sec. 3
@@ -375,11 +375,16 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         "kernel": {"levels": "k_sweep_level (one launch per dependency level)",
                    "steps": "k_step_coeffs + k_step_levels (two launches per BFS layer)",
                    "tiles": "k_sweep_tiles (one persistent launch)",
-                   "patches": ("k_patch_quad (fp32 storage: two wavelength pairs per lane; " if f32 and ((nlam + 1) // 2) % 2 == 0
-                               else "k_patch_lean (64 registers, four workgroups per CU; " if (nlam + 1) // 2 >= 2
-                               else "k_patch_solve (") +
-                              "one fused launch per BFS layer and direction: coefficients + "
-                              "Gauss-Seidel levels of every patch, J reduction of the previous layer riding along)"
+                   "patches": (("k_patch_chain_quad (fp32 storage: two wavelength pairs per lane; " if f32 and ((nlam + 1) // 2) % 2 == 0
+                                else "k_patch_chain (64 registers, four workgroups per CU; ") +
+                               "ONE chained launch for every BFS layer of every angle: a workgroup takes the next item "
+                               "(patch, angle, block of wavelength pairs) of its XCD queue and waits, pair by pair, for the patches "
+                               "whose stored intensities it gathers; J_dir formed by items of the same launch)") if launches == 1
+                   else (("k_patch_quad (fp32 storage: two wavelength pairs per lane; " if f32 and ((nlam + 1) // 2) % 2 == 0
+                          else "k_patch_lean (64 registers, four workgroups per CU; " if (nlam + 1) // 2 >= 2
+                          else "k_patch_solve (") +
+                         "one fused launch per BFS layer and direction: coefficients + "
+                         "Gauss-Seidel levels of every patch, J reduction of the previous layer riding along)")
                    }.get(plan.last_path, plan.last_path),
         "path": plan.last_path, "launches_per_step": launches,
         "step_event_ms": step_event_ms,

@@ -142,9 +142,24 @@ case = vrt.LineCase(lam=lam, blocks=blocks, lambda0=lambda0, c0=C0, velocity=vel
 S_h = np.ascontiguousarray(case.B0[:, :nbb])
 line_only = vrt.LineCase(**{**{k: getattr(case, k) for k in vrt.LineCase.FIELDS}, "lam": lam[:nbb], "B0": S_h})
 vrt.J_lambda_voronoi_line(S_h, lte, sites, line_only, "ul7n12.dat")            # warm-up: plan, staging buffers
+# the C entry itself, as the Julia shim calls it: its arguments prepared before the clock starts (γ and the line
+# strength of the populations are the caller's numpy / Julia work either way)
+L0 = _lib.load()
+plan_l, wq_l = api._quadrature_plan(sites, "ul7n12.dat", 3)
+gam_h = api._f64(line_only.gamma(lte))
+str_h = api._f64(line_only.strength_const * (lte[0] * line_only.Bij - lte[1] * line_only.Bji))
+vel_h, dop_h, ac_h, lam_h = api._f64(velocity), api._f64(doppler), api._f64(alpha_cont), api._f64(lam[:nbb])
+n1h = int(sites.layers_up[1] - 1)
+I0_h = api._f64(S_h[sites.perm_up[:n1h] - 1])
+Jh = np.zeros((n, nbb))
+def line_call():
+    api.check(L0.vrt_plan_execute_line(plan_l._h, nbb, nbb, api._d(lam_h), float(lambda0), float(C0), api._d(vel_h), api._d(dop_h),
+                                       api._d(gam_h), api._d(str_h), api._d(ac_h), api._d(S_h), api._d(I0_h), None,
+                                       api._d(api._f64(wq_l)), api._d(Jh)))
+line_call()
 t0 = time.perf_counter()
 for _ in range(3):
-    Jh = vrt.J_lambda_voronoi_line(S_h, lte, sites, line_only, "ul7n12.dat")
+    line_call()
 dt = (time.perf_counter() - t0) / 3
 up = 8.0 * (n * nbb + 7 * n) / 1e9
 print(f"vrt_plan_execute_line, host arrays in -> J out ({nbb} wavelengths): {dt * 1e3:.1f} ms per J "

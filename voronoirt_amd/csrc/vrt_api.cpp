@@ -256,6 +256,14 @@ static void free_plan(vrt_plan *p)
         if (p->step_join[i]) (void)hipEventDestroy(p->step_join[i]);
         if (p->step_stream[i]) (void)hipStreamDestroy(p->step_stream[i]);
     }
+    for (CopyLane &l : p->copy_lanes) {
+        for (int b = 0; b < 2; b++) {
+            if (l.pin[b]) (void)hipHostFree(l.pin[b]);
+            if (l.ev[b]) (void)hipEventDestroy(l.ev[b]);
+        }
+        if (l.st) (void)hipStreamDestroy(l.st);
+    }
+    if (p->copy_done) (void)hipEventDestroy(p->copy_done);
     if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -789,7 +797,15 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_, c
         bool replayed = false;
         if (use_graph) {
             if (!(p->graph_exec && p->graph_key == key)) {
-                if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+                for (CopyLane &l : p->copy_lanes) {
+        for (int b = 0; b < 2; b++) {
+            if (l.pin[b]) (void)hipHostFree(l.pin[b]);
+            if (l.ev[b]) (void)hipEventDestroy(l.ev[b]);
+        }
+        if (l.st) (void)hipStreamDestroy(l.st);
+    }
+    if (p->copy_done) (void)hipEventDestroy(p->copy_done);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
                 p->graph_exec = nullptr;
                 hipGraph_t graph = nullptr;
                 if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {

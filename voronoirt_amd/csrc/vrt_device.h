@@ -122,6 +122,44 @@ __device__ __forceinline__ double exp_neg(double x)       // exp(-x), 5e-4 <= x 
     return ldexp(p, (int)kf);
 }
 
+// exp(-x) for 0 <= x (the patch kernels call it for 5e-4 <= x <= 50), table-driven: -x = N ln2/32 + r with |r| <= ln2/64, exp(-x) = 2^(N >> 5) T[N & 31] p(r),
+// T[j] = 2^(j/32) from a 32-entry LDS table (one 8-byte read per evaluation, conflict-free: the 32 entries cover the
+// 64 banks once) and p the degree-5 Taylor polynomial (remainder r^6/720 < 2.3e-15).  Against the degree-10 polynomial
+// on |r| <= ln2/2 it replaces: four fused multiply-adds fewer per evaluation, and five of its eleven non-inline fp64
+// constants -- ten scalar registers of a kernel that is short of exactly those.  Relative error ~3e-15 (contract 1e-10).
+static __device__ const double kExp2_32[32] = {
+    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237, 1.0905077326652577, 1.1143867425958924,
+    1.1387886347566916, 1.1637248587775775, 1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332,
+    1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832, 1.4142135623730951, 1.4451808069770467,
+    1.4768261459394993, 1.5091644275934228, 1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965,
+    1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072, 1.8340080864093424, 1.8741676341103,
+    1.9152065613971474, 1.9571441241754002};
+__device__ __forceinline__ double *exp2_table()
+{
+    __shared__ double t[32];
+    return t;
+}
+// every kernel that evaluates it: fill the table, then a barrier before the first evaluation
+__device__ __forceinline__ void exp2_table_fill()
+{
+    if (threadIdx.x < 32) exp2_table()[threadIdx.x] = kExp2_32[threadIdx.x];
+}
+__device__ __forceinline__ double exp_neg_tab(double x)          // exp(-x), 0 <= x <= 700
+{
+    const double t = -x;
+    const double nf = rint(t * 46.16624130844683);            // N = round(t 32 / ln 2), |N| <= 2309
+    double r = fma(-nf, 0.021660849335603416, t);             // Cody-Waite: ln2/32 = hi (29 bits) + lo
+    r = fma(-nf, 5.689487495325457e-11, r);                   // |r| <= 0.01084
+    const int N = (int)nf;
+    double p = 1.0 / 120.0;
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p * exp2_table()[N & 31], N >> 5);
+}
+
 __device__ __forceinline__ void lin_weights(double dtau, double &a, double &b, double &e)
 {
     // reciprocal of dtau (only consumed when dtau >= 5e-4): hardware estimate + 2 Newton steps

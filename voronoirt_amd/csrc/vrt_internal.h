@@ -95,6 +95,16 @@ struct Direction {
 
 struct PlanCacheEntry;
 
+// Host <-> device lanes of the host-pointer entry points (vrt_lambda.cpp: vrt_plan_execute_line): per lane a copy stream
+// and two pinned staging buffers, filled / drained by a host thread of its own, so that the caller's pageable arrays
+// travel at PCIe speed (a pageable hipMemcpy stages through ONE thread: 0.4 GB of S took 20 ms each way)
+struct CopyLane {
+    hipStream_t st = nullptr;
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+constexpr size_t kCopyChunk = (size_t)8 << 20;      // bytes per staging buffer
+
 // Tuning options of a plan (vrt_plan_set_option / vrt_grid_set_option).  Defaults; an environment variable of the
 // option's name presets it, read ONCE when the plan is created (never during an execute).  Results do not
 // depend on any of them (the parity tests run the paths and shapes against each other).
@@ -288,6 +298,8 @@ struct vrt_plan {
     vrt::SweepKey graph_key;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    std::vector<vrt::CopyLane> copy_lanes;      // host-pointer entry points (ensure_copy_lanes)
+    hipEvent_t copy_done = nullptr;
     int64_t last_launches = 0;
     std::mutex mu;
 };

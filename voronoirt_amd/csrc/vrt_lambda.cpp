@@ -6,9 +6,12 @@
 //   vrt_lambda_*           Λ_voronoi's loop (src/lambda_iteration.jl:205-300) with library-owned device state:
 //                          per iteration only the criterion's scalar comes back
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "vrt_internal.h"
 
@@ -25,6 +28,105 @@ int dalloc(T **p, size_t count)
         *p = nullptr;
         return fail(e == hipErrorOutOfMemory ? VRT_ENOMEM : VRT_ENODEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
+    return VRT_OK;
+}
+
+// ---- pageable host arrays at PCIe speed: lanes of (host thread, copy stream, two pinned staging buffers) ----------------
+struct CopyJob {
+    const char *host_src = nullptr;     // upload: rows of `width` bytes, `hstride` apart
+    char *host_dst = nullptr;           // download
+    char *dev = nullptr;                // dense on the device: rows x width bytes
+    size_t rows = 0, width = 0, hstride = 0;
+};
+
+int ensure_copy_lanes(vrt_plan *p, int lanes)
+{
+    if ((int)p->copy_lanes.size() >= lanes && p->copy_done) return VRT_OK;
+    if (!p->copy_done) VRT_HIP_TRY(hipEventCreateWithFlags(&p->copy_done, hipEventDisableTiming));
+    while ((int)p->copy_lanes.size() < lanes) {
+        CopyLane l;
+        VRT_HIP_TRY(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            VRT_HIP_TRY(hipHostMalloc(&l.pin[b], kCopyChunk, hipHostMallocDefault));
+            VRT_HIP_TRY(hipEventCreateWithFlags(&l.ev[b], hipEventDisableTiming));
+        }
+        p->copy_lanes.push_back(l);
+    }
+    return VRT_OK;
+}
+
+// rows x width bytes per job <= kCopyChunk
+void split_jobs(std::vector<CopyJob> &jobs, const void *host, void *dev, size_t rows, size_t width, size_t hstride, bool download)
+{
+    const size_t per = std::max<size_t>(1, kCopyChunk / std::max<size_t>(width, 1));
+    for (size_t r0 = 0; r0 < rows; r0 += per) {
+        CopyJob j;
+        j.rows = std::min(per, rows - r0);
+        j.width = width;
+        j.hstride = hstride;
+        j.dev = (char *)dev + r0 * width;
+        if (download) j.host_dst = (char *)const_cast<void *>(host) + r0 * hstride;
+        else j.host_src = (const char *)host + r0 * hstride;
+        jobs.push_back(j);
+    }
+}
+
+void rows_copy(char *dst, size_t dstride, const char *src, size_t sstride, size_t rows, size_t width)
+{
+    if (dstride == width && sstride == width) { std::memcpy(dst, src, rows * width); return; }
+    for (size_t r = 0; r < rows; r++) std::memcpy(dst + r * dstride, src + r * sstride, width);
+}
+
+// every lane takes the jobs lane, lane + L, ...; uploads leave on the lanes' streams (`st` then waits for them), downloads
+// start behind `after` (an event of the producing stream) and are complete in host memory on return
+int run_copy_jobs(vrt_plan *p, const std::vector<CopyJob> &jobs, bool download, hipEvent_t after, hipStream_t st, int device)
+{
+    const int L = (int)p->copy_lanes.size();
+    std::vector<int> rcs((size_t)L, VRT_OK);
+    auto lane_work = [&](int li) {
+        CopyLane &l = p->copy_lanes[(size_t)li];
+        if (hipSetDevice(device) != hipSuccess) { rcs[(size_t)li] = VRT_ENODEVICE; return; }
+        auto ok = [&](hipError_t e) { if (e != hipSuccess) rcs[(size_t)li] = VRT_ENODEVICE; return e == hipSuccess; };
+        if (download && after && !ok(hipStreamWaitEvent(l.st, after, 0))) return;
+        int pending[2] = {-1, -1};
+        int slot = 0;
+        for (size_t k = (size_t)li; k < jobs.size(); k += (size_t)L, slot ^= 1) {
+            const CopyJob &j = jobs[k];
+            const size_t bytes = j.rows * j.width;
+            if (pending[slot] >= 0) {                        // the buffer's previous transfer: finished (and, downloading, taken home)
+                if (!ok(hipEventSynchronize(l.ev[slot]))) return;
+                if (download) {
+                    const CopyJob &o = jobs[(size_t)pending[slot]];
+                    rows_copy(o.host_dst, o.hstride, (const char *)l.pin[slot], o.width, o.rows, o.width);
+                }
+            }
+            if (download) {
+                if (!ok(hipMemcpyAsync(l.pin[slot], j.dev, bytes, hipMemcpyDeviceToHost, l.st))) return;
+            } else {
+                rows_copy((char *)l.pin[slot], j.width, j.host_src, j.hstride, j.rows, j.width);
+                if (!ok(hipMemcpyAsync(j.dev, l.pin[slot], bytes, hipMemcpyHostToDevice, l.st))) return;
+            }
+            if (!ok(hipEventRecord(l.ev[slot], l.st))) return;
+            pending[slot] = (int)k;
+        }
+        for (int b = 0; b < 2; b++) {                        // drain (oldest first: the slot that is next in turn)
+            const int sl = slot ^ b;
+            if (pending[sl] < 0) continue;
+            if (download) {
+                if (!ok(hipEventSynchronize(l.ev[sl]))) return;
+                const CopyJob &o = jobs[(size_t)pending[sl]];
+                rows_copy(o.host_dst, o.hstride, (const char *)l.pin[sl], o.width, o.rows, o.width);
+            }
+        }
+    };
+    if (!run_workers(L, lane_work)) return fail(VRT_ENOMEM, "out of host memory in a copy lane");
+    for (int li = 0; li < L; li++)
+        if (rcs[(size_t)li]) return fail(rcs[(size_t)li], "a host <-> device copy lane failed");
+    if (!download)
+        for (int li = 0; li < L; li++) {                     // `st` follows the uploads
+            CopyLane &l = p->copy_lanes[(size_t)li];
+            for (int b = 0; b < 2; b++) VRT_HIP_TRY(hipStreamWaitEvent(st, l.ev[b], 0));
+        }
     return VRT_OK;
 }
 
@@ -102,10 +204,10 @@ int vrt_plan_execute_line(vrt_plan *p, int64_t nlam, int64_t ld, const double *l
             return fail(VRT_EINVAL, "the line entry needs a layer path (at most 4 visits per site and 255 levels per layer)");
         if (p->A != (int)p->n_angles_user)
             return fail(VRT_EINVAL, "per-angle alpha needs every angle active (no θ = 90 direction)");
-        const size_t n = (size_t)g->n, nS = n * (size_t)ld;
-        const size_t nU = (size_t)g->up.n1 * (size_t)nlam, nD = (size_t)g->down.n1 * (size_t)nlam;
+        const size_t n = (size_t)g->n, nl = (size_t)nlam, nS = n * nl;           // dense (n, nlam) on the device
+        const size_t nU = (size_t)g->up.n1 * nl, nD = (size_t)g->down.n1 * nl;
         hipStream_t st = g->stream;
-        // staging: S | J in the plan's stage buffers; the nine per-site vectors + λ in stage 1; α_tot native in ws_AA
+        // staging: S | J in the plan's stage buffers; the seven per-site vectors + λ in stage 1; α_tot native in ws_AA
         auto ensure = [&](double *&buf, size_t &cap, size_t count) -> int {
             if (buf && count <= cap) return VRT_OK;
             if (buf) (void)hipFree(buf);
@@ -115,7 +217,7 @@ int vrt_plan_execute_line(vrt_plan *p, int64_t nlam, int64_t ld, const double *l
             if (!r) cap = count;
             return r;
         };
-        const size_t vecs = 7 * n + (size_t)nlam;        // velocity (3n), ΔλD, γ, strength, α_cont, λ
+        const size_t vecs = 7 * n + nl;                  // velocity (3n), ΔλD, γ, strength, α_cont, λ
         if ((rc = ensure(p->d_stage[0], p->stage_cap[0], nS))) return rc;
         if ((rc = ensure(p->d_stage[1], p->stage_cap[1], vecs))) return rc;
         if ((rc = ensure(p->d_stage[4], p->stage_cap[4], nS))) return rc;
@@ -123,31 +225,80 @@ int vrt_plan_execute_line(vrt_plan *p, int64_t nlam, int64_t ld, const double *l
         if ((rc = ensure(p->ws_AA, p->ws_AA_cap, nnat))) return rc;
         double *dv = p->d_stage[1];
         double *d_vel = dv, *d_dop = dv + 3 * n, *d_gam = dv + 4 * n, *d_str = dv + 5 * n, *d_ac = dv + 6 * n, *d_lam = dv + 7 * n;
-        VRT_HIP_TRY(hipMemcpyAsync(p->d_stage[0], S, sizeof(double) * nS, hipMemcpyHostToDevice, st));
-        VRT_HIP_TRY(hipMemcpyAsync(d_vel, velocity, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
-        VRT_HIP_TRY(hipMemcpyAsync(d_dop, doppler_width, sizeof(double) * n, hipMemcpyHostToDevice, st));
-        VRT_HIP_TRY(hipMemcpyAsync(d_gam, gamma, sizeof(double) * n, hipMemcpyHostToDevice, st));
-        VRT_HIP_TRY(hipMemcpyAsync(d_str, line_strength, sizeof(double) * n, hipMemcpyHostToDevice, st));
-        VRT_HIP_TRY(hipMemcpyAsync(d_ac, alpha_cont, sizeof(double) * n, hipMemcpyHostToDevice, st));
-        VRT_HIP_TRY(hipMemcpyAsync(d_lam, lambda, sizeof(double) * (size_t)nlam, hipMemcpyHostToDevice, st));
         double *dU = nullptr, *dD = nullptr;
         if (I0_up && nU) {
             if ((rc = ensure(p->d_stage[2], p->stage_cap[2], nU))) return rc;
             dU = p->d_stage[2];
-            VRT_HIP_TRY(hipMemcpyAsync(dU, I0_up, sizeof(double) * nU, hipMemcpyHostToDevice, st));
         }
         if (I0_down && nD) {
             if ((rc = ensure(p->d_stage[3], p->stage_cap[3], nD))) return rc;
             dD = p->d_stage[3];
-            VRT_HIP_TRY(hipMemcpyAsync(dD, I0_down, sizeof(double) * nD, hipMemcpyHostToDevice, st));
         }
-        // α_tot of every angle straight into the native layout (lambda_iteration.jl:72-80, :89, :93-96), then the sweep
+        // The caller's arrays are pageable: they cross PCIe through copy lanes (a host thread, a copy stream and two pinned
+        // buffers each).  Order: the per-site vectors -> the opacity kernel starts while S is still on its way -> sweep ->
+        // J comes home in chunks.  Only the nlam columns of S and J are touched (ld >= nlam: the padding stays the caller's).
+        unsigned hw = std::thread::hardware_concurrency();
+        const int lanes = (int)std::max(2u, std::min(8u, (hw ? hw : 8u) / 2));
+        if ((rc = ensure_copy_lanes(p, lanes))) return rc;
+        const size_t w8 = sizeof(double);
+#ifdef VRT_DIAG
+        const auto t0 = std::chrono::steady_clock::now();
+#endif
+        std::vector<CopyJob> jobs;
+        split_jobs(jobs, velocity, d_vel, 1, w8 * 3 * n, w8 * 3 * n, false);
+        split_jobs(jobs, doppler_width, d_dop, 1, w8 * n, w8 * n, false);
+        split_jobs(jobs, gamma, d_gam, 1, w8 * n, w8 * n, false);
+        split_jobs(jobs, line_strength, d_str, 1, w8 * n, w8 * n, false);
+        split_jobs(jobs, alpha_cont, d_ac, 1, w8 * n, w8 * n, false);
+        // (a 1-row job wider than a staging buffer is cut by bytes: rows of 1 MiB)
+        {
+            std::vector<CopyJob> cut;
+            for (const CopyJob &j : jobs)
+                if (j.rows == 1 && j.width > kCopyChunk) {
+                    const size_t piece = (size_t)1 << 20;
+                    split_jobs(cut, j.host_src, j.dev, j.width / piece, piece, piece, false);
+                    const size_t done = j.width / piece * piece;
+                    if (done < j.width) split_jobs(cut, j.host_src + done, j.dev + done, 1, j.width - done, j.width - done, false);
+                } else
+                    cut.push_back(j);
+            jobs.swap(cut);
+        }
+        split_jobs(jobs, lambda, d_lam, 1, w8 * nl, w8 * nl, false);
+        if ((rc = run_copy_jobs(p, jobs, false, nullptr, st, g->device))) return rc;
+#ifdef VRT_DIAG
+        const auto t1 = std::chrono::steady_clock::now();
+#endif
+        // α_tot of every angle straight into the native layout (lambda_iteration.jl:72-80, :89, :93-96)
         if ((rc = launch_line_opacity(p, nlam, d_lam, lambda0, c0, d_vel, d_dop, d_gam, d_str, d_ac, p->ws_AA, st))) return rc;
+        jobs.clear();
+        split_jobs(jobs, S, p->d_stage[0], n, w8 * nl, w8 * (size_t)ld, false);
+        if (dU) split_jobs(jobs, I0_up, dU, (size_t)g->up.n1, w8 * nl, w8 * nl, false);
+        if (dD) split_jobs(jobs, I0_down, dD, (size_t)g->down.n1, w8 * nl, w8 * nl, false);
+        if ((rc = run_copy_jobs(p, jobs, false, nullptr, st, g->device))) return rc;
+#ifdef VRT_DIAG
+        const auto t2 = std::chrono::steady_clock::now();
+#endif
         // (execute_dev_locked reuses ws_AA only for the CALLER-layout per-angle alpha, not for the native one)
-        rc = execute_dev_locked(p, nlam, ld, p->d_stage[0], p->ws_AA, VRT_ALPHA_ANGLE_NATIVE, dU, dD, weights,
+        rc = execute_dev_locked(p, nlam, nlam, p->d_stage[0], p->ws_AA, VRT_ALPHA_ANGLE_NATIVE, dU, dD, weights,
                                 p->d_stage[4], nullptr, st);
         if (rc) return rc;
-        VRT_HIP_TRY(hipMemcpyAsync(J, p->d_stage[4], sizeof(double) * nS, hipMemcpyDeviceToHost, st));
+        VRT_HIP_TRY(hipEventRecord(p->copy_done, st));
+#ifdef VRT_DIAG
+        const auto t3 = std::chrono::steady_clock::now();
+        (void)hipStreamSynchronize(st);
+        const auto t4 = std::chrono::steady_clock::now();
+#endif
+        jobs.clear();
+        split_jobs(jobs, J, p->d_stage[4], n, w8 * nl, w8 * (size_t)ld, true);
+        if ((rc = run_copy_jobs(p, jobs, true, p->copy_done, st, g->device))) return rc;
+#ifdef VRT_DIAG
+        {
+            const auto t5 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "[vrt execute_line] lanes %d: vectors up %.1f ms, S staged %.1f ms, launches %.1f ms, wait for the sweep %.1f ms, J down %.1f ms\n",
+                         lanes, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5));
+        }
+#endif
         VRT_HIP_TRY(hipStreamSynchronize(st));
         return VRT_OK;
     } catch (const std::bad_alloc &) {
