@@ -55,6 +55,42 @@ __device__ __forceinline__ double c_div_re(cplx a, cplx b)                // Re(
     r = fma(fma(-d, r, 1.0), r, r);
     return fma(a.re, b.re, a.im * b.im) * r;
 }
+// cos z for the |z| <= ~12 that region 4 of w4 can produce (z = -2 x y, |x| + y < 5.5): when every lane of the wave has
+// |z| <= pi/4 -- the narrow damping wings of a stellar atmosphere: always -- its Taylor polynomial to z^14 (remainder
+// 1e-15); otherwise Cody-Waite reduction by pi/2 (fdlibm's two-part split: exact for |k| <= 2^20) and the sine /
+// cosine polynomials of the reduced argument.  (libm's cos drags its large-argument reduction into the kernel:
+// 102 -> VGPRs and a third of this region's instructions.)
+__device__ __forceinline__ double cos_poly(double z2)
+{
+    double p = -1.0 / 87178291200.0;
+    p = fma(p, z2, 1.0 / 479001600.0);
+    p = fma(p, z2, -1.0 / 3628800.0);
+    p = fma(p, z2, 1.0 / 40320.0);
+    p = fma(p, z2, -1.0 / 720.0);
+    p = fma(p, z2, 1.0 / 24.0);
+    p = fma(p, z2, -0.5);
+    return fma(p, z2, 1.0);
+}
+__device__ __forceinline__ double cos_small(double z)
+{
+    if (__ballot(fabs(z) > 0.78539816339744831) == 0ull) return cos_poly(z * z);
+    const double kf = rint(z * 0.63661977236758134308);
+    double r = fma(-kf, 1.57079632673412561417e+00, z);
+    r = fma(-kf, 6.07710050650619224932e-11, r);
+    const double r2 = r * r;
+    double sp = -1.0 / 1307674368000.0;
+    sp = fma(sp, r2, 1.0 / 6227020800.0);
+    sp = fma(sp, r2, -1.0 / 39916800.0);
+    sp = fma(sp, r2, 1.0 / 362880.0);
+    sp = fma(sp, r2, -1.0 / 5040.0);
+    sp = fma(sp, r2, 1.0 / 120.0);
+    sp = fma(sp, r2, -1.0 / 6.0);
+    const double sn = fma(sp * r2, r, r), cs = cos_poly(r2);
+    const int q = (int)kf & 3;
+    const double v = (q & 1) ? sn : cs;
+    return (q == 1 || q == 2) ? -v : v;
+}
+
 __device__ double humlicek_w4_re(double x, double y)
 {
     const cplx t = {y, -x};
@@ -95,20 +131,7 @@ __device__ double humlicek_w4_re(double x, double y)
     // lane of the wave has |u.im| <= pi/4 the cosine is its Taylor polynomial to z^14 (remainder 1e-15), no range
     // reduction.  libm's exp + cos were half of this region's instructions, and this region ~80 % of the kernel.
     const double ex = exp_neg_tab(-u.re);
-    double cs;
-    if (__ballot(fabs(u.im) > 0.78539816339744831) == 0ull) {
-        const double z2 = u.im * u.im;
-        double p = -1.0 / 87178291200.0;
-        p = fma(p, z2, 1.0 / 479001600.0);
-        p = fma(p, z2, -1.0 / 3628800.0);
-        p = fma(p, z2, 1.0 / 40320.0);
-        p = fma(p, z2, -1.0 / 720.0);
-        p = fma(p, z2, 1.0 / 24.0);
-        p = fma(p, z2, -0.5);
-        cs = fma(p, z2, 1.0);
-    } else
-        cs = cos(u.im);
-    return ex * cs - c_div_re(c_mul(t, num), den);
+    return ex * cos_small(u.im) - c_div_re(c_mul(t, num), den);
 }
 
 constexpr double kPi = 3.14159265358979323846;
@@ -118,7 +141,7 @@ constexpr double kPi = 3.14159265358979323846;
 // site's seven line parameters are read once and every pair plane is written coalesced (16 B/lane)
 // T2 = double2, or float2 for the fp32 VALUE path (the arithmetic stays fp64, the stored pair is rounded)
 template <typename T2>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256)                // (82 registers, five waves per SIMD; forced to 80 / six: 12 B of scratch, no faster)
 k_line_opacity(int64_t n, int nlam, int npair, int lgB, const int32_t *__restrict__ store, double k0, double k1, double k2,
                const double *__restrict__ lambda, double lambda0, double c0, const double *__restrict__ velocity,
                const double *__restrict__ doppler, const double *__restrict__ gamma,
