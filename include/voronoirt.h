@@ -242,6 +242,9 @@ int vrt_patch_schedule_get(const vrt_patch_schedule *s, int32_t *layer_patch_off
  * and the never-visited last site have no owner).  dep_off [patches + 1] first, then dep_list [dep_off[patches]];
  * either pointer may be NULL. */
 int vrt_patch_schedule_get_deps(const vrt_patch_schedule *s, int64_t *dep_off, int32_t *dep_list);
+/* The angle's layer schedule as the patch builder derives it on the way (plan creation uses this one): same contents as
+ * vrt_layer_schedule's outputs (vis[n], nlev[vrt_grid_num_layer_offsets], *n_visits); any pointer may be NULL. */
+int vrt_patch_schedule_get_layers(const vrt_patch_schedule *s, uint32_t *vis, int32_t *nlev, int64_t *n_visits);
 void vrt_patch_schedule_destroy(vrt_patch_schedule *s);
 
 /* ---- single solves: drop-in bodies for Delaunay_upII / Delaunay_downII --------------------

@@ -458,6 +458,10 @@ def test_patch_schedule_equals_serial_gauss_seidel(grid, bcc_small, voro_small):
             unsplit, nv = _run_layer_tiles(so, hs, k, S, I0, alpha, dirn, n_sweeps)
             assert np.array_equal(got, unsplit)                 # same arithmetic on the same values
             assert ps["live_visits"] == nv and ps["visits"] >= nv
+            # the builder's by-product IS the angle's layer schedule (plan creation takes it from there)
+            up_tab, *_ = orc.upwind_table(so, k)
+            vis, nlev, nvis = build_layer_schedule(hs, dirn, up_tab, n_sweeps)
+            assert np.array_equal(ps["layer_vis"], vis) and np.array_equal(ps["layer_nlev"], nlev) and ps["layer_visits"] == nvis
             if own >= 60000:                                    # one patch per layer: no halo at all
                 assert ps["visits"] == nv and ps["entries"] == n - (lay[1] - 1) - 1
             halo += ps["entries"] - (n - (lay[1] - 1) - 1)

@@ -115,6 +115,7 @@ PROTOTYPES = {
     "vrt_patch_schedule_get": (ctypes.c_int, [vp, p_i32, p_i32, p_i32, p_i32, p_i64, p_i32,
                                               ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     "vrt_patch_schedule_get_deps": (ctypes.c_int, [vp, p_i64, p_i32]),
+    "vrt_patch_schedule_get_layers": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_uint32), p_i32, p_i64]),
     "vrt_patch_schedule_destroy": (None, [vp]),
     "vrt_lambda_update_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp, vp, vp, p_dbl, vp]),
     "vrt_short_characteristics": (ctypes.c_int, [c_i64, c_i64, c_i64, p_dbl, p_dbl, p_dbl, c_i64, p_dbl,

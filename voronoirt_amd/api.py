@@ -130,7 +130,10 @@ class VoronoiSites:
         check(_lib.load().vrt_grid_set_option(self._h, name.encode(), str(value).encode()))
         self._options[name] = str(value)
         for p in list(self._live_plans):
-            p.set_option(name, value)
+            try:
+                p.set_option(name, value)
+            except VrtError:
+                pass          # an option that shapes what plan creation builds: it holds for the plans created from now on
 
     def storage_order(self, d: int) -> np.ndarray:
         """1-based site id at every storage position of direction d (> 0 up, < 0 down): the site
@@ -593,6 +596,13 @@ def build_patch_schedule(sites: VoronoiSites, dir: int, up, n_sweeps: int = 3, o
         check(L.vrt_patch_schedule_get_deps(h, _i(out["dep_off"]), None))
         out["dep_list"] = np.zeros(int(out["dep_off"][-1]), dtype=np.int32)
         check(L.vrt_patch_schedule_get_deps(h, None, out["dep_list"].ctypes.data_as(_lib.p_i32)))
+        # the angle's layer schedule, as the builder derives it on the way (= build_layer_schedule's outputs)
+        out["layer_vis"] = np.zeros(sites.n, dtype=np.uint32)
+        out["layer_nlev"] = np.zeros((sites.layers_up if dir > 0 else sites.layers_down).size, dtype=np.int32)
+        nv = ctypes.c_int64()
+        check(L.vrt_patch_schedule_get_layers(h, out["layer_vis"].ctypes.data_as(u32),
+                                              out["layer_nlev"].ctypes.data_as(_lib.p_i32), ctypes.byref(nv)))
+        out["layer_visits"] = nv.value
     finally:
         L.vrt_patch_schedule_destroy(h)
     out.update(patches=P, entries=E, visits=int(cnt[2]), live_visits=int(cnt[3]), max_entries=int(cnt[4]))

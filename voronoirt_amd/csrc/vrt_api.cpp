@@ -1,5 +1,7 @@
 // extern "C" entry points of libvrt_hip.so (declared in include/voronoirt.h).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +31,17 @@ void tuning_from_env(Tuning &t)
                                   "VRT_TILE_DEBUG"};
     for (const char *nm : names) {
         const char *e = std::getenv(nm);
-        if (e && *e) (void)tuning_set(t, nm, e, /*created=*/false);     // a bad value keeps the default
+        if (e && *e && tuning_set(t, nm, e, /*created=*/false) != VRT_OK) {
+            // a bad value keeps the default -- said once per variable, so that a typo such as VRT_PATH=patch does not
+            // quietly benchmark another path than the one meant
+            static std::mutex mu;
+            static std::vector<std::string> said;
+            std::lock_guard<std::mutex> lock(mu);
+            if (std::find(said.begin(), said.end(), std::string(nm)) == said.end()) {
+                said.push_back(nm);
+                std::fprintf(stderr, "[libvrt_hip] ignoring %s=%s: %s\n", nm, e, g_err.c_str());
+            }
+        }
     }
 }
 
@@ -370,6 +382,16 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
     if (n_sweeps < 1) return fail(VRT_EINVAL, "n_sweeps must be >= 1");
     int rc = use_device(g->device);
     if (rc) return rc;
+#ifdef VRT_DIAG
+    auto t_phase = std::chrono::steady_clock::now();
+    auto tick = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[plan_create] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
+        t_phase = now;
+    };
+#else
+    auto tick = [](const char *) {};
+#endif
     vrt_plan *p = new (std::nothrow) vrt_plan();
     if (!p) return fail(VRT_ENOMEM, "out of host memory");
     p->g = g;
@@ -451,6 +473,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
     // per-angle layer-local schedules (always needed: they drive the default steps/tiles paths and
     // detect sites without an upwind neighbour), built concurrently on the host.  The global-level
     // schedule of the "levels" path is built on first use (ensure_level_schedule).
+    tick("upwind tables (device) + D2H");
     p->h_up1.swap(up1);
     p->h_up2.swap(up2);
     std::vector<LayerSchedule> lsched((size_t)A);
@@ -473,27 +496,32 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
     // a patch owns as many consecutive sites as its dependency cone leaves room for (VRT_PATCH_OWN: at most that many)
     const int patch_own = p->tune.patch_own > 0 ? std::min(p->tune.patch_own, p->patch_cap) : p->patch_cap;
     {
-        unsigned hw = std::thread::hardware_concurrency();
-        int nthr = (int)std::min<unsigned>(hw ? hw : 4, 16);
-        nthr = std::max(1, std::min(nthr, A));
+        // one job per angle, dealt to the host threads; a job splits further by layer (the layers of an angle are analysed
+        // independently, vrt_patch.cpp) when threads are left over.  The patch builder returns the angle's layer schedule
+        // as a by-product -- the same analysis -- so build_layer_schedule itself only runs for an angle whose layers do not
+        // fit the packed encoding (it then says so too; the level kernels take over).
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int nthr = std::max(1, (int)std::min<unsigned>(std::min(hw, 16u), (unsigned)A));
+        const int sub_threads = (int)std::max(1u, std::min(16u, hw / (unsigned)nthr));
+        std::atomic<int> next_job(0);
         // (every schedule build holds a visit trace of up to n_sweeps n entries and a dozen n-sized arrays)
-        if (!run_workers(nthr, [&](int t) {
-                for (int a = t; a < A; a += nthr) {
+        if (!run_workers(nthr, [&](int) {
+                for (;;) {
+                    const int a = next_job.fetch_add(1);
+                    if (a >= A) break;
                     const bool up = p->dir_of_active[(size_t)a] > 0;
-                    build_layer_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
-                                         p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n,
-                                         lsched[(size_t)a]);
-                    if (lsched[(size_t)a].ok) {
-                        build_patch_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps,
-                                             p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n,
-                                             patch_own, p->patch_cap, psched[(size_t)a]);
-                    }
+                    const int32_t *u1 = p->h_up1.data() + (size_t)a * n, *u2 = p->h_up2.data() + (size_t)a * n;
+                    build_patch_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps, u1, u2, patch_own,
+                                         p->patch_cap, psched[(size_t)a], sub_threads, &lsched[(size_t)a]);
+                    if (!lsched[(size_t)a].ok && lsched[(size_t)a].bad_site < 0)
+                        build_layer_schedule(up ? g->up : g->down, /*ascending=*/up, n, n_sweeps, u1, u2, lsched[(size_t)a]);
                 }
             })) {
             free_plan(p);
             return fail(VRT_ENOMEM, "out of host memory while building the sweep schedules");
         }
     }
+    tick("layer + patch schedules");
     for (int a = 0; a < A; a++) {
         if (lsched[(size_t)a].bad_site >= 0) {
             std::string msg = "site " + std::to_string(lsched[(size_t)a].bad_site + 1) +
@@ -645,6 +673,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             }
         }
     }
+    tick("tables upload + entry kernels");
 #undef VRT_TRY_FREE
 #undef VRT_HIP_TRY_FREE
     *out = p;
@@ -1170,6 +1199,7 @@ int vrt_layer_sorted_slots(const vrt_grid *g, int dir, const uint32_t *vis, int6
 
 struct vrt_patch_schedule {
     vrt::PatchSchedule s;
+    vrt::LayerSchedule layers;       // the builder's by-product (what plan creation uses as the angle's layer schedule)
 };
 
 int vrt_patch_schedule_build(const vrt_grid *g, int dir, const int64_t *up, int n_sweeps, int own_target,
@@ -1190,7 +1220,7 @@ int vrt_patch_schedule_build(const vrt_grid *g, int dir, const int64_t *up, int 
         }
         vrt_patch_schedule *ps = new vrt_patch_schedule();
         build_patch_schedule(direction_of(g, dir), dir > 0, n, n_sweeps, u1.data(), u2.data(), own_target, entry_cap,
-                             ps->s);
+                             ps->s, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())), &ps->layers);
         if (ps->s.bad_site >= 0) {
             const std::string msg = "site " + std::to_string(ps->s.bad_site + 1) + " has no upwind neighbour";
             delete ps;
@@ -1236,6 +1266,17 @@ int vrt_patch_schedule_get_deps(const vrt_patch_schedule *s, int64_t *dep_off, i
     const PatchSchedule &p = s->s;
     if (dep_off) std::copy(p.dep_off.begin(), p.dep_off.end(), dep_off);
     if (dep_list) std::copy(p.dep_list.begin(), p.dep_list.end(), dep_list);
+    return VRT_OK;
+}
+
+int vrt_patch_schedule_get_layers(const vrt_patch_schedule *s, uint32_t *vis, int32_t *nlev, int64_t *n_visits)
+{
+    if (!s) return fail(VRT_EINVAL, "NULL schedule");
+    const LayerSchedule &ls = s->layers;
+    if (!ls.ok) return fail(VRT_EINVAL, "schedule does not fit the packed layer-tile encoding");
+    if (vis) std::copy(ls.vis.begin(), ls.vis.end(), vis);
+    if (nlev) std::copy(ls.nlev.begin(), ls.nlev.end(), nlev);
+    if (n_visits) *n_visits = ls.n_visits;
     return VRT_OK;
 }
 

@@ -362,8 +362,12 @@ struct PatchSchedule {
     int64_t bad_site = -1;
     bool ok = false;
 };
+// `threads`: host threads the layers of the angle are dealt to (they are analysed independently); may throw std::bad_alloc
 void build_patch_schedule(const Direction &dir, bool ascending, int64_t n, int n_sweeps, const int32_t *up1,
-                          const int32_t *up2, int own_target, int entry_cap, PatchSchedule &out);
+                          const int32_t *up2, int own_target, int entry_cap, PatchSchedule &out, int threads = 1,
+                          LayerSchedule *layers = nullptr);
+// (`layers`: also filled with what build_layer_schedule returns for the angle -- the same analysis, done layer by layer
+//  here -- whenever its packed encoding fits; !layers->ok with bad_site < 0 means "ask build_layer_schedule")
 
 // ---- device launchers (vrt_kernels.hip) ------------------------------------------------------
 int launch_delaunay_lines(vrt_grid *g);
