@@ -194,6 +194,33 @@ def test_gpu_regular_rows_longer_than_the_workgroup(monkeypatch):
         assert np.abs(got[j] - ref).max() / np.abs(ref).max() < 1e-12
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(7, 62, 62), (5, 40, 23), (4, 72, 77), (3, 3, 3), (4, 150, 140)])
+def test_gpu_regular_xy_batches_split_form(monkeypatch, shape):
+    """Batches whose planes are all of the xy kind (steep rays) run as k_reg_xy_coefs over the whole chip + one light
+    march per solve (upwind plane in LDS, or read back from memory when two planes do not fit): the same expressions
+    in the same order as the plane loop of k_regular_solve (xy_up_ray :191-278, xy_down_ray :288-372), so all three
+    forms agree bit for bit -- and with the oracle to 1e-12."""
+    nz, nx, ny = shape
+    z, x, y, S, al, I0 = _random_problem(nz, nx, ny, 21)
+    z = np.cumsum(0.2 + 0.05 * np.arange(nz)) * (x[1] - x[0])            # thin planes: every steep ray cuts xy first
+    angles = [(175.0, 30.0), (6.0, 200.0), (172.0, 300.0), (180.0, 0.0), (9.0, 100.0)]
+    ks = np.stack([vrt.direction(t, p) for t, p in angles])
+    ups = [t > 90 for t, _ in angles]
+    rng = np.random.default_rng(5)
+    I0s = rng.random((len(angles),) + I0.shape)
+    got = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("VRT_REG_XY", mode)
+        got[mode] = vrt.short_characteristics_batch(ks, ups, S, I0s, al, z, x, y, 3)
+    assert np.array_equal(got["0"], got["1"]) and np.array_equal(got["0"], got["2"])
+    for j in range(len(angles)):
+        f = orc.short_characteristics_up if ups[j] else orc.short_characteristics_down
+        ref, kinds = f(ks[j], S, I0s[j], al, z, x, y, 3, return_planes=True)
+        assert {int(c) for c in kinds if c} == {1}
+        assert np.abs(got["1"][j] - ref).max() / np.abs(ref).max() < 1e-12
+
+
 # ---- analytic known answers that follow from the code (no reference run needed) ---------------------
 _KAT_ANGLES = ((170.0, 30.0), (100.0, 10.0), (100.0, 80.0), (10.0, 200.0), (80.0, 190.0), (80.0, 100.0))
 

@@ -501,7 +501,8 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
         // as a by-product -- the same analysis -- so build_layer_schedule itself only runs for an angle whose layers do not
         // fit the packed encoding (it then says so too; the level kernels take over).
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const int nthr = std::max(1, (int)std::min<unsigned>(std::min(hw, 16u), (unsigned)A));
+        // (all angles at once when the host has four threads for each: no second round with most threads idle)
+        const int nthr = std::max(1, (int)std::min<unsigned>(std::min(hw, (unsigned)A * 4u <= hw ? 64u : 16u), (unsigned)A));
         const int sub_threads = (int)std::max(1u, std::min(16u, hw / (unsigned)nthr));
         std::atomic<int> next_job(0);
         // (every schedule build holds a visit trace of up to n_sweeps n entries and a dozen n-sized arrays)

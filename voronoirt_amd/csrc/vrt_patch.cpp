@@ -351,23 +351,39 @@ void build_patch_schedule(const Direction &dir, bool ascending, int64_t n, int n
     std::vector<int32_t> owner((size_t)n, -1);       // storage position -> patch
     for (int32_t q = 0; q < patch_id; q++)
         for (int32_t j = 0; j < out.patch_own_cnt[(size_t)q]; j++) owner[(size_t)(out.patch_own_lo[(size_t)q] + j)] = q;
-    out.dep_off.push_back(0);
-    std::vector<int32_t> deps;
-    int64_t layer = first;
-    for (int32_t q = 0; q < patch_id; q++) {
-        while (layer < last && q >= out.layer_patch_off[(size_t)layer + 1]) layer++;
-        deps.clear();
-        for (int64_t e = out.patch_ent_off[(size_t)q]; e < out.patch_ent_off[(size_t)q + 1]; e++) {
-            const int32_t i = dir.store[(size_t)out.entry_pos[(size_t)e]];
-            for (int qq = 0; qq < 2; qq++) {
-                const int32_t u = qq == 0 ? up1[i] : up2[i];
-                if (dir.layer_of[(size_t)u] < layer && owner[(size_t)pos_of[(size_t)u]] >= 0) deps.push_back(owner[(size_t)pos_of[(size_t)u]]);
+    // (patches are independent here too: contiguous ranges of them per thread, concatenated in patch order)
+    const int dthr = (int)std::max<int64_t>(1, std::min<int64_t>(threads, patch_id / 256 + 1));
+    std::vector<std::vector<int32_t>> part_list((size_t)dthr);
+    std::vector<std::vector<int32_t>> part_cnt((size_t)dthr);
+    auto dep_worker = [&](int t) {
+        const int32_t q0 = (int32_t)((int64_t)patch_id * t / dthr), q1 = (int32_t)((int64_t)patch_id * (t + 1) / dthr);
+        std::vector<int32_t> deps;
+        std::vector<int32_t> &list = part_list[(size_t)t], &cnt = part_cnt[(size_t)t];
+        cnt.reserve((size_t)(q1 - q0));
+        int64_t layer = first;
+        for (int32_t q = q0; q < q1; q++) {
+            while (layer < last && q >= out.layer_patch_off[(size_t)layer + 1]) layer++;
+            deps.clear();
+            for (int64_t e = out.patch_ent_off[(size_t)q]; e < out.patch_ent_off[(size_t)q + 1]; e++) {
+                const int32_t i = dir.store[(size_t)out.entry_pos[(size_t)e]];
+                for (int qq = 0; qq < 2; qq++) {
+                    const int32_t u = qq == 0 ? up1[i] : up2[i];
+                    if (dir.layer_of[(size_t)u] < layer && owner[(size_t)pos_of[(size_t)u]] >= 0) deps.push_back(owner[(size_t)pos_of[(size_t)u]]);
+                }
             }
+            std::sort(deps.begin(), deps.end());
+            deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
+            list.insert(list.end(), deps.begin(), deps.end());
+            cnt.push_back((int32_t)deps.size());
         }
-        std::sort(deps.begin(), deps.end());
-        deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
-        out.dep_list.insert(out.dep_list.end(), deps.begin(), deps.end());
-        out.dep_off.push_back((int64_t)out.dep_list.size());
+    };
+    if (dthr <= 1) dep_worker(0);
+    else if (!run_workers(dthr, dep_worker)) throw std::bad_alloc();
+    out.dep_off.reserve((size_t)patch_id + 1);
+    out.dep_off.push_back(0);
+    for (int t = 0; t < dthr; t++) {
+        for (int32_t c : part_cnt[(size_t)t]) out.dep_off.push_back(out.dep_off.back() + c);
+        out.dep_list.insert(out.dep_list.end(), part_list[(size_t)t].begin(), part_list[(size_t)t].end());
     }
 }
 

@@ -77,6 +77,27 @@ __device__ __forceinline__ double reg_bilinear(double xm, double ym, double x1, 
     return ((y2 - ym) * f1 + (ym - y1) * f2) / dy;
 }
 
+// n / d given r = 1.0 / d (correctly rounded): the quotient estimate n r, its exact residual, one correction -- three
+// instructions that return the correctly rounded quotient (Markstein's theorem; checked against IEEE division on 3e5
+// random and grid-like operand pairs), where the division itself is a dozen: k_reg_xy_march runs ONE compute unit
+// per solve at the fp64 rate and is bound by exactly these.  (Not for d = 0 or results near the over/underflow limits.)
+__device__ __forceinline__ double reg_div(double n, double d, double r)
+{
+    const double q0 = n * r;
+    const double e = fma(-q0, d, n);
+    return fma(e, r, q0);
+}
+
+// reg_bilinear with the three divisions done by reg_div: bit-identical results
+__device__ __forceinline__ double reg_bilinear_div(double xm, double ym, double x1, double x2, double y1, double y2,
+                                                   double rdx, double rdy, double Q11, double Q12, double Q21, double Q22)
+{
+    const double dx = x2 - x1, dy = y2 - y1;
+    const double f1 = reg_div((x2 - xm) * Q11 + (xm - x1) * Q21, dx, rdx);
+    const double f2 = reg_div((x2 - xm) * Q12 + (xm - x1) * Q22, dx, rdx);
+    return reg_div((y2 - ym) * f1 + (ym - y1) * f2, dy, rdy);
+}
+
 // the same interpolation with the two interval lengths inverted once per plane and thread: the
 // row march is a dependent chain per row, and an fp64 division costs as much as the rest of a step.
 // Differs from reg_bilinear in the last bits only (parity contract of the regular solver: 1e-12).
@@ -418,6 +439,306 @@ k_regular_solve(RegArgs ra)
     }
 }
 
+// ---- batches whose planes are all of the xy kind (steep rays: every plane point-parallel) --------------------------
+// The march through the planes is a dependent chain, but only through I: of a point's update
+//     I_c = (e I_u + a S_u) + b S_c                      (xy_up_ray :263 / xy_down_ray :357)
+// the interpolated upwind opacity and source function, Δτ, linear_weights and with them e, a S_u and b S_c depend
+// on the fields alone.  k_reg_xy_coefs forms those three numbers for every point of every plane of every solve at
+// once (grid = tiles x planes x solves: the whole chip), k_reg_xy_march then walks the planes of a solve with one
+// workgroup whose step is four LDS reads of the upwind plane (kept in LDS with its ghost zones, double-buffered),
+// the bilinear interpolation, two multiply-adds and ONE barrier; the coefficients of the next plane are already in
+// flight (the barrier waits for LDS only).  Same expressions in the same order as the plane loop of
+// k_regular_solve, so the results are identical to its bit for bit.
+__global__ void __launch_bounds__(256)
+k_reg_xy_coefs(RegArgs ra, double *__restrict__ xy, int64_t solve0)
+{
+    const int nz = ra.nz, nx = ra.nx, ny = ra.ny;
+    const int64_t solve = solve0 + blockIdx.z;
+    const int s = 1 + (int)blockIdx.y;
+    const int mx = nx - 2, my = ny - 2;
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= mx * my) return;
+    const double k0 = ra.k[3 * solve], k1 = ra.k[3 * solve + 1], k2 = ra.k[3 * solve + 2];
+    const bool up = ra.up[solve] != 0;
+    const int64_t plane = (int64_t)nx * ny;
+    const int64_t field = ra.field_period > 0 ? solve % ra.field_period : solve;
+    const double *S = ra.S + field * ra.S_stride, *Al = ra.alpha + field * ra.A_stride;
+    const double *x = ra.x, *y = ra.y, *z = ra.z;
+    int sign_x, sign_y;                                           // xy_intersect, functions.jl:430-457
+    if (k1 > 0 && k2 > 0) { sign_x = -1; sign_y = -1; }
+    else if (k1 < 0 && k2 > 0) { sign_x = 1; sign_y = -1; }
+    else if (k1 < 0 && k2 < 0) { sign_x = 1; sign_y = 1; }
+    else if (k1 > 0 && k2 < 0) { sign_x = -1; sign_y = 1; }
+    else { sign_x = 1; sign_y = 1; }
+    const int hx = (sign_x + 1) / 2, hy = (sign_y + 1) / 2;
+    const int idz = up ? s : nz - 1 - s, idz_u = up ? idz - 1 : idz + 1;
+    const double *Sc = S + (int64_t)idz * plane, *Su = S + (int64_t)idz_u * plane;
+    const double *Ac = Al + (int64_t)idz * plane, *Au = Al + (int64_t)idz_u * plane;
+    const double r = fabs((z[idz_u] - z[idz]) / k0);
+    const double x_inc = r * k1, y_inc = r * k2;
+    const int idx = 1 + t % mx, idy = 1 + t / mx;
+    const int xl = idx - hx, xu = xl + 1, yl = idy - hy, yu = yl + 1;
+    const double x_up = x[idx] + x_inc, y_up = y[idy] + y_inc;
+    const double a_u = reg_bilinear(x_up, y_up, x[xl], x[xu], y[yl], y[yu], PL(Au, xl, yl), PL(Au, xl, yu), PL(Au, xu, yl),
+                                    PL(Au, xu, yu));
+    const double dtau = r * (PL(Ac, idx, idy) + a_u) / 2.0;
+    const double S_u = reg_bilinear(x_up, y_up, x[xl], x[xu], y[yl], y[yu], PL(Su, xl, yl), PL(Su, xl, yu), PL(Su, xu, yl),
+                                    PL(Su, xu, yu));
+    double a, b, e;
+    reg_linear_weights(dtau, a, b, e);
+    double *c = xy + ((int64_t)blockIdx.z * nz + idz) * 3 * plane + (idx + nx * idy);
+    c[0] = e;
+    c[plane] = a * S_u;
+    c[2 * plane] = b * PL(Sc, idx, idy);
+}
+
+typedef unsigned int reg_u32x2 __attribute__((ext_vector_type(2)));
+
+// The march with the upwind plane read back from memory: the fallback for planes of which two do not fit LDS.
+__global__ void __launch_bounds__(1024)
+k_reg_xy_march_mem(RegArgs ra, const double *__restrict__ xy, int64_t solve0)
+{
+    const int nz = ra.nz, nx = ra.nx, ny = ra.ny;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int64_t solve = solve0 + blockIdx.x;
+    const int64_t plane = (int64_t)nx * ny;
+    const double k0 = ra.k[3 * solve], k1 = ra.k[3 * solve + 1], k2 = ra.k[3 * solve + 2];
+    const bool up = ra.up[solve] != 0;
+    double *I = ra.I + solve * plane * nz;
+    const double *cf = xy + (int64_t)blockIdx.x * nz * 3 * plane;
+    const double *x = ra.x, *y = ra.y, *z = ra.z;
+    int sign_x, sign_y;
+    if (k1 > 0 && k2 > 0) { sign_x = -1; sign_y = -1; }
+    else if (k1 < 0 && k2 > 0) { sign_x = 1; sign_y = -1; }
+    else if (k1 < 0 && k2 < 0) { sign_x = 1; sign_y = 1; }
+    else if (k1 > 0 && k2 < 0) { sign_x = -1; sign_y = 1; }
+    else { sign_x = 1; sign_y = 1; }
+    const int hx = (sign_x + 1) / 2, hy = (sign_y + 1) / 2;
+    const int mx = nx - 2, my = ny - 2;
+    {                                                             // boundary plane: I[1,:,:] = I_0 (:61) / I[end,:,:] = I_0 (:146)
+        double *Ib = I + (int64_t)(up ? 0 : nz - 1) * plane;
+        const double *I0 = ra.I0 + solve * plane;
+        for (int64_t t = tid; t < plane; t += T) Ib[t] = I0[t];
+    }
+    __syncthreads();
+    for (int s = 1; s < nz; s++) {
+        const int idz = up ? s : nz - 1 - s, idz_u = up ? idz - 1 : idz + 1;
+        const double r = fabs((z[idz_u] - z[idz]) / k0);
+        const double x_inc = r * k1, y_inc = r * k2;
+        double *Ic = I + (int64_t)idz * plane;
+        const double *Ip = I + (int64_t)idz_u * plane;
+        const double *cz = cf + (int64_t)idz * 3 * plane;
+        for (int t = tid; t < mx * my; t += T) {
+            const int iy = t / mx, idx = 1 + t - mx * iy, idy = 1 + iy;
+            const int xl = idx - hx, xu = xl + 1, yl = idy - hy, yu = yl + 1;
+            const double x_up = x[idx] + x_inc, y_up = y[idy] + y_inc;
+            const double I_u = reg_bilinear(x_up, y_up, x[xl], x[xu], y[yl], y[yu], PL(Ip, xl, yl), PL(Ip, xl, yu),
+                                            PL(Ip, xu, yl), PL(Ip, xu, yu));
+            const int64_t o = idx + (int64_t)nx * idy;
+            PL(Ic, idx, idy) = (cz[o] * I_u + cz[plane + o]) + cz[2 * plane + o];
+        }
+        __syncthreads();
+        for (int idx = 1 + tid; idx <= nx - 2; idx += T) {        // y ghost zones :270-271
+            PL(Ic, idx, 0) = PL(Ic, idx, ny - 2);
+            PL(Ic, idx, ny - 1) = PL(Ic, idx, 1);
+        }
+        __syncthreads();
+        for (int idy = tid; idy < ny; idy += T) {                 // x ghost zones :274-275
+            PL(Ic, 0, idy) = PL(Ic, nx - 2, idy);
+            PL(Ic, nx - 1, idy) = PL(Ic, 1, idy);
+        }
+        __syncthreads();
+    }
+}
+
+// The march with the upwind plane in LDS.  One workgroup = one compute unit runs a solve, so the march is bound by
+// the instructions it issues per point; everything that does not depend on the point is kept out of its way:
+//  * of the bilinear interpolation (functions.jl:332-355) the differences (x2 - xm), (xm - x1) depend on (ix, plane)
+//    only and dx on ix only (the same in y): 1-D tables in LDS, those of the next plane written during this one;
+//    the three divisions are reg_div's three instructions;
+//  * the planes in LDS hold no ghost zones: a read that falls on one goes to the interior point it mirrors
+//    (:270-275; only one side per axis can, the upwind one) -- except in the first step, whose upwind plane is the
+//    caller's I_0 with whatever its ghost zones hold (:61, :146);
+//  * a finished plane goes to memory one step later, whole and coalesced, ghost zones filled on the way;
+//  * the coefficients of the next plane are loaded (buffer loads: one offset register per point) BEFORE this plane's
+//    stores are issued and the barrier waits for LDS only, so no wait in the loop ever waits for a store.
+// NPT > 0: that many points per thread with their coefficients in registers; NPT = 0: any number, loaded where used.
+// LDS (doubles): 2 planes | x, y | (dx, 1/dx) by ix_lower, (dy, 1/dy) | 2 x (x2-xm, xm-x1) by ix, 2 x the same in y | z
+template <int NPT>
+__global__ void __launch_bounds__(1024)
+k_reg_xy_march_lds(RegArgs ra, const double *__restrict__ xy, int64_t solve0)
+{
+    extern __shared__ __attribute__((aligned(16))) double pl[];
+    constexpr int NP = NPT > 0 ? NPT : 1;
+    const int nz = ra.nz, nx = ra.nx, ny = ra.ny;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int64_t solve = solve0 + blockIdx.x;
+    const int plane = nx * ny;
+    int po = 0, co = plane;                                            // offsets of the upwind / the new plane in pl
+    double *ax = pl + 2 * plane, *ay = ax + nx;
+    const int lead = 2 * plane + nx + ny;
+    double2 *dxr = (double2 *)(pl + lead + (lead & 1)), *dyr = dxr + nx;   // (padded to 16 bytes; the host's lds_m too)
+    double2 *wxa = dyr + ny, *wya = wxa + 2 * nx;
+    double *az = (double *)(wya + 2 * ny);
+    const double k0 = ra.k[3 * solve], k1 = ra.k[3 * solve + 1], k2 = ra.k[3 * solve + 2];
+    const bool up = ra.up[solve] != 0;
+    double *I = ra.I + solve * plane * nz;
+    const double *cf = xy + (int64_t)blockIdx.x * nz * 3 * plane;
+    int sign_x, sign_y;
+    if (k1 > 0 && k2 > 0) { sign_x = -1; sign_y = -1; }
+    else if (k1 < 0 && k2 > 0) { sign_x = 1; sign_y = -1; }
+    else if (k1 < 0 && k2 < 0) { sign_x = 1; sign_y = 1; }
+    else if (k1 > 0 && k2 < 0) { sign_x = -1; sign_y = 1; }
+    else { sign_x = 1; sign_y = 1; }
+    const int hx = (sign_x + 1) / 2, hy = (sign_y + 1) / 2;
+    const int mx = nx - 2, my = ny - 2;
+    for (int t = tid; t < nx; t += T) {
+        ax[t] = ra.x[t];
+        if (t + 1 < nx) {
+            const double d = ra.x[t + 1] - ra.x[t];
+            dxr[t] = make_double2(d, 1.0 / d);
+        }
+    }
+    for (int t = tid; t < ny; t += T) {
+        ay[t] = ra.y[t];
+        if (t + 1 < ny) {
+            const double d = ra.y[t + 1] - ra.y[t];
+            dyr[t] = make_double2(d, 1.0 / d);
+        }
+    }
+    for (int t = tid; t < nz; t += T) az[t] = ra.z[t];
+    {                                                             // boundary plane: I[1,:,:] = I_0 (:61) / I[end,:,:] = I_0 (:146)
+        double *Ib = I + (int64_t)(up ? 0 : nz - 1) * plane;
+        const double *I0 = ra.I0 + solve * plane;
+        for (int t = tid; t < plane; t += T) {
+            const double v = I0[t];
+            Ib[t] = v;
+            pl[po + t] = v;
+        }
+    }
+    __syncthreads();
+    // the interpolation weights of plane step s into table half (s & 1)
+    auto weights = [&](int s) {
+        const int idz = up ? s : nz - 1 - s, idz_u = up ? idz - 1 : idz + 1;
+        const double r = fabs((az[idz_u] - az[idz]) / k0);
+        const double x_inc = r * k1, y_inc = r * k2;
+        for (int t = tid; t < mx + my; t += T) {
+            if (t < mx) {
+                const int idx = 1 + t, xl = idx - hx;
+                const double x_up = ax[idx] + x_inc;
+                wxa[(s & 1) * nx + idx] = make_double2(ax[xl + 1] - x_up, x_up - ax[xl]);
+            } else {
+                const int idy = 1 + t - mx, yl = idy - hy;
+                const double y_up = ay[idy] + y_inc;
+                wya[(s & 1) * ny + idy] = make_double2(ay[yl + 1] - y_up, y_up - ay[yl]);
+            }
+        }
+    };
+    int pt[NP];                                                   // ix | iy << 16; -1: none
+    int cs[NP + 1];                                               // copy-out: LDS source of plane element tid + j T; -1: none
+    if (NPT > 0) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const int t = tid + j * T;
+            pt[j] = t < mx * my ? (1 + t % mx) | ((1 + t / mx) << 16) : -1;          // (nx, ny <= 16384)
+        }
+#pragma unroll
+        for (int j = 0; j < NP + 1; j++) {
+            const int t = tid + j * T;
+            const int iy = t / nx, ix = t - nx * iy;
+            const int sx = ix == 0 ? nx - 2 : ix == nx - 1 ? 1 : ix, sy = iy == 0 ? ny - 2 : iy == ny - 1 ? 1 : iy;
+            cs[j] = t < plane ? sx + nx * sy : -1;
+        }
+    }
+    double ce[NP], caS[NP], cbS[NP], ne[NP], naS[NP], nbS[NP];
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(cf), 0, __builtin_amdgcn_readfirstlane((int)((unsigned)nz * 3u * (unsigned)plane * 8u)), 0x00020000);
+    auto fetch = [&](int s, double (&e_)[NP], double (&aS_)[NP], double (&bS_)[NP]) {
+        const int idz = up ? s : nz - 1 - s;
+        const int so = __builtin_amdgcn_readfirstlane(idz * 3 * plane * 8), sp = __builtin_amdgcn_readfirstlane(plane * 8);
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            if (pt[j] >= 0) {
+                const int o = ((pt[j] & 0xFFFF) + nx * (pt[j] >> 16)) * 8;
+                reg_u32x2 v0 = __builtin_amdgcn_raw_buffer_load_b64(crs, o, so, 0);
+                reg_u32x2 v1 = __builtin_amdgcn_raw_buffer_load_b64(crs, o, so + sp, 0);
+                reg_u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(crs, o, so + 2 * sp, 0);
+                __builtin_memcpy(&e_[j], &v0, 8);
+                __builtin_memcpy(&aS_[j], &v1, 8);
+                __builtin_memcpy(&bS_[j], &v2, 8);
+            }
+    };
+    if (NPT > 0) fetch(1, ce, caS, cbS);
+    weights(1);
+    __syncthreads();
+    for (int s = 1; s < nz; s++) {
+        const int idz = up ? s : nz - 1 - s, idz_u = up ? idz - 1 : idz + 1;
+        if (NPT > 0 && s + 1 < nz) fetch(s + 1, ne, naS, nbS);
+        if (s > 1) {                                              // the plane of the previous step to memory, ghost zones filled
+            double *Iu = I + (int64_t)idz_u * plane;
+            if (NPT > 0) {
+#pragma unroll
+                for (int j = 0; j < NP + 1; j++)
+                    if (cs[j] >= 0) Iu[tid + j * T] = pl[po + cs[j]];
+            } else {
+                for (int t = tid; t < plane; t += T) {
+                    const int iy = t / nx, ix = t - nx * iy;
+                    const int sx = ix == 0 ? nx - 2 : ix == nx - 1 ? 1 : ix, sy = iy == 0 ? ny - 2 : iy == ny - 1 ? 1 : iy;
+                    Iu[t] = pl[po + sx + nx * sy];
+                }
+            }
+        }
+        if (s + 1 < nz) weights(s + 1);
+        const bool wrap = s > 1;                                  // (step 1 reads the caller's I_0, ghost zones as given)
+        const double2 *wxs = wxa + (s & 1) * nx, *wys = wya + (s & 1) * ny;
+        const double *cz = cf + (int64_t)idz * 3 * plane;
+        auto point = [&](int idx, int idy, double e_, double aS_, double bS_) {
+            const int xl = idx - hx, yl = idy - hy;
+            int xa = xl, xb = xl + 1, ya = yl, yb = yl + 1;       // where the four upwind values are read
+            if (wrap) {
+                if (hx) xa = xa == 0 ? nx - 2 : xa; else xb = xb == nx - 1 ? 1 : xb;
+                if (hy) ya = ya == 0 ? ny - 2 : ya; else yb = yb == ny - 1 ? 1 : yb;
+            }
+            const double2 wx = wxs[idx], wy = wys[idy], dx = dxr[xl], dy = dyr[yl];
+            const double *P = pl + po;
+            const double Q11 = P[xa + nx * ya], Q12 = P[xa + nx * yb], Q21 = P[xb + nx * ya], Q22 = P[xb + nx * yb];
+            const double f1 = reg_div(wx.x * Q11 + wx.y * Q21, dx.x, dx.y);          // reg_bilinear's expressions
+            const double f2 = reg_div(wx.x * Q12 + wx.y * Q22, dx.x, dx.y);
+            const double I_u = reg_div(wy.x * f1 + wy.y * f2, dy.x, dy.y);
+            pl[co + idx + nx * idy] = (e_ * I_u + aS_) + bS_;
+        };
+        if (NPT > 0) {
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                int pj = pt[j];
+                asm volatile("" : "+v"(pj));                      // (indices and LDS offsets re-derived per plane, not kept per point)
+                if (pj >= 0) point(pj & 0xFFFF, pj >> 16, ce[j], caS[j], cbS[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                ce[j] = ne[j]; caS[j] = naS[j]; cbS[j] = nbS[j];
+            }
+        } else {
+#pragma unroll 1
+            for (int t = tid; t < mx * my; t += T) {
+                const int iy = t / mx, idx = 1 + t - mx * iy, p = idx + nx * (1 + iy);
+                point(idx, 1 + iy, cz[p], cz[plane + p], cz[2 * plane + p]);
+            }
+        }
+        // the planes talk through LDS only: wait for the LDS writes, not for the loads and stores in flight
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int t_ = po; po = co; co = t_;
+    }
+    if (nz > 1) {                                                 // the last plane
+        double *Il = I + (int64_t)(up ? nz - 1 : 0) * plane;
+        for (int t = tid; t < plane; t += T) {
+            const int iy = t / nx, ix = t - nx * iy;
+            const int sx = ix == 0 ? nx - 2 : ix == nx - 1 ? 1 : ix, sy = iy == 0 ? ny - 2 : iy == ny - 1 ? 1 : iy;
+            Il[t] = pl[po + sx + nx * sy];
+        }
+    }
+}
+
 #undef PL
 
 }  // namespace vrt
@@ -430,19 +751,21 @@ struct vrt_regular {
     int64_t nz = 0, nx = 0, ny = 0;
     double *d_g = nullptr;                 // z | x | y
     std::vector<double> h_g;               // the same on the host (launch geometry)
-    double *d_S = nullptr, *d_A = nullptr, *d_I = nullptr, *d_k = nullptr, *d_coef = nullptr;
+    double *d_S = nullptr, *d_A = nullptr, *d_I = nullptr, *d_k = nullptr, *d_coef = nullptr, *d_xy = nullptr;
     int *d_up = nullptr;
-    int64_t cap_S = 0, cap_A = 0, cap_I = 0, cap_k = 0, cap_coef = 0;      // in solves
+    int64_t cap_S = 0, cap_A = 0, cap_I = 0, cap_k = 0, cap_coef = 0, cap_xy = 0;      // in solves
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timed = false;
     int force_threads = 0;                 // VRT_REG_THREADS, read once at creation (tests: forces the launch shape)
+    int xy_split = 1;                      // VRT_REG_XY (creation): 0 = all-xy batches through k_regular_solve too;
+                                           //   2 = split, upwind plane read from memory instead of LDS (tests)
 };
 
 static void regular_free(vrt_regular *r)
 {
     if (!r) return;
     for (void *p : {(void *)r->d_g, (void *)r->d_S, (void *)r->d_A, (void *)r->d_I, (void *)r->d_k, (void *)r->d_up,
-                    (void *)r->d_coef})
+                    (void *)r->d_coef, (void *)r->d_xy})
         if (p) (void)hipFree(p);
     for (hipEvent_t e : r->ev)
         if (e) (void)hipEventDestroy(e);
@@ -463,6 +786,7 @@ extern "C" int vrt_regular_create(int64_t nz, int64_t nx, int64_t ny, const doub
     VRT_HIP_TRY(hipSetDevice(device));
     vrt_regular *r = new vrt_regular;
     if (const char *e = std::getenv("VRT_REG_THREADS")) r->force_threads = std::max(64, std::min(1024, std::atoi(e) / 64 * 64));
+    if (const char *e = std::getenv("VRT_REG_XY")) r->xy_split = std::max(0, std::min(2, std::atoi(e)));
     r->device = device;
     r->nz = nz; r->nx = nx; r->ny = ny;
     r->h_g.assign(z, z + nz);
@@ -559,9 +883,9 @@ extern "C" int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const do
     // A batch too small to fill the chip whose rays are all steep enough to cut the horizontal plane
     // first (every plane point-parallel: the searchlight / emergent-intensity case, θ = 180°) spends
     // its threads on the plane loops instead: up to 1024 per solve (60³: 1.46 -> 0.73 ms per solve)
+    bool all_xy = true;
     {
         const double *hz = r->h_g.data(), *hx = hz + nz, *hy = hx + nx;
-        bool all_xy = true;
         for (int64_t s = 0; s < n_solve && all_xy; s++) {
             const double *ks = k + 3 * s;
             const double r_x = std::fabs((hx[1] - hx[0]) / ks[1]), r_y = std::fabs((hy[1] - hy[0]) / ks[2]);
@@ -571,11 +895,45 @@ extern "C" int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const do
             }
         }
         if (all_xy)
-            while (threads < 1024 && n_solve * threads * 2 <= 256 * 1024 && (int64_t)threads * 2 <= (nx - 2) * (ny - 2))
+            while (threads * 2 <= 1024 && n_solve * threads * 2 <= 256 * 1024 && (int64_t)threads * 2 <= (nx - 2) * (ny - 2))
                 threads *= 2;
     }
     if (r->force_threads) threads = r->force_threads;
-    if (threads <= 256)
+    // Such a batch takes the split form (k_reg_xy_coefs over the whole chip + k_reg_xy_march, above)
+    const int64_t interior = (nx - 2) * (ny - 2);
+    int mt = (int)std::min<int64_t>(1024, (interior + 63) / 64 * 64);
+    if (r->force_threads) mt = r->force_threads;
+    const int npt = (int)((interior + mt - 1) / mt);
+    if (all_xy && r->xy_split && 24 * vol < ((int64_t)1 << 31)) {      // (a solve's coefficients: 32-bit byte offsets)
+        // coefficients: 3 doubles per point, plane and solve, in chunks of solves of at most 2 GiB
+        const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({n_solve, 65535, ((int64_t)1 << 31) / (24 * vol)}));
+        if ((rc = regular_grow(r->d_xy, r->cap_xy, chunk, (size_t)(3 * vol)))) return rc;
+        // LDS of the march: two planes, the axes and the weight tables (layout: k_reg_xy_march_lds); the planes
+        // padded to an even number of doubles so that the 16-byte tables behind them stay aligned
+        const size_t planes_d = 2 * (size_t)(nx * ny), lead_d = planes_d + (size_t)(nx + ny);
+        const size_t lds_m = sizeof(double) * (lead_d + (lead_d & 1) + (size_t)(6 * (nx + ny) + nz));
+        const bool in_lds = r->xy_split == 1 && lds_m <= 150 * 1024;
+#define VRT_XY_MARCH(N)                                                                                                 \
+    do {                                                                                                                \
+        if (lds_m > 48 * 1024)                                                                                          \
+            VRT_HIP_TRY(hipFuncSetAttribute((const void *)k_reg_xy_march_lds<N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)lds_m));                                                               \
+        hipLaunchKernelGGL((k_reg_xy_march_lds<N>), dim3((unsigned)cnt), dim3((unsigned)mt), lds_m, st, ra, r->d_xy, s0); \
+    } while (0)
+        // (registers hold NPT points and NPT + 1 elements of the copy to memory per thread)
+        const bool fits = nx * ny <= (int64_t)(npt <= 1 ? 2 : npt <= 2 ? 3 : 5) * mt;
+        for (int64_t s0 = 0; s0 < n_solve; s0 += chunk) {
+            const int64_t cnt = std::min(chunk, n_solve - s0);
+            hipLaunchKernelGGL(k_reg_xy_coefs, dim3((unsigned)((interior + 255) / 256), (unsigned)(nz - 1), (unsigned)cnt),
+                               dim3(256), 0, st, ra, r->d_xy, s0);
+            if (!in_lds) hipLaunchKernelGGL(k_reg_xy_march_mem, dim3((unsigned)cnt), dim3((unsigned)mt), 0, st, ra, r->d_xy, s0);
+            else if (npt <= 1 && fits) VRT_XY_MARCH(1);
+            else if (npt <= 2 && fits) VRT_XY_MARCH(2);
+            else if (npt <= 4 && fits) VRT_XY_MARCH(4);
+            else VRT_XY_MARCH(0);
+        }
+#undef VRT_XY_MARCH
+    } else if (threads <= 256)
         hipLaunchKernelGGL(k_regular_solve<256>, dim3((unsigned)n_solve), dim3((unsigned)threads), lds, st, ra);
     else
         hipLaunchKernelGGL(k_regular_solve<1024>, dim3((unsigned)n_solve), dim3((unsigned)threads), lds, st, ra);
