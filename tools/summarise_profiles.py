@@ -34,6 +34,32 @@ for r in csv.DictReader(open(stats_csv)):
         once = any(k in name for k in bench.ONE_TIME_KERNELS)
         ks[name] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                     "ms_per_step": float(r["TotalDurationNs"]) / 1e6 / (1 if once else steps_total)}
+# launches of the two sweep directions run concurrently on two streams: beside the SUM of a kernel's durations
+# (ms_per_step) give the wall time its dispatches cover (union of their intervals) and the queues they ran on
+trace = glob.glob(os.path.join(go, f"prof_{tag}_default", "**", "*kernel_trace.csv"), recursive=True)
+if trace:
+    spans = collections.defaultdict(list)
+    queues = collections.defaultdict(set)
+    for r in csv.DictReader(open(trace[0])):
+        if r["Kernel_Name"].startswith(("vrt::", "void vrt::")):
+            name = r["Kernel_Name"].split("(")[0]
+            spans[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+            queues[name].add(r["Queue_Id"])
+    for name, iv in spans.items():
+        if name not in ks:
+            continue
+        iv.sort()
+        covered, cur_lo, cur_hi = 0, iv[0][0], iv[0][1]
+        for lo, hi in iv[1:]:
+            if lo > cur_hi:
+                covered += cur_hi - cur_lo
+                cur_lo, cur_hi = lo, hi
+            else:
+                cur_hi = max(cur_hi, hi)
+        covered += cur_hi - cur_lo
+        once = any(k in name for k in bench.ONE_TIME_KERNELS)
+        ks[name]["covered_wall_ms_per_step"] = covered / 1e6 / (1 if once else steps_total)
+        ks[name]["queues"] = len(queues[name])
 pmc = collections.defaultdict(lambda: collections.defaultdict(float))
 for ctr in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_EA0_RDREQ_DRAM_sum"):
     for f in glob.glob(os.path.join(go, f"pmc_{tag}_default_{ctr}", "**", "*counter_collection.csv"), recursive=True):
@@ -63,7 +89,9 @@ summary = {
             "(tools/prof_pmc.sh), sums over all dispatches of a kernel, FETCH_SIZE / WRITE_SIZE in KiB; per "
             "MI355X_MICROARCH.md FETCH_SIZE tallies 128-B requests at 64 B on gfx950, so bytes = 2 x FETCH_SIZE + "
             "WRITE_SIZE.  The sweep runs on two internal streams, so launches of the two directions overlap and "
-            "their summed durations exceed the wall time of the sweep.",
+            "their summed durations (kernel_stats.*.ms_per_step) exceed the wall time of the sweep: "
+            "kernel_stats.*.covered_wall_ms_per_step is the union of a kernel's dispatch intervals per step and "
+            "`queues` the number of hardware queues they ran on.",
     "source_digest": bench.source_digest(),
     "alpha_layout": b["config"].get("alpha_layout"),
     "path": b["roofline"]["path"],

@@ -681,6 +681,13 @@ __device__ __forceinline__ void chain_publish(const int32_t *s_dep, int steps_do
 }
 
 // ---- one pair at a time within 64 registers: FOUR workgroups per CU ---------------------------------------------------
+// wave priority inside the level loop (s_setprio): the loop is a chain of barriers with a few instructions per wave
+// between them, while the compute unit's other workgroups run their arithmetic phases -- served first, a level costs
+// its own latency instead of its turn in the queue
+#ifndef VRT_LEVEL_PRIO
+#define VRT_LEVEL_PRIO 3
+#endif
+
 // No unit of the chip is saturated by the patch kernel; its phases (gathers, arithmetic, level loop) overlap only as
 // far as three 512-thread workgroups per CU allow (72 registers).  This form fits the 64 of a fourth: the three
 // alpha gathers first, the four optical depths from them (the alphas die), then the five S / I gathers in flight
@@ -788,6 +795,7 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
             if (bk > it.b0 && tid == 0) chain_publish(s_dep, bk - it.b0);   // ... in every wave: pairs b0 .. bk-1 are published
         }
         const int nlev = (kDiag && (dbg & 1)) ? 0 : it.nlev;
+        __builtin_amdgcn_s_setprio(VRT_LEVEL_PRIO);
         for (int t = 1; t <= nlev; t++) {
             if ((vis & 0xFFu) == (uint32_t)t) {                          // a site's visits come at increasing levels
                 const double2 xv = ptile[loc & 0xFFFFu], yv = ptile[loc >> 16];
@@ -799,6 +807,7 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
             }
             __syncthreads();
         }
+        __builtin_amdgcn_s_setprio(0);
         if (tid < it.own_cnt && !(kDiag && (dbg & 8) && ptile[tid].x != 1.2345e300)) {
             if (CHAIN && !(kDiag && (dbg & 1024))) {
                 const __amdgpu_buffer_rsrc_t rsI = plane_rsrc(Ia + qb, n << sh);
