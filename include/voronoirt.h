@@ -435,8 +435,14 @@ int vrt_short_characteristics(int64_t nz, int64_t nx, int64_t ny, const double *
  * device pointers in the layouts above, k and up stay on the host; asynchronous on `stream`.
  * field_period > 0: solve s reads the S / alpha array number s % field_period (solves ordered
  * direction-major with the wavelength fastest share one array per wavelength); 0: array s.
- * vrt_regular_last_solve_ms: HIP-event time of the last execute's solve kernel (synchronise first).
- * A handle serves one caller at a time (its workspaces are reused by every execute). */
+ * vrt_regular_last_solve_ms: HIP-event time of the last execute's solve kernel(s) (synchronise first).
+ * A handle serves one caller at a time (its workspaces are reused by every execute).
+ * A batch in which every ray cuts the horizontal plane first on every plane (steep rays: xy_up_ray / xy_down_ray
+ * only, src/characteristics.jl:72, :191-372) runs as a chip-wide coefficient kernel + one light march per solve,
+ * with 3 doubles per point, plane and solve of extra workspace (chunks of at most 2 GiB); results are bit-identical
+ * to the single kernel's.  Environment, read at vrt_regular_create (diagnostics and tests): VRT_REG_XY = 0 keeps the
+ * single kernel for such batches, 2 reads the upwind plane back from memory instead of LDS; VRT_REG_THREADS forces
+ * the workgroup size. */
 typedef struct vrt_regular vrt_regular;
 int vrt_regular_create(int64_t nz, int64_t nx, int64_t ny, const double *z, const double *x,
                        const double *y, int device, vrt_regular **out);
