@@ -105,7 +105,7 @@ static int alpha_to_native_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dal
         const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
         hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2 << native_lg(p, sizeof(T) == 4), dir.d_store,
                            dalpha + (size_t)p->user_of_active[(size_t)a] * (size_t)n * (size_t)ld,
-                           out + (size_t)a * plane);
+                           out + (size_t)a * plane, (const T *)nullptr, (T *)nullptr);
     }
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
@@ -267,7 +267,12 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     for (int d = 0; d < 2; d++)
         if (use_dir[d] && (rc = ensure_dev(p->ws_S[d], p->ws_S_cap[d], dcount(plane)))) return rc;
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
-    TileArgs ta;
+    // a handful of wavelengths in the pair layout: the narrow forms of the layout changes (vrt_layout_kernels.h)
+    const bool narrow = lb != 1 && nlam <= 16;
+    int narrow_lgP = 0;
+    while ((1 << narrow_lgP) < (int)((nlam + 1) / 2)) narrow_lgP++;
+    const unsigned narrow_blocks = (unsigned)((((int64_t)n << narrow_lgP) + 255) / 256);
+    TileArgs ta{};                                  // (zeroed, padding included: the chained launch compares argument blocks byte for byte)
     ta.n = n;
     ta.nlam = (int)nlam;
     ta.A = A;
@@ -318,18 +323,24 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         ta.alpha[d] = nullptr;
         if (!use_dir[d]) continue;
         hipStream_t st = dir_st[d];                 // (shadows the caller's stream inside this loop)
-        hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store, dS,
-                           reinterpret_cast<T *>(p->ws_S[d]));
+        const bool with_alpha = alpha_mode == VRT_ALPHA_SITE_LAM;           // S and α of the direction in ONE launch
+        if (with_alpha) {
+            if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], dcount(plane)))) return rc;
+            ta.alpha[d] = p->ws_A[d];
+        }
+        const T *in2 = with_alpha ? dalpha : nullptr;
+        T *out2 = with_alpha ? reinterpret_cast<T *>(p->ws_A[d]) : nullptr;
+        if (narrow)
+            hipLaunchKernelGGL(k_to_sweep_order_narrow<T>, dim3(narrow_blocks, with_alpha ? 2 : 1), dim3(256), 0, st, n, (int)nlam, ld,
+                               log2_pairs(lb), narrow_lgP, dir.d_store, dS, reinterpret_cast<T *>(p->ws_S[d]), in2, out2);
+        else
+            hipLaunchKernelGGL(k_to_sweep_order<T>, dim3(tgrid.x, tgrid.y, with_alpha ? 2 : 1), dim3(256), 0, st, n, (int)nlam, ld, lb,
+                               dir.d_store, dS, reinterpret_cast<T *>(p->ws_S[d]), in2, out2);
         ta.S[d] = p->ws_S[d];
         if (alpha_mode == VRT_ALPHA_SITE) {
             if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], dcount((size_t)n)))) return rc;
             hipLaunchKernelGGL(k_gather_vec<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
                                dir.d_store, dalpha, reinterpret_cast<T *>(p->ws_A[d]));
-            ta.alpha[d] = p->ws_A[d];
-        } else if (alpha_mode == VRT_ALPHA_SITE_LAM) {
-            if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], dcount(plane)))) return rc;
-            hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
-                               dalpha, reinterpret_cast<T *>(p->ws_A[d]));
             ta.alpha[d] = p->ws_A[d];
         }
         const int cnt = d == 0 ? p->n_up : p->n_down;
@@ -351,7 +362,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
             hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, dir_st[p->dir_of_active[(size_t)a] > 0 ? 0 : 1],
                                n, (int)nlam, ld, lb, dir.d_store, dalpha + (size_t)a * (size_t)n * (size_t)ld,
-                               reinterpret_cast<T *>(p->ws_AA) + (size_t)a * plane);
+                               reinterpret_cast<T *>(p->ws_AA) + (size_t)a * plane, (const T *)nullptr, (T *)nullptr);
         }
         ta.alpha_angle = p->ws_AA;
     }
@@ -413,7 +424,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         if (patches && (rc = ensure_patch_work(p, G, p->h_step_angles, p->step_group_off))) return rc;
         // J reduction riding along the patch launches: a stream that holds ALL angles of a direction forms
         // J_dir of layer l - 1 in its launch of layer l (the layer is final, its lines still cache-resident)
-        PatchReduce red_tmpl;
+        PatchReduce red_tmpl{};
         int owner_of_dir[2] = {-1, -1};
         int64_t reduced_upto[2] = {0, 0};
         if (patches && dJ) {
@@ -649,8 +660,12 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             hipLaunchKernelGGL(k_reduce_dir<T>, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st,
                                (int64_t)plane, (int64_t)plane, dw, wI, Jd[d]);
         }
-        hipLaunchKernelGGL(k_combine_J<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, g->up.d_store,
-                           g->down.d_srank, Jd[0], Jd[1], dJ);
+        if (narrow)
+            hipLaunchKernelGGL(k_combine_J_narrow<T>, dim3(narrow_blocks), dim3(256), 0, st, n, (int)nlam, ld, log2_pairs(lb), narrow_lgP,
+                               g->up.d_store, g->down.d_srank, Jd[0], Jd[1], dJ);
+        else
+            hipLaunchKernelGGL(k_combine_J<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, g->up.d_store,
+                               g->down.d_srank, Jd[0], Jd[1], dJ);
         VRT_HIP_TRY(hipGetLastError());
     }
     if (dI_out) {

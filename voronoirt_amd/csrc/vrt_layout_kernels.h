@@ -8,11 +8,16 @@
 namespace vrt {
 
 // out[l][p] = in[order[p]][l]   (caller's (nλ, n) site-major rows -> wavelength-major sweep order)
+// gridDim.z = 2: the second array pair (in2 -> out2: S and α of a direction in ONE launch) in the blocks with z = 1
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_to_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__restrict__ order,
-                 const T *__restrict__ in, T *__restrict__ out)
+                 const T *__restrict__ in, T *__restrict__ out, const T *__restrict__ in2 = nullptr, T *__restrict__ out2 = nullptr)
 {
+    if (blockIdx.z) {
+        in = in2;
+        out = out2;
+    }
     __shared__ T tile[64][65];
     __shared__ int32_t rows[64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -52,6 +57,29 @@ k_to_sweep_order(int64_t n, int nlam, int64_t ld, int lb, const int32_t *__restr
             }
         }
     }
+}
+
+// The same for a handful of wavelengths (nλ <= 16, pair layout): the 64-wavelength tile above would run with most of its
+// lanes idle (1 M sites x 7 λ: 100 µs; this form: one thread per (storage position, wavelength pair), a site's pairs in
+// neighbouring lanes).  lgP = log2 of the lanes per site (>= pairs)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_to_sweep_order_narrow(int64_t n, int nlam, int64_t ld, int lgB, int lgP, const int32_t *__restrict__ order,
+                        const T *__restrict__ in, T *__restrict__ out, const T *__restrict__ in2, T *__restrict__ out2)
+{
+    if (blockIdx.y) {
+        in = in2;
+        out = out2;
+    }
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pos = e >> lgP;
+    const int pr = (int)(e & ((1 << lgP) - 1)), npair = (nlam + 1) >> 1;
+    if (pos >= n || pr >= npair) return;
+    const T *row = in + (size_t)order[pos] * ld;
+    typename Pair<T>::type v2;
+    v2.x = row[2 * pr];
+    v2.y = 2 * pr + 1 < nlam ? row[2 * pr + 1] : (T)0;
+    reinterpret_cast<typename Pair<T>::type *>(out)[pair_index(pr, pos, n, lgB, npair)] = v2;
 }
 
 // out[p] = in[order[p]]   (per-site vector, e.g. wavelength-independent α)
@@ -168,6 +196,29 @@ k_combine_J(int64_t n, int nlam, int64_t ldJ, int lb, const int32_t *__restrict_
         const int64_t q = p0 + r;
         if (q < n && l0 + tx < nlam) J[(size_t)order_up[q] * ldJ + l0 + tx] = tile[r][tx];
     }
+}
+
+// k_combine_J for a handful of wavelengths (nλ <= 16, pair layout): one thread per (up position, wavelength pair)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_combine_J_narrow(int64_t n, int nlam, int64_t ldJ, int lgB, int lgP, const int32_t *__restrict__ order_up,
+                   const int32_t *__restrict__ rank_down, const T *__restrict__ Ju, const T *__restrict__ Jdn, T *__restrict__ J)
+{
+    typedef typename Pair<T>::type T2;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pos = e >> lgP;
+    const int pr = (int)(e & ((1 << lgP) - 1)), npair = (nlam + 1) >> 1;
+    if (pos >= n || pr >= npair) return;
+    const int32_t site = order_up[pos];
+    double2 v = make_double2(0.0, 0.0);
+    if (Ju) v = to_d2(reinterpret_cast<const T2 *>(Ju)[pair_index(pr, pos, n, lgB, npair)]);
+    if (Jdn) {
+        const double2 u = to_d2(reinterpret_cast<const T2 *>(Jdn)[pair_index(pr, rank_down[site], n, lgB, npair)]);
+        v.x = v.x + u.x; v.y = v.y + u.y;
+    }
+    T *row = J + (size_t)site * ldJ;
+    row[2 * pr] = (T)v.x;
+    if (2 * pr + 1 < nlam) row[2 * pr + 1] = (T)v.y;
 }
 
 // out[order[p]][l] = in[l][p]  (sweep order, wavelength-major -> caller's site-major rows)
