@@ -191,6 +191,10 @@ int vrt_plan_last_path(const vrt_plan *p);
  *                                              (default: where a layer alone cannot fill the chip)
  *   VRT_CHAIN_PAIRS, VRT_CHAIN_SPIN            wavelength-pair blocks per item of the chained launch at most (default 9); polls
  *                                              (x 1024) after which a waiting workgroup gives up (default 2048)
+ *   VRT_CHAIN_DATAFLAG = 0 | 1 | 2             chained launch, fp64: the stored intensities are their own flags (the planes are
+ *                                              filled with a NaN pattern before the launch; a gather that still holds it
+ *                                              is repeated) instead of progress words: never, always, auto (default: for
+ *                                              one or two wavelength pairs, where the fill is cheaper than the words)
  *   VRT_PATCH_QUAD = 0 | 1                     fp32 storage: four wavelengths per lane (creation only; default 1)
  *   VRT_PAIR_BLOCK = 1 | 2 | 4 | 8 | 16        wavelength pairs of a site side by side in the patch path's planes and
  *                                              in the plan's native alpha (creation only; default 1)

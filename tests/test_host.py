@@ -74,6 +74,11 @@ def test_default_patch_kernels_hold_their_register_budget(tmp_path):
     assert len(chain) == 3
     for k, v in chain.items():
         assert v["VGPRs"] <= 64 and v["ScratchSize [bytes/lane]"] == 0 and v["Occupancy [waves/SIMD]"] == 8, (k, v)
+    # its data-as-flag form (one or two wavelength pairs: the chip is far from full) trades two waves per SIMD for no scratch
+    df = {k: v for k, v in usage.items() if "k_patch_chain_dfId" in k and "Li512E" in k}
+    assert len(df) == 3
+    for k, v in df.items():
+        assert v["VGPRs"] <= 80 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
 
 
 def test_no_cpu_fallback(bcc_small):

@@ -75,24 +75,29 @@ def test_patches_J_matches_oracle_and_steps(grids, name, own, nlam, monkeypatch)
 @pytest.mark.parametrize("shape", [(1, 1, 256), (1, 1, 512), (1, 1, 1024), (2, 1, 256), (2, 1, 512), (1, 2, 256),
                                    (1, 2, 512), (1, 2, 1024), (2, 2, 512)])
 @pytest.mark.parametrize("f32", [False, True])
-@pytest.mark.parametrize("variant", ["plain", "lean", "chain", "block8", "block8-lean"])
+@pytest.mark.parametrize("variant", ["plain", "lean", "chain", "chain-df", "block8", "block8-lean"])
 def test_every_patch_kernel_instantiation(grids, shape, f32, variant, monkeypatch):
     """Every (entries per thread, wavelength pairs, threads) instantiation of k_patch_solve, fp64 and fp32
     storage: same results (fp64: to rounding; fp32: 5e-6 against the fp64 oracle on the rounded inputs).
     Variants: the 64-register kernel (VRT_PATCH_LEAN, the default of the (1, 1, NT) shapes; "plain" = the 72-register
     one) with one launch per layer, the chained launch (VRT_PATCH_CHAIN, the default: k_patch_chain; floats with an odd pair
-    count as here run the pair kernel inside it) and the storage layout with 8 wavelength pairs of a site side by
-    side (VRT_PAIR_BLOCK; 9 wavelengths = 5 pairs: blocks 4 + 1)."""
+    count as here run the pair kernel inside it; "chain-df": its hand-off by the intensities themselves, VRT_CHAIN_DATAFLAG,
+    fp64 only) and the storage layout with 8 wavelength pairs of a site side by side (VRT_PAIR_BLOCK; 9 wavelengths =
+    5 pairs: blocks 4 + 1)."""
     import torch
     hs, so = grids["voronoi"]
     K, Q, NT = shape
-    if ("lean" in variant or variant == "chain") and (K, Q) != (1, 1):
+    chain = variant.startswith("chain")
+    if ("lean" in variant or chain) and (K, Q) != (1, 1):
         pytest.skip("the 64-register kernel replaces the (1, 1, NT) shapes")
-    if variant == "chain" and NT != 512:
+    if chain and NT != 512:
         pytest.skip("the chained launch exists for 512-thread workgroups")
-    monkeypatch.setenv("VRT_PATCH_LEAN", "1" if ("lean" in variant or variant == "chain") else "0")
-    monkeypatch.setenv("VRT_PATCH_CHAIN", "1" if variant == "chain" else "0")
-    if variant == "chain" and f32:          # 5 pairs: floats in blocks of two pairs would need sibling workgroups (per-layer launches)
+    if variant == "chain-df" and f32:
+        pytest.skip("the data-as-flag hand-off exists for fp64 storage")
+    monkeypatch.setenv("VRT_PATCH_LEAN", "1" if ("lean" in variant or chain) else "0")
+    monkeypatch.setenv("VRT_PATCH_CHAIN", "1" if chain else "0")
+    monkeypatch.setenv("VRT_CHAIN_DATAFLAG", "1" if variant == "chain-df" else "0")
+    if chain and f32:          # 5 pairs: floats in blocks of two pairs would need sibling workgroups (per-layer launches)
         monkeypatch.setenv("VRT_PATCH_QUAD", "0")
     monkeypatch.setenv("VRT_PAIR_BLOCK", "8" if "block8" in variant else "4" if "block4" in variant else "1")
     monkeypatch.setenv("VRT_PATCH_K", str(K))
@@ -114,7 +119,7 @@ def test_every_patch_kernel_instantiation(grids, shape, f32, variant, monkeypatc
                      dI0_up=Ud.data_ptr(), dI0_down=Dd.data_ptr(), stream=st, f32=f32)
     torch.cuda.synchronize()
     assert plan.last_path == "patches"
-    assert (plan.last_launches == 1) == (variant == "chain")
+    assert (plan.last_launches == 1) == chain
     r = lambda x: x.astype(npdt).astype(np.float64)
     ref = orc.J_voronoi(w, th, ph, r(S), r(al), so, I0_up=r(I0u), I0_down=r(I0d), nthreads=4)
     assert _rel(Jd.cpu().numpy().astype(np.float64), ref) < (5e-6 if f32 else RTOL)
@@ -123,8 +128,8 @@ def test_every_patch_kernel_instantiation(grids, shape, f32, variant, monkeypatc
 
 @pytest.mark.parametrize("f32", [False, True])
 def test_kernel_variants_agree_bit_for_bit(grids, f32, monkeypatch):
-    """The chained launch (default), the 64-register kernel launched per layer and the 72-register one
-    evaluate the same expressions in the same order on the same values: J and the per-angle intensities are bitwise
+    """The chained launch (both hand-offs: progress words, and the intensities as their own flags), the 64-register
+    kernel launched per layer and the 72-register one evaluate the same expressions in the same order on the same values: J and the per-angle intensities are bitwise
     equal (fp32 storage, 16 wavelengths: the chained launch runs k_patch_quad's pair loop with VRT_PATCH_QUAD=1)."""
     import torch
     hs, so = grids["bcc"]
@@ -142,11 +147,12 @@ def test_kernel_variants_agree_bit_for_bit(grids, f32, monkeypatch):
     got = {}
     for name, env in (("lean", {"VRT_PATCH_LEAN": "1"}), ("plain", {"VRT_PATCH_LEAN": "0"}),
                       ("chain", {"VRT_PATCH_LEAN": "1", "VRT_PATCH_CHAIN": "1"}),
+                      ("chain-df", {"VRT_PATCH_LEAN": "1", "VRT_PATCH_CHAIN": "1", "VRT_CHAIN_DATAFLAG": "1"}),
                       ("chain-quad", {"VRT_PATCH_LEAN": "1", "VRT_PATCH_CHAIN": "1", "VRT_PATCH_QUAD": "1"}),
                       ("lean-quad", {"VRT_PATCH_LEAN": "1", "VRT_PATCH_QUAD": "1"})):
-        if "quad" in name and not f32:
+        if ("quad" in name and not f32) or (name == "chain-df" and f32):
             continue
-        for k in ("VRT_PATCH_LEAN", "VRT_PATCH_CHAIN", "VRT_PATCH_QUAD"):
+        for k in ("VRT_PATCH_LEAN", "VRT_PATCH_CHAIN", "VRT_PATCH_QUAD", "VRT_CHAIN_DATAFLAG"):
             monkeypatch.setenv(k, env.get(k, "0"))
         plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3, dirs=[1 if t > 90 else -1 for t in th])
         Jd = torch.full((n, nlam), float("nan"), dtype=dt, device=dev)

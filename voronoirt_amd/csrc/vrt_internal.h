@@ -135,6 +135,8 @@ struct Tuning {
                                   //   alone cannot fill the chip (patch_chain_possible)
     int chain_pairs = 9;          // VRT_CHAIN_PAIRS: wavelength-pair blocks an item of the chained launch solves at most
     int chain_spin = 2048;        // VRT_CHAIN_SPIN: polls (x 1024) after which a waiting workgroup gives up (~2 s)
+    int chain_dataflag = 2;       // VRT_CHAIN_DATAFLAG: the chained launch's intensities as their own flags: 0 never, 1 wherever
+                                  //   the kernel exists, 2 auto (one or two wavelength pairs: the planes are filled per step)
     int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
     int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)
 };
@@ -447,7 +449,9 @@ int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angl
 int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, int group, int Q, hipStream_t st,
                        bool f32, const PatchReduce *reduce);
 bool patch_chain_possible(const vrt_plan *p, int npair, bool f32);
-int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t st, bool f32, const PatchReduce *reduce);
+bool patch_chain_dataflag(const vrt_plan *p, int npair, bool f32);
+int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t st, bool f32, const PatchReduce *reduce,
+                       bool dataflag);
 int patch_chain_check(vrt_plan *p);
 
 }  // namespace vrt

@@ -263,6 +263,10 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     int rc;
     if ((rc = ensure_dev(p->d_I, p->I_cap, dcount((size_t)std::max(1, A) * plane)))) return rc;
     T *wI = reinterpret_cast<T *>(p->d_I);
+    // chained launch with the intensities as their own flags (vrt_patch.hip: chain_data_wait): every plane is filled with
+    // the NaN pattern first; the boundary kernel below then writes the boundary layer and the never-visited site's zero
+    const bool chain_df = patches && A > 0 && patch_chain_possible(p, (int)(nl_pad / 2), kF32) && patch_chain_dataflag(p, (int)(nl_pad / 2), kF32);
+    if (chain_df) VRT_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p->d_I, (int)0x7FF87FF8u, (size_t)A * plane * sizeof(T) / 4, st));
     const bool use_dir[2] = {p->n_up > 0, p->n_down > 0};
     for (int d = 0; d < 2; d++)
         if (use_dir[d] && (rc = ensure_dev(p->ws_S[d], p->ws_S_cap[d], dcount(plane)))) return rc;
@@ -486,7 +490,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                         if ((p->dir_of_active[(size_t)a] > 0) == (d == 0)) red.angles[d][red.count[d]++] = a;
                     fused_dir[d] = use_dir[d];
                 }
-            if ((rc = launch_patch_chain(p, sa.ta, npair, st, kF32, dJ ? &red : nullptr))) return rc;
+            if ((rc = launch_patch_chain(p, sa.ta, npair, st, kF32, dJ ? &red : nullptr, chain_df))) return rc;
             launches = 1;
             VRT_HIP_TRY(hipEventRecord(p->ev1, st));
         } else {

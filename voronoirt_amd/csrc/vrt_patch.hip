@@ -574,7 +574,7 @@ struct ChainDev;
 // LDS words of the chained launch behind the entry table; then 64 + kChainDepLds dependency slots (patch indices, padded
 // with the item's own patch up to a multiple of 64: every lane of a poll has a word it may load)
 constexpr int kCtlItem = 0, kCtlSelf = 1, kCtlNdep = 2, kCtlDepOff = 3, kCtlArgsLo = 4, kCtlArgsHi = 5, kCtlProgLo = 6, kCtlProgHi = 7,
-              kCtlBase = 8, kCtlWords = 12;
+              kCtlBase = 8, kCtlGaveUp = 9, kCtlWords = 12;
 template <int CAP>
 __device__ __forceinline__ uint32_t *chain_ctl_slots(const EntryTable<CAP> &tab) { return tab.loc + CAP; }
 template <int CAP>
@@ -692,12 +692,50 @@ __device__ __forceinline__ void chain_publish(const int32_t *s_dep, int steps_do
 // far as three 512-thread workgroups per CU allow (72 registers).  This form fits the 64 of a fourth: the three
 // alpha gathers first, the four optical depths from them (the alphas die), then the five S / I gathers in flight
 // while the weights are evaluated one after the other, each folded into its share of the visit as soon as it exists.
+// ---- the chained launch's second hand-off: the intensity IS the flag (small pair counts) -----------------------------
+// Before the launch the intensity planes are filled with kChainSentinel in every 32-bit word (a quiet NaN as a double
+// and as a float; the boundary layer and the never-visited site's zero are written behind the fill).  A patch stores
+// its intensities write-through as before and publishes nothing; a gather that still holds the pattern is repeated.
+// What the progress words cost per layer of the chain -- the drain of the stores, the barrier, the publishing store,
+// the consumer's poll and only then its gathers: two round trips through the fabric -- becomes one.  The fill is
+// 16 bytes per (site, angle, pair) per step, so this form is chosen for one or two pairs only (VRT_CHAIN_DATAFLAG).
+constexpr uint32_t kChainSentinel = 0x7FF87FF8u;
+__device__ __forceinline__ bool chain_is_sentinel(double2 v)
+{
+    return (uint32_t)__double2hiint(v.x) == kChainSentinel || (uint32_t)__double2hiint(v.y) == kChainSentinel;
+}
+__device__ __forceinline__ bool chain_is_sentinel(float2 v)
+{
+    return __float_as_uint(v.x) == kChainSentinel || __float_as_uint(v.y) == kChainSentinel;
+}
+// A wait is bounded by a fixed number of repeats (seconds: nothing but a fault of the launch itself makes an owner never
+// store) -- no limit held in a register, no call inside the loop (the solver has neither to spare); past it the item
+// is reported through the launch's status words like a give-up of chain_wait_slow.
+constexpr uint32_t kChainDataSpins = 1u << 21;
+__device__ __forceinline__ void chain_data_give_up_cd(const ChainDev *cd, uint32_t item);
+template <typename T2>
+__device__ __forceinline__ void chain_data_wait(__amdgpu_buffer_rsrc_t rs, unsigned off1, unsigned off2, T2 &r1, T2 &r2,
+                                                const int32_t *s_dep)
+{
+    uint32_t spins = 0;
+    while (__any(chain_is_sentinel(r1) || chain_is_sentinel(r2))) {      // wave-uniform: the lanes' upwinds finish together or nearly
+        __builtin_amdgcn_s_sleep(2);
+        r1 = BufSc1<T2>::load(rs, off1);
+        r2 = BufSc1<T2>::load(rs, off2);
+        if (++spins > kChainDataSpins) {
+            // (noted in the item's LDS words; chain_item reports it where the solver's registers are free again)
+            const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(s_dep - kCtlWords))[kCtlGaveUp] = 1u;
+            break;
+        }
+    }
+}
+
 // lean_pairs: the wavelength pairs [it.b0, it.b1) of one item, the patch's entry table parked in `tab`.  CHAIN: inside
 // the chained launch (intensities through sc1 buffer accesses, dependencies polled per pair, progress published).
 #ifndef VRT_LEAN_ATTR
 #define VRT_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
-template <typename T, int AM, int NT, bool CHAIN>
+template <typename T, int AM, int NT, int CHAIN>
 __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it, const EntryTable<NT> &tab,
                                            double2 *ptile)
 {
@@ -720,7 +758,7 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
         const size_t qb = (size_t)k0 * (size_t)n + (size_t)(CHAIN ? 0 : it.sib);
         const int sh = lw + lgT2;
         uint32_t seen = 0;
-        if constexpr (CHAIN) seen = chain_peek(s_dep, bk - it.b0 + 1);   // in flight beside the alpha gathers
+        if constexpr (CHAIN == 1) seen = chain_peek(s_dep, bk - it.b0 + 1);   // in flight beside the alpha gathers
         double2 c, g1, g2;
         {
             const int p = tab.pos[tid];
@@ -755,7 +793,9 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
             T2 rI_1, rI_2;
             if constexpr (CHAIN) {
                 // the patches that store these intensities have published this pair (Guideline 16: poll, then sc1 loads)
-                if (!(kDiag && (dbg & 256))) chain_wait(s_dep, bk - it.b0 + 1, seen);
+                if constexpr (CHAIN == 1) {
+                    if (!(kDiag && (dbg & 256))) chain_wait(s_dep, bk - it.b0 + 1, seen);
+                }
                 const __amdgpu_buffer_rsrc_t rsI = plane_rsrc(Ia + qb, n << sh);
                 if (kDiag && (dbg & 512)) {
                     rI_1 = at(Ia + qb, (unsigned)i1 << sh);
@@ -763,6 +803,11 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
                 } else {
                     rI_1 = BufSc1<T2>::load(rsI, (unsigned)i1 << sh);
                     rI_2 = BufSc1<T2>::load(rsI, (unsigned)i2 << sh);
+                }
+                // ... or the intensities are their own flags: the planes were filled with a NaN pattern before the launch,
+                // a gather that still holds it is repeated (chain_data_wait)
+                if constexpr (CHAIN == 2) {
+                    if (!(kDiag && (dbg & 256))) chain_data_wait<T2>(rsI, (unsigned)i1 << sh, (unsigned)i2 << sh, rI_1, rI_2, s_dep);
                 }
             } else {
                 rI_1 = at(Ia + qb, (unsigned)i1 << sh);
@@ -789,9 +834,9 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
             asm volatile("v_mov_b64 %0, 0" : "=v"(z));
             if (tid < it.n_ent) ptile[tid] = make_double2(z, z);         // I = zero(S), :23
         }
-        if constexpr (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous pair's stores have left (its loads are long consumed)
+        if constexpr (CHAIN == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous pair's stores have left (its loads are long consumed)
         __syncthreads();
-        if constexpr (CHAIN) {
+        if constexpr (CHAIN == 1) {
             if (bk > it.b0 && tid == 0) chain_publish(s_dep, bk - it.b0);   // ... in every wave: pairs b0 .. bk-1 are published
         }
         const int nlev = (kDiag && (dbg & 1)) ? 0 : it.nlev;
@@ -838,7 +883,7 @@ k_patch_lean(PatchArgs pa)
     if (tid == 0) ptile[it.n_ent] = make_double2(0.0, 0.0);  // the zero slot
     exp2_table_fill();
     __syncthreads();
-    lean_pairs<T, AM, NT, false>(pair_io<AM>(pa, it.d), it, tab, ptile);
+    lean_pairs<T, AM, NT, 0>(pair_io<AM>(pa, it.d), it, tab, ptile);
 }
 
 
@@ -1068,10 +1113,18 @@ __device__ __forceinline__ void chain_wait_slow(const int32_t *s_dep, int step)
     }
 }
 
+__device__ __forceinline__ void chain_data_give_up_cd(const ChainDev *cd, uint32_t item)
+{
+    st_agent(cd->ctrl + kChainAbortWord, 1u);                  // the host reports it (patch_chain_check)
+    uint32_t *hs = cd->host_status;
+    __hip_atomic_store(hs + 1, item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(hs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // J_dir over storage positions [lo, hi) of direction r for the pair blocks [b0, b1): the reduction of
 // patch_reduce_role, every intensity read by an sc1 load
-template <typename T, int NT, int LGB>
-__device__ __forceinline__ void chain_reduce(const ChainDev &cd, int r, int lo, int hi, int b0, int b1)
+template <typename T, int NT, int LGB, int MODE>
+__device__ __forceinline__ void chain_reduce(const ChainDev &cd, const ChainDev *cdp, uint32_t item, int r, int lo, int hi, int b0, int b1)
 {
     typedef typename Pair<T>::type T2;
     const int tid = threadIdx.x;
@@ -1093,7 +1146,19 @@ __device__ __forceinline__ void chain_reduce(const ChainDev &cd, int r, int lo, 
                 const int a = cd.red.angles[r][j];
                 const double wa = cd.red.w[a];
                 const __amdgpu_buffer_rsrc_t rs = plane_rsrc(I0 + (size_t)a * plane + base, (unsigned)(run << lgT2));
-                const double2 v = to_d2(BufSc1<T2>::load(rs, (unsigned)(f << lgT2)));
+                T2 raw = BufSc1<T2>::load(rs, (unsigned)(f << lgT2));
+                if constexpr (MODE == 2) {                    // the value is its own flag: repeat while it holds the fill pattern
+                    uint32_t spins = 0;
+                    while (chain_is_sentinel(raw) && !(kDiag && (cd.dbg & 256))) {
+                        __builtin_amdgcn_s_sleep(2);
+                        raw = BufSc1<T2>::load(rs, (unsigned)(f << lgT2));
+                        if (++spins > kChainDataSpins) {
+                            chain_data_give_up_cd(cdp, item);
+                            break;
+                        }
+                    }
+                }
+                const double2 v = to_d2(raw);
                 ax += wa * v.x;
                 ay += wa * v.y;
             }
@@ -1107,9 +1172,10 @@ __device__ __forceinline__ void chain_reduce(const ChainDev &cd, int r, int lo, 
 // in scalar registers the solver needs: 28 of them spilled, and with them a vector register of the 64).  Tickets are
 // taken in order by workgroups that are running, so the argument about progress above holds whatever order the
 // blocks of the grid start in; the grid has exactly one block per item.
-template <typename T, int AM, int NT, bool QUAD>
+template <typename T, int AM, int NT, bool QUAD, int MODE>
 __device__ __forceinline__ void chain_item(const ChainDev &ca, const ChainDev *cd, uint32_t base, double2 *ptile)
 {
+    static_assert(MODE == 1 || (MODE == 2 && !QUAD), "the data-as-flag form exists for the pair kernel");
     const int tid = threadIdx.x;
     constexpr int PLANES = QUAD ? 2 : 1;
     constexpr int LGB = QUAD ? 1 : 0;
@@ -1130,6 +1196,7 @@ __device__ __forceinline__ void chain_item(const ChainDev &ca, const ChainDev *c
             q = (q + 1) & 7;
         }
         s_ctl[kCtlItem] = (uint32_t)idx;
+        s_ctl[kCtlGaveUp] = 0u;
         s_ctl[kCtlArgsLo] = (uint32_t)(uint64_t)cd;
         s_ctl[kCtlArgsHi] = (uint32_t)((uint64_t)cd >> 32);
     }
@@ -1143,7 +1210,7 @@ __device__ __forceinline__ void chain_item(const ChainDev &ca, const ChainDev *c
     const int Bx = __builtin_amdgcn_readfirstlane(B4.x), By = __builtin_amdgcn_readfirstlane(B4.y);
     const int Bz = __builtin_amdgcn_readfirstlane(B4.z), Bw = __builtin_amdgcn_readfirstlane(B4.w);
     if (Az & 0x40000000u) return;                            // padding: every queue holds as many items of a layer as the longest
-    {
+    if constexpr (MODE == 1) {
         // dependency slots: the list (its first kChainDepLds entries), padded with the item's own patch to a multiple of 64
         const int32_t *deps = ca.deps;
         const int padded = min(kChainDepLds + 64, (By + 63) / 64 * 64 + (By == 0 ? 64 : 0));
@@ -1169,9 +1236,11 @@ __device__ __forceinline__ void chain_item(const ChainDev &ca, const ChainDev *c
         s_ctl[kCtlBase] = base;
     }
     if (Az >> 31) {                                          // ---- J_dir of a finished range ----------------------------
-        __syncthreads();                                     // the dependency list is in LDS
-        chain_wait(s_dep, Bw, chain_peek(s_dep, Bw));
-        chain_reduce<T, NT, LGB>(ca, d, Ax, Ay, b0, b1);
+        if constexpr (MODE == 1) {
+            __syncthreads();                                 // the dependency list is in LDS
+            chain_wait(s_dep, Bw, chain_peek(s_dep, Bw));
+        }
+        chain_reduce<T, NT, LGB, MODE>(ca, cd, (uint32_t)idx, d, Ax, Ay, b0, b1);
         return;
     }
     PatchItem it;
@@ -1197,11 +1266,17 @@ __device__ __forceinline__ void chain_item(const ChainDev &ca, const ChainDev *c
     __syncthreads();                                         // the dependency list is in LDS
     if (kDiag && (ca.dbg & 2048)) it.b1 = it.b0;             // diagnostics: the item's overhead alone
     if constexpr (QUAD) quad_pairs<AM, NT, true>(pa, it, tab, ptile);
-    else lean_pairs<T, AM, NT, true>(pa, it, tab, ptile);
-    // the last pair: every storing wave drains, then ONE lane publishes the finished item
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) chain_publish(s_dep, b1 - b0);
+    else lean_pairs<T, AM, NT, MODE>(pa, it, tab, ptile);
+    if constexpr (MODE == 2) {
+        __syncthreads();
+        if (tid == 0 && s_ctl[kCtlGaveUp]) chain_data_give_up_cd(cd, (uint32_t)idx);
+    }
+    if constexpr (MODE == 1) {
+        // the last pair: every storing wave drains, then ONE lane publishes the finished item
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) chain_publish(s_dep, b1 - b0);
+    }
 }
 
 template <typename T, int AM, int NT>
@@ -1209,14 +1284,24 @@ __global__ void __launch_bounds__(NT) VRT_LEAN_ATTR
 k_patch_chain(ChainDev ca, const ChainDev *cd, uint32_t base)
 {
     extern __shared__ __attribute__((aligned(16))) double2 ptile[];
-    chain_item<T, AM, NT, false>(ca, cd, base, ptile);
+    chain_item<T, AM, NT, false, 1>(ca, cd, base, ptile);
+}
+// the intensities are their own flags (chain_data_wait): the planes were filled with kChainSentinel before the launch.
+// (Six waves per SIMD: the repeat loop holds the gathered pair and its offsets beside everything the solver has live at
+// that point -- 12 B of scratch at 64 registers -- and this form runs where the chip is far from full anyway.)
+template <typename T, int AM, int NT>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
+k_patch_chain_df(ChainDev ca, const ChainDev *cd, uint32_t base)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 ptile[];
+    chain_item<T, AM, NT, false, 2>(ca, cd, base, ptile);
 }
 template <int AM, int NT>
 __global__ void __launch_bounds__(NT) VRT_QUAD_ATTR
 k_patch_chain_quad(ChainDev ca, const ChainDev *cd, uint32_t base)
 {
     extern __shared__ __attribute__((aligned(16))) double2 ptile[];
-    chain_item<float, AM, NT, true>(ca, cd, base, ptile);
+    chain_item<float, AM, NT, true, 1>(ca, cd, base, ptile);
 }
 
 // the instantiated launch shapes (entries per thread, pairs at a time, threads)
@@ -1411,6 +1496,15 @@ bool patch_chain_possible(const vrt_plan *p, int npair, bool f32)
     return per_layer * (double)pair_block_count(npair, lgB) <= 1536.0;
 }
 
+// the chained launch's hand-off by the data itself (chain_data_wait): fp64 pair kernel only; auto: one or two wavelength
+// pairs -- the fill of the planes costs 16 bytes per (site, angle, pair) and step, the progress words two fabric round
+// trips per LAYER (C2: 0.54 -> see DESIGN.md section 5)
+bool patch_chain_dataflag(const vrt_plan *p, int npair, bool f32)
+{
+    if (f32 || p->tune.chain_dataflag == 0 || native_lg(p, f32) != 0) return false;
+    return p->tune.chain_dataflag == 1 || npair <= 2;
+}
+
 // Items per patch: enough that ONE layer (both directions) offers about as many items as the chip holds workgroups
 // (1024: a workgroup takes its item in queue order and, if the item's layer is not ready, waits for it while holding
 // its place -- items of a later layer started early are slots spent waiting), and at most VRT_CHAIN_PAIRS blocks each
@@ -1576,9 +1670,15 @@ static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool 
 }
 
 template <typename T, int AM>
-static int launch_chain_mode(bool quad, int64_t items, size_t lds, hipStream_t st, const ChainDev &h, const ChainDev *cd, uint32_t base)
+static int launch_chain_mode(bool quad, bool dataflag, int64_t items, size_t lds, hipStream_t st, const ChainDev &h, const ChainDev *cd, uint32_t base)
 {
     constexpr int NT = 512;
+    if constexpr (sizeof(T) == 8) {
+        if (dataflag) {
+            hipLaunchKernelGGL((k_patch_chain_df<T, AM, NT>), dim3((unsigned)items), dim3(NT), lds, st, h, cd, base);
+            return VRT_OK;
+        }
+    }
     if constexpr (sizeof(T) == 4) {
         if (quad) {
             hipLaunchKernelGGL((k_patch_chain_quad<AM, NT>), dim3((unsigned)items), dim3(NT), lds, st, h, cd, base);
@@ -1591,7 +1691,7 @@ static int launch_chain_mode(bool quad, int64_t items, size_t lds, hipStream_t s
 
 // ONE launch for every layer of every active angle (and J_dir of both directions when `reduce` is given: its weights,
 // angle lists [0] = up, [1] = down and J_dir planes)
-int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t st, bool f32, const PatchReduce *reduce)
+int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t st, bool f32, const PatchReduce *reduce, bool dataflag)
 {
     // a give-up of an EARLIER chained launch of this plan (its results were wrong) is reported here at the latest
     if (int rc0 = patch_chain_check(p)) return rc0;
@@ -1650,16 +1750,16 @@ int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t s
     const ChainDev *cd = reinterpret_cast<const ChainDev *>(p->d_chain_dev);
     switch (ta.alpha_mode) {
     case VRT_ALPHA_SITE:
-        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_SITE>(quad, p->chain_items, lds, st, h, cd, base)
-                 : launch_chain_mode<double, VRT_ALPHA_SITE>(quad, p->chain_items, lds, st, h, cd, base);
+        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_SITE>(quad, dataflag, p->chain_items, lds, st, h, cd, base)
+                 : launch_chain_mode<double, VRT_ALPHA_SITE>(quad, dataflag, p->chain_items, lds, st, h, cd, base);
         break;
     case VRT_ALPHA_SITE_LAM:
-        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_SITE_LAM>(quad, p->chain_items, lds, st, h, cd, base)
-                 : launch_chain_mode<double, VRT_ALPHA_SITE_LAM>(quad, p->chain_items, lds, st, h, cd, base);
+        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_SITE_LAM>(quad, dataflag, p->chain_items, lds, st, h, cd, base)
+                 : launch_chain_mode<double, VRT_ALPHA_SITE_LAM>(quad, dataflag, p->chain_items, lds, st, h, cd, base);
         break;
     default:
-        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_ANGLE_SITE_LAM>(quad, p->chain_items, lds, st, h, cd, base)
-                 : launch_chain_mode<double, VRT_ALPHA_ANGLE_SITE_LAM>(quad, p->chain_items, lds, st, h, cd, base);
+        rc = f32 ? launch_chain_mode<float, VRT_ALPHA_ANGLE_SITE_LAM>(quad, dataflag, p->chain_items, lds, st, h, cd, base)
+                 : launch_chain_mode<double, VRT_ALPHA_ANGLE_SITE_LAM>(quad, dataflag, p->chain_items, lds, st, h, cd, base);
         break;
     }
     if (rc) return rc;
