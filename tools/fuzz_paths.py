@@ -53,6 +53,20 @@ for case in range(cases):
         J, I = plan.execute(S, al, weights=w, I0_up=I0, want_I=True)
         res[path] = (J.copy(), I.copy())
         plan.close()
+    # the patch path's launch forms -- per-layer launches, chained with progress words, chained with the intensities as
+    # their own flags -- against whatever the default chose: bit for bit
+    os.environ["VRT_PATH"] = "patches"
+    for form, env in (("launches", {"VRT_PATCH_CHAIN": "0"}), ("chain", {"VRT_PATCH_CHAIN": "1", "VRT_CHAIN_DATAFLAG": "0"}),
+                      ("chain-df", {"VRT_PATCH_CHAIN": "1", "VRT_CHAIN_DATAFLAG": "1"})):
+        os.environ.update(env)
+        plan = vrt.FormalPlan(hs, ks, n_sweeps)
+        Jf, If = plan.execute(S, al, weights=w, I0_up=I0, want_I=True)
+        plan.close()
+        for k in env:
+            os.environ.pop(k)
+        if not (np.array_equal(Jf, res["patches"][0]) and np.array_equal(If, res["patches"][1])):
+            print(f"case {case} {desc}: patch path form '{form}' differs from the default form")
+            sys.exit(1)
     # the single-wavelength level kernel (large layers / fp32 storage) on the same problem: bitwise the pair kernel
     os.environ["VRT_PATH"] = "steps"
     os.environ["VRT_STEP_SINGLE"] = "1"

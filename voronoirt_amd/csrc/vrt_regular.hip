@@ -904,7 +904,7 @@ extern "C" int vrt_regular_execute_dev(vrt_regular *r, int64_t n_solve, const do
     int mt = (int)std::min<int64_t>(1024, (interior + 63) / 64 * 64);
     if (r->force_threads) mt = r->force_threads;
     const int npt = (int)((interior + mt - 1) / mt);
-    if (all_xy && r->xy_split && 24 * vol < ((int64_t)1 << 31)) {      // (a solve's coefficients: 32-bit byte offsets)
+    if (all_xy && r->xy_split && 24 * vol < ((int64_t)1 << 31) && nz <= 65536) {   // (a solve's coefficients: 32-bit byte offsets; planes = grid.y)
         // coefficients: 3 doubles per point, plane and solve, in chunks of solves of at most 2 GiB
         const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>({n_solve, 65535, ((int64_t)1 << 31) / (24 * vol)}));
         if ((rc = regular_grow(r->d_xy, r->cap_xy, chunk, (size_t)(3 * vol)))) return rc;
