@@ -827,15 +827,7 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_, c
         bool replayed = false;
         if (use_graph) {
             if (!(p->graph_exec && p->graph_key == key)) {
-                for (CopyLane &l : p->copy_lanes) {
-        for (int b = 0; b < 2; b++) {
-            if (l.pin[b]) (void)hipHostFree(l.pin[b]);
-            if (l.ev[b]) (void)hipEventDestroy(l.ev[b]);
-        }
-        if (l.st) (void)hipStreamDestroy(l.st);
-    }
-    if (p->copy_done) (void)hipEventDestroy(p->copy_done);
-    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+                if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
                 p->graph_exec = nullptr;
                 hipGraph_t graph = nullptr;
                 if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {

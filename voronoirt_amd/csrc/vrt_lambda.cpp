@@ -88,6 +88,9 @@ int run_copy_jobs(vrt_plan *p, const std::vector<CopyJob> &jobs, bool download, 
         if (hipSetDevice(device) != hipSuccess) { rcs[(size_t)li] = VRT_ENODEVICE; return; }
         auto ok = [&](hipError_t e) { if (e != hipSuccess) rcs[(size_t)li] = VRT_ENODEVICE; return e == hipSuccess; };
         if (download && after && !ok(hipStreamWaitEvent(l.st, after, 0))) return;
+        // (the staging buffers may still feed the last transfers of an EARLIER call: those first)
+        for (int b = 0; b < 2; b++)
+            if (!ok(hipEventSynchronize(l.ev[b]))) return;
         int pending[2] = {-1, -1};
         int slot = 0;
         for (size_t k = (size_t)li; k < jobs.size(); k += (size_t)L, slot ^= 1) {
