@@ -305,7 +305,10 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         const int G = std::max(1, std::min({p->tune.step_streams, 4, A}));
         if ((rc = ensure_step_streams(p, G))) return rc;
         bool forked = false;
-        for (int d = 0; d < 2; d++) {
+        // (not for a chained step of a few wavelengths: its layout changes are a few microseconds each, less than the
+        // event round trip that brings the second stream back)
+        const bool tiny = narrow && patches && patch_chain_possible(p, (int)(nl_pad / 2), kF32);
+        for (int d = 0; d < 2 && !tiny; d++) {
             if (!use_dir[d]) continue;
             for (int gi = 1; gi < G; gi++) {
                 int have = 0;
