@@ -263,6 +263,20 @@ __device__ __forceinline__ void solve2(const double A[4], const double b[2], dou
     x[0] = (b0 - a01 * x[1]) / a00;
 }
 
+// The rate kernels run 91 Boltzmann factors and 51 Voigt profiles per site and are bound by that arithmetic: the per-site
+// divisors (Δλ_D, T) are inverted once, 1/λ comes from the hardware estimate + two Newton steps, exp(-hc/λkT) from the
+// table-driven exp_neg_tab -- last-bit differences from the oracle's divisions and libm (contract of this row: 1e-12).
+__device__ __forceinline__ double rcp_newton(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return fma(fma(-d, r, 1.0), r, r);
+}
+__device__ __forceinline__ double boltzmann(double hc_over_kT, double lam)      // exp(-hc / (λ k T)), rates.jl:473
+{
+    return exp_neg_tab(fmin(hc_over_kT * rcp_newton(lam), 745.0));
+}
+
 // R of site i out, its statistical equilibrium solved (n_levels = 2, populations.jl:191-221)
 __device__ __forceinline__ void populations_from_rates(const RatesArgs &ra, int64_t i, const double R[9])
 {
@@ -295,11 +309,24 @@ k_rates_populations(RatesArgs ra)
 {
     exp2_table_fill();
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = ra.n;
-    if (i >= n) return;
-    const double *__restrict__ Ji = ra.J + (size_t)i * (size_t)ra.ld;
-    const double T = ra.temperature[i];
+    const int tid = threadIdx.x;
+    const int64_t n = ra.n, site0 = (int64_t)blockIdx.x * 256;
+    const bool valid = site0 + tid < n;
+    const int64_t i = valid ? site0 + tid : n - 1;                  // (a thread past the end works on the last site and stores nothing)
+    // J is (n, ld) with the wavelength fastest: a thread walking its own row makes every load of the wave touch 64
+    // different lines.  The block's 256 rows are staged through LDS 16 wavelengths at a time instead (a site's 128
+    // bytes by 16 neighbouring lanes), and a thread picks its row's values up from there (row stride 17: no conflicts)
+    __shared__ double Jt[256 * 17];
+    auto stage = [&](int64_t l0c, int64_t hi) {
+        __syncthreads();                                            // the previous chunk has been consumed
+        for (int idx = tid; idx < 256 * 16; idx += 256) {
+            const int sr = idx >> 4, c = idx & 15;
+            const int64_t site = site0 + sr, l = l0c + c;
+            Jt[sr * 17 + c] = (site < n && l < hi) ? ra.J[(size_t)site * (size_t)ra.ld + (size_t)l] : 0.0;
+        }
+        __syncthreads();
+    };
+    const double hT = ra.hc_over_kB / ra.temperature[i];
     double R[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) R[q] = 0.0;
@@ -310,8 +337,9 @@ k_rates_populations(RatesArgs ra)
         const double n_ratio = ra.lte[i + n * (level - 1)] / ra.lte[i + n * 2];
         double rij = 0.0, rji = 0.0, s_prev = 0.0, G_prev = 0.0, J_prev = 0.0;
         for (int64_t l = lo; l < hi; l++) {
-            const double lam = ra.lambda[l], s = sig[l - lo], Jl = Ji[l];
-            const double G = n_ratio * exp(-ra.hc_over_kB / (lam * T));                 // Gij, rates.jl:473
+            if (((l - lo) & 15) == 0) stage(l, hi);
+            const double lam = ra.lambda[l], s = sig[l - lo], Jl = Jt[tid * 17 + (int)((l - lo) & 15)];
+            const double G = n_ratio * boltzmann(hT, lam);                               // Gij, rates.jl:473
             if (l > lo) {
                 const double lp = ra.lambda[l - 1], dl = lam - lp;
                 rij += ra.pref_ij * ((lp * s_prev * J_prev + lam * s * Jl) * dl);      // :262-263
@@ -328,13 +356,15 @@ k_rates_populations(RatesArgs ra)
         const int64_t lo = ra.blocks[0], hi = ra.blocks[1];
         const double n_ratio = ra.lte[i] / ra.lte[i + n];
         const double dD = ra.doppler[i], gm = ra.gamma[i];
+        const double r_dD = 1.0 / dD, r_a = 1.0 / (4.0 * kPi * ra.c0 * dD), r_prof = 1.0 / (sqrt(kPi) * dD);
         double rij = 0.0, rji = 0.0, s_prev = 0.0, G_prev = 0.0, J_prev = 0.0;
         for (int64_t l = lo; l < hi; l++) {
-            const double lam = ra.lambda[l], Jl = Ji[l];
-            const double a = gm * (lam * lam) / (4.0 * kPi * ra.c0 * dD);
-            const double v = (lam - ra.lambda0) / dD;                                    // rates.jl:408
-            const double s = ra.sigma_bb_const * (humlicek_w4_re(v, a) / (sqrt(kPi) * dD));
-            const double G = n_ratio * exp(-ra.hc_over_kB / (lam * T));
+            if (((l - lo) & 15) == 0) stage(l, hi);
+            const double lam = ra.lambda[l], Jl = Jt[tid * 17 + (int)((l - lo) & 15)];
+            const double a = gm * (lam * lam) * r_a;
+            const double v = (lam - ra.lambda0) * r_dD;                                  // rates.jl:408
+            const double s = ra.sigma_bb_const * (humlicek_w4_re(v, a) * r_prof);
+            const double G = n_ratio * boltzmann(hT, lam);
             if (l > lo) {
                 const double lp = ra.lambda[l - 1], dl = lam - lp;
                 rij += ra.pref_ij * ((lp * s_prev * J_prev + lam * s * Jl) * dl);      // :236-237
@@ -346,7 +376,7 @@ k_rates_populations(RatesArgs ra)
         R[0 + 3 * 1] = rij;
         R[1 + 3 * 0] = rji;
     }
-    populations_from_rates(ra, i, R);
+    if (valid) populations_from_rates(ra, i, R);
 }
 
 // ---- the same split over wavelength blocks (several devices: vrt_multi_lambda_*, vrt_multi.cpp) -------------------------
@@ -365,23 +395,24 @@ k_rates_partial(RatesArgs ra, int64_t l0, int64_t l1, double *__restrict__ share
     const int64_t n = ra.n;
     if (i >= n) return;
     const double *__restrict__ Ji = ra.J + (size_t)i * (size_t)ra.ld - l0;      // indexed by the GLOBAL wavelength
-    const double T = ra.temperature[i];
+    const double hT = ra.hc_over_kB / ra.temperature[i];
     for (int tr = 0; tr < 3; tr++) {                                              // bf level 1, bf level 2, bb
         const int64_t lo = ra.blocks[tr < 2 ? 2 * (tr + 1) : 0], hi = ra.blocks[tr < 2 ? 2 * (tr + 1) + 1 : 1];
         const double n_ratio = tr < 2 ? ra.lte[i + n * tr] / ra.lte[i + n * 2] : ra.lte[i] / ra.lte[i + n];
         const double *__restrict__ sig = tr == 0 ? ra.sigma_bf1 : ra.sigma_bf2;
         const double dD = ra.doppler[i], gm = ra.gamma[i];
+        const double r_dD = 1.0 / dD, r_a = 1.0 / (4.0 * kPi * ra.c0 * dD), r_prof = 1.0 / (sqrt(kPi) * dD);
         double rij = 0.0, rji = 0.0;
         for (int64_t l = lo > l0 ? lo : l0; l < (hi < l1 ? hi : l1); l++) {
             const double lam = ra.lambda[l], Jl = Ji[l];
             double s;
             if (tr < 2) s = sig[l - lo];
             else {
-                const double a = gm * (lam * lam) / (4.0 * kPi * ra.c0 * dD);
-                const double v = (lam - ra.lambda0) / dD;                                // rates.jl:408
-                s = ra.sigma_bb_const * (humlicek_w4_re(v, a) / (sqrt(kPi) * dD));
+                const double a = gm * (lam * lam) * r_a;
+                const double v = (lam - ra.lambda0) * r_dD;                              // rates.jl:408
+                s = ra.sigma_bb_const * (humlicek_w4_re(v, a) * r_prof);
             }
-            const double G = n_ratio * exp(-ra.hc_over_kB / (lam * T));                 // Gij, rates.jl:473
+            const double G = n_ratio * boltzmann(hT, lam);                               // Gij, rates.jl:473
             double W = 0.0;
             if (l > lo) W += lam - ra.lambda[l - 1];
             if (l < hi - 1) W += ra.lambda[l + 1] - lam;
