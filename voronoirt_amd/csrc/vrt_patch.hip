@@ -189,6 +189,41 @@ __device__ __forceinline__ void entry_lambda_seq(double d1, double d2, const dou
     else entry_terms_seq<2>(d1, d2, pw1, pw2, in1, in2, S_c, S_1, S_2, I_1, I_2, c, g1, g2, next);
 }
 
+// The same visit with the upwind intensities applied LAST (the data-as-flag chained launch, where a workgroup waits for
+// exactly those): everything that does not need I_1, I_2 -- the four weights, a_r S_ur, the couplings -- is formed while the
+// gathers are in flight or repeated, and what is left behind the wait is three dependent operations per upwind.  The
+// same operations on the same values in the same association as entry_terms_seq: bit-identical.
+struct LateTerms { double ce1, p1, cb1, ce2, p2, cb2; };
+template <int MODE>
+__device__ __forceinline__ void late_coeffs(double dt1, double dt2, double S_1, double S_2, LateTerms &L, double &next)
+{
+    double ca, cb, ce;
+    lin_weights_fma<MODE>(dt1, ca, cb, ce);
+    L.ce1 = ce; L.p1 = ca * S_1; L.cb1 = cb;
+    asm volatile("" : "+v"(L.ce1), "+v"(L.p1), "+v"(L.cb1), "+v"(dt2));
+    lin_weights_fma<MODE>(dt2, ca, cb, ce);
+    L.ce2 = ce; L.p2 = ca * S_2; L.cb2 = cb;
+    asm volatile("" : "+v"(L.ce2), "+v"(L.p2), "+v"(L.cb2), "+v"(next));
+}
+__device__ __forceinline__ void late_lambda(double d1, double d2, double S_1, double S_2, LateTerms &L, double &next)
+{
+    const bool mid = ((d1 >= 5e-4) & (d1 <= 50.0)) | ((d2 >= 5e-4) & (d2 <= 50.0));
+    const bool thin = (d1 < 5e-4) | (d2 < 5e-4);
+    if (__ballot(mid) == 0ull) late_coeffs<0>(d1, d2, S_1, S_2, L, next);
+    else if (__ballot(thin) == 0ull) late_coeffs<1>(d1, d2, S_1, S_2, L, next);
+    else late_coeffs<2>(d1, d2, S_1, S_2, L, next);
+}
+__device__ __forceinline__ void late_apply(const LateTerms &L, const double *pw1, const double *pw2, bool in1, bool in2,
+                                           double S_c, double I_1, double I_2, double &c, double &g1, double &g2)
+{
+    const double w1 = *pw1, w2 = *pw2;
+    const double t1 = fma(L.cb1, S_c, fma(L.ce1, I_1, L.p1)) * w1;
+    const double t2 = fma(L.cb2, S_c, fma(L.ce2, I_2, L.p2)) * w2;
+    c = t1 + t2;
+    g1 = in1 ? L.ce1 * w1 : 0.0;
+    g2 = in2 ? L.ce2 * w2 : 0.0;
+}
+
 // wavelength pair `idx` of a plane: 32-bit byte offset from a wave-uniform base (planes are < 4 GiB: n < 2^28),
 // so the load takes the saddr + voffset form -- one address VGPR, no 64-bit vector arithmetic
 template <typename T2>
@@ -805,16 +840,33 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
                     rI_2 = BufSc1<T2>::load(rsI, (unsigned)i2 << sh);
                 }
                 // ... or the intensities are their own flags: the planes were filled with a NaN pattern before the launch,
-                // a gather that still holds it is repeated (chain_data_wait)
+                // a gather that still holds it is repeated (chain_data_wait) -- behind the weights, which do not need them:
+                // what a layer of the chain waits for after its intensities arrive is 14 operations, not ~190
                 if constexpr (CHAIN == 2) {
-                    if (!(kDiag && (dbg & 256))) chain_data_wait<T2>(rsI, (unsigned)i1 << sh, (unsigned)i2 << sh, rI_1, rI_2, s_dep);
+                    const bool in1 = (v1 >= it.lo) & (v1 < it.hi), in2 = (v2 >= it.lo) & (v2 < it.hi);
+                    if (!(kDiag && (dbg & 4))) {
+                        LateTerms Lx, Ly;
+                        late_lambda(d1x, d2x, (double)rS_1.x, (double)rS_2.x, Lx, d1y);
+                        double sink = 0.0;
+                        late_lambda(d1y, d2y, (double)rS_1.y, (double)rS_2.y, Ly, sink);
+                        if (!(kDiag && (dbg & 256))) chain_data_wait<T2>(rsI, (unsigned)i1 << sh, (unsigned)i2 << sh, rI_1, rI_2, s_dep);
+                        late_apply(Lx, tab.w1 + tid, tab.w2 + tid, in1, in2, (double)rS_c.x, (double)rI_1.x, (double)rI_2.x, c.x, g1.x, g2.x);
+                        late_apply(Ly, tab.w1 + tid, tab.w2 + tid, in1, in2, (double)rS_c.y, (double)rI_1.y, (double)rI_2.y, c.y, g1.y, g2.y);
+                    } else {
+                        if (!(kDiag && (dbg & 256))) chain_data_wait<T2>(rsI, (unsigned)i1 << sh, (unsigned)i2 << sh, rI_1, rI_2, s_dep);
+                        c = make_double2(d1x + (double)rS_c.x + (double)rS_1.x + (double)rI_1.x, d2y + (double)rS_c.y + (double)rS_2.y + (double)rI_2.y);
+                        g1 = make_double2(in1 ? d2x : 0.0, in1 ? d1y : 0.0);
+                        g2 = make_double2(in2 ? d1x : 0.0, in2 ? d2y : 0.0);
+                    }
                 }
             } else {
                 rI_1 = at(Ia + qb, (unsigned)i1 << sh);
                 rI_2 = at(Ia + qb, (unsigned)i2 << sh);
             }
             const bool in1 = (v1 >= it.lo) & (v1 < it.hi), in2 = (v2 >= it.lo) & (v2 < it.hi);
-            if (kDiag && (dbg & 4)) {                            // diagnostics: no weights arithmetic
+            if constexpr (CHAIN == 2) {
+                // (done above, around the wait)
+            } else if (kDiag && (dbg & 4)) {                     // diagnostics: no weights arithmetic
                 c = make_double2(d1x + (double)rS_c.x + (double)rS_1.x + (double)rI_1.x, d2y + (double)rS_c.y + (double)rS_2.y + (double)rI_2.y);
                 g1 = make_double2(in1 ? d2x : 0.0, in1 ? d1y : 0.0);
                 g2 = make_double2(in2 ? d1x : 0.0, in2 ? d2y : 0.0);
