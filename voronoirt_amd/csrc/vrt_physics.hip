@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 #include <string>
 
 #include "vrt_device.h"
@@ -52,7 +53,7 @@ __device__ __forceinline__ double c_div_re(cplx a, cplx b)                // Re(
     const double d = fma(b.re, b.re, b.im * b.im);
     double r = __builtin_amdgcn_rcp(d);
     r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);                        // (v_rcp_f64 is good to ~2^-23: the second step is needed below 1e-13)
     return fma(a.re, b.re, a.im * b.im) * r;
 }
 // cos z for the |z| <= ~12 that region 4 of w4 can produce (z = -2 x y, |x| + y < 5.5): when every lane of the wave has
@@ -153,30 +154,40 @@ __device__ double humlicek_w4_re(double x, double y)
 constexpr double kPi = 3.14159265358979323846;
 
 // ---- opacity prologue -------------------------------------------------------------------------------
-// one thread per storage position of the angle's direction; it walks the wavelength pairs, so the
-// site's seven line parameters are read once and every pair plane is written coalesced (16 B/lane)
-// T2 = double2, or float2 for the fp32 VALUE path (the arithmetic stays fp64, the stored pair is rounded)
+// one thread per storage position of an angle's direction (blockIdx.y = active angle: ONE launch for all of them); it
+// walks the wavelength pairs, so the site's line parameters are read once and every pair plane is written coalesced
+// (16 B/lane).  T2 = double2, or float2 for the fp32 VALUE path (the arithmetic stays fp64, the stored pair is rounded).
+// The kernel is bound by the COUNT of its fp64 instructions (measured: time is linear in it, ~linear in nothing else --
+// eight instead of four waves per SIMD change nothing), so what does not depend on the wavelength is
+// folded per site: gamma / (4 pi c dlambda_D), strength / (sqrt(pi) dlambda_D), and the profile enters alpha_tot by one
+// fused multiply-add (last-bit differences from the oracle's expression order; contract of this row: 1e-12).
+struct OpacityAngles {
+    double k[kMaxAngles][3];
+    unsigned char down[kMaxAngles];
+};
 template <typename T2>
 __global__ void __launch_bounds__(256)
-k_line_opacity(int64_t n, int nlam, int npair, int lgB, const int32_t *__restrict__ store, double k0, double k1, double k2,
-               const double *__restrict__ lambda, double lambda0, double c0, const double *__restrict__ velocity,
+k_line_opacity(int64_t n, int nlam, int npair, int lgB, const int32_t *__restrict__ store_up, const int32_t *__restrict__ store_down,
+               OpacityAngles ang, const double *__restrict__ lambda, double lambda0, double c0, const double *__restrict__ velocity,
                const double *__restrict__ doppler, const double *__restrict__ gamma,
                const double *__restrict__ strength, const double *__restrict__ alpha_cont,
-               T2 *__restrict__ out /* pair planes of the plan's native layout (vrt_device.h: pair_index) */)
+               T2 *__restrict__ out0 /* pair planes of the plan's native layout (vrt_device.h: pair_index), angle after angle */,
+               size_t plane_pairs)
 {
     exp2_table_fill();
     __syncthreads();
     const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= n) return;
-    const int32_t site = store[pos];
+    const int ia = blockIdx.y;
+    const int32_t site = (ang.down[ia] ? store_down : store_up)[pos];
+    T2 *__restrict__ out = out0 + (size_t)ia * plane_pairs;
     // v_los = dot(velocity, -k)   (line.jl:126, :205)
-    const double v_los = velocity[3 * (size_t)site] * (-k0) + velocity[3 * (size_t)site + 1] * (-k1) +
-                         velocity[3 * (size_t)site + 2] * (-k2);
-    const double dD = doppler[site], gm = gamma[site], st = strength[site], ac = alpha_cont[site];
-    // the kernel is bound by its fp64 arithmetic (51 Voigt evaluations per site and angle), and a
-    // division costs a dozen dependent instructions: the three per-site divisors are inverted once
-    // (last-bit differences from the oracle's divisions; contract of this row: 1e-12)
-    const double r_dD = 1.0 / dD, r_a = 1.0 / (4.0 * kPi * c0 * dD), r_prof = 1.0 / (sqrt(kPi) * dD);
+    const double v_los = velocity[3 * (size_t)site] * (-ang.k[ia][0]) + velocity[3 * (size_t)site + 1] * (-ang.k[ia][1]) +
+                         velocity[3 * (size_t)site + 2] * (-ang.k[ia][2]);
+    const double dD = doppler[site], ac = alpha_cont[site];
+    const double r_dD = 1.0 / dD;
+    const double ga = gamma[site] / (4.0 * kPi * c0 * dD);                 // a = gamma lambda^2 / (4 pi c dlambda_D), broadening.jl:87-89
+    const double sp = strength[site] / (sqrt(kPi) * dD);                   // alpha_line = strength H / (sqrt(pi) dlambda_D), line.jl:133, :219-225
     const double shift = lambda0 * v_los / c0;
     for (int q = 0; q < npair; q++) {
         double v2[2];
@@ -185,9 +196,9 @@ k_line_opacity(int64_t n, int nlam, int npair, int lgB, const int32_t *__restric
             const int l = 2 * q + h;
             if (l < nlam) {
                 const double lam = lambda[l];
-                const double a = gm * (lam * lam) * r_a;                               // broadening.jl:87-89
+                const double a = ga * (lam * lam);
                 const double v = (lam - lambda0 + shift) * r_dD;                       // line.jl:132
-                v2[h] = st * (humlicek_w4_re(v, a) * r_prof) + ac;                     // line.jl:133, :219-225; lambda_iteration.jl:93-96
+                v2[h] = fma(sp, humlicek_w4_re(v, a), ac);                             // lambda_iteration.jl:93-96
             } else
                 v2[h] = ac;                                                            // padding wavelength: finite
         }
@@ -205,19 +216,23 @@ int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, doubl
     vrt_grid *g = p->g;
     const int64_t n = g->n;
     const int npair = (int)((nlam + 1) / 2);
-    const size_t plane = (size_t)npair * 2 * (size_t)n;
+    const size_t plane_pairs = (size_t)npair * (size_t)n;
+    if (p->A <= 0) return VRT_OK;
+    OpacityAngles ang;
+    std::memset(&ang, 0, sizeof(ang));
     for (int a = 0; a < p->A; a++) {
-        const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-        const double *k = p->k.data() + 3 * (size_t)a;
-        if (f32_out)
-            hipLaunchKernelGGL(k_line_opacity<float2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (int)nlam, npair,
-                               native_lg(p, f32_out), dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
-                               d_strength, d_alpha_cont, reinterpret_cast<float2 *>((float *)d_out + (size_t)a * plane));
-        else
-            hipLaunchKernelGGL(k_line_opacity<double2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (int)nlam, npair,
-                               native_lg(p, f32_out), dir.d_store, k[0], k[1], k[2], d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma,
-                               d_strength, d_alpha_cont, reinterpret_cast<double2 *>((double *)d_out + (size_t)a * plane));
+        for (int j = 0; j < 3; j++) ang.k[a][j] = p->k[3 * (size_t)a + (size_t)j];
+        ang.down[a] = p->dir_of_active[(size_t)a] > 0 ? 0 : 1;
     }
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)p->A);
+    if (f32_out)
+        hipLaunchKernelGGL(k_line_opacity<float2>, grid, dim3(256), 0, st, n, (int)nlam, npair, native_lg(p, f32_out), g->up.d_store,
+                           g->down.d_store, ang, d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma, d_strength, d_alpha_cont,
+                           reinterpret_cast<float2 *>(d_out), plane_pairs);
+    else
+        hipLaunchKernelGGL(k_line_opacity<double2>, grid, dim3(256), 0, st, n, (int)nlam, npair, native_lg(p, f32_out), g->up.d_store,
+                           g->down.d_store, ang, d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma, d_strength, d_alpha_cont,
+                           reinterpret_cast<double2 *>(d_out), plane_pairs);
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
