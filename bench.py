@@ -39,6 +39,11 @@ import time
 
 import numpy as np
 
+# the CPU-baseline leg runs the oracle on an OpenMP team; idle OpenMP workers that spin after their region would eat
+# the box's CPU share while the secondary (C2) measurement enqueues its ~10 launches per 0.45-ms step (seen: 1.76 ms wall
+# per step against 0.45 ms of HIP-event time).  Read by libgomp when it is loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -423,7 +428,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         I0_h = I0_up[:, :lam_s].contiguous().cpu().numpy().astype(np.float64)
         t0 = time.time()
         J_ref = orc.J_voronoi(w_mine, theta[my_angles], phi[my_angles], S_h, al_h, so, I0_up=I0_h,
-                              nthreads=cores)
+                              nthreads=min(cores, lam_s))     # (one thread per wavelength of the sample: no idle team members)
         t_cpu = time.time() - t0
         cpu_updates = n * A * lam_s
         # T = 1: one wavelength, one thread (T = 1 and T = all cores); all angles, or
