@@ -748,15 +748,50 @@ __device__ __forceinline__ bool chain_is_sentinel(float2 v)
 // is reported through the launch's status words like a give-up of chain_wait_slow.
 constexpr uint32_t kChainDataSpins = 1u << 21;
 __device__ __forceinline__ void chain_data_give_up_cd(const ChainDev *cd, uint32_t item);
+// Every other repeat asks the reading XCD's own L2 (agent scope: sc1 alone).  A patch's upwind owners are mostly patches of
+// the same queue, i.e. the same XCD (the queues cut every layer at the same eighths of the storage order): their
+// write-through stores pass through this very L2, and a line a repeat has brought in is updated there -- the value is seen
+// after an L2 round trip instead of a trip to memory and back.  A line whose owner ran on another XCD stays stale in this
+// L2 (it still shows the fill pattern); the system-scope repeats in between see it.  A value that is not the pattern is
+// final whichever way it was read: the planes are filled before the launch, and a launch starts with clean L2s.
+template <typename T2>
+__device__ __forceinline__ T2 load_agent_scope(__amdgpu_buffer_rsrc_t rs, unsigned off);
+template <>
+__device__ __forceinline__ double2 load_agent_scope<double2>(__amdgpu_buffer_rsrc_t rs, unsigned off)
+{
+    const vrt_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);
+    double2 d;
+    __builtin_memcpy(&d, &v, 16);
+    return d;
+}
+template <>
+__device__ __forceinline__ float2 load_agent_scope<float2>(__amdgpu_buffer_rsrc_t rs, unsigned off)
+{
+    const vrt_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 16);
+    float2 d;
+    __builtin_memcpy(&d, &v, 8);
+    return d;
+}
+#ifndef VRT_CHAIN_L2_POLL
+#define VRT_CHAIN_L2_POLL 1
+#endif
 template <typename T2>
 __device__ __forceinline__ void chain_data_wait(__amdgpu_buffer_rsrc_t rs, unsigned off1, unsigned off2, T2 &r1, T2 &r2,
                                                 const int32_t *s_dep)
 {
     uint32_t spins = 0;
     while (__any(chain_is_sentinel(r1) || chain_is_sentinel(r2))) {      // wave-uniform: the lanes' upwinds finish together or nearly
-        __builtin_amdgcn_s_sleep(2);
-        r1 = BufSc1<T2>::load(rs, off1);
-        r2 = BufSc1<T2>::load(rs, off2);
+        __builtin_amdgcn_s_sleep(1);
+        if (VRT_CHAIN_L2_POLL && !(spins & 1u)) {
+            // (only the lanes still waiting: a lane that holds a value keeps it)
+            const T2 a1 = load_agent_scope<T2>(rs, off1), a2 = load_agent_scope<T2>(rs, off2);
+            if (chain_is_sentinel(r1)) r1 = a1;
+            if (chain_is_sentinel(r2)) r2 = a2;
+        } else {
+            const T2 a1 = BufSc1<T2>::load(rs, off1), a2 = BufSc1<T2>::load(rs, off2);
+            if (chain_is_sentinel(r1)) r1 = a1;
+            if (chain_is_sentinel(r2)) r2 = a2;
+        }
         if (++spins > kChainDataSpins) {
             // (noted in the item's LDS words; chain_item reports it where the solver's registers are free again)
             const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(s_dep - kCtlWords))[kCtlGaveUp] = 1u;
