@@ -450,8 +450,10 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
                        bool f32, const PatchReduce *reduce);
 bool patch_chain_possible(const vrt_plan *p, int npair, bool f32);
 bool patch_chain_dataflag(const vrt_plan *p, int npair, bool f32);
+// ctrl_zeroed: the launch's control words (chain_ctrl_words() of them at p->d_chain_ctrl) were zeroed on `st` by the caller
 int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t st, bool f32, const PatchReduce *reduce,
-                       bool dataflag);
+                       bool dataflag, bool ctrl_zeroed = false);
+int chain_ctrl_words();
 int patch_chain_check(vrt_plan *p);
 
 }  // namespace vrt

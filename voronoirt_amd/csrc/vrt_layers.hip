@@ -266,7 +266,11 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     // chained launch with the intensities as their own flags (vrt_patch.hip: chain_data_wait): every plane is filled with
     // the NaN pattern first; the boundary kernel below then writes the boundary layer and the never-visited site's zero
     const bool chain_df = patches && A > 0 && patch_chain_possible(p, (int)(nl_pad / 2), kF32) && patch_chain_dataflag(p, (int)(nl_pad / 2), kF32);
-    if (chain_df) VRT_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p->d_I, (int)0x7FF87FF8u, (size_t)A * plane * sizeof(T) / 4, st));
+    // ... in ONE launch with the step's other preparations where those are a few microseconds each (k_chain_prepare)
+    const bool prep = chain_df && !kF32 && lb == 2 && nlam <= 16 && alpha_mode != VRT_ALPHA_ANGLE_SITE_LAM;
+    if (chain_df && !prep) VRT_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p->d_I, (int)0x7FF87FF8u, (size_t)A * plane * sizeof(T) / 4, st));
+    ChainPrep cp{};
+    bool prep_ctrl = false;
     const bool use_dir[2] = {p->n_up > 0, p->n_down > 0};
     for (int d = 0; d < 2; d++)
         if (use_dir[d] && (rc = ensure_dev(p->ws_S[d], p->ws_S_cap[d], dcount(plane)))) return rc;
@@ -337,7 +341,13 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         }
         const T *in2 = with_alpha ? dalpha : nullptr;
         T *out2 = with_alpha ? reinterpret_cast<T *>(p->ws_A[d]) : nullptr;
-        if (narrow)
+        if (prep) {
+            if constexpr (!kF32) {
+                cp.tin[cp.njob] = dS; cp.tout[cp.njob] = p->ws_S[d]; cp.torder[cp.njob] = dir.d_store; cp.njob++;
+                if (with_alpha) { cp.tin[cp.njob] = in2; cp.tout[cp.njob] = out2; cp.torder[cp.njob] = dir.d_store; cp.njob++; }
+                cp.n1[d] = dir.n1; cp.store[d] = dir.d_store; cp.rank[d] = dir.d_rank; cp.I0[d] = d == 0 ? dI0_up : dI0_down;
+            }
+        } else if (narrow)
             hipLaunchKernelGGL(k_to_sweep_order_narrow<T>, dim3(narrow_blocks, with_alpha ? 2 : 1), dim3(256), 0, st, n, (int)nlam, ld,
                                log2_pairs(lb), narrow_lgP, dir.d_store, dS, reinterpret_cast<T *>(p->ws_S[d]), in2, out2);
         else
@@ -351,11 +361,27 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             ta.alpha[d] = p->ws_A[d];
         }
         const int cnt = d == 0 ? p->n_up : p->n_down;
-        if (dir.n1 > 0) {
+        if (dir.n1 > 0 && !prep) {
             const dim3 bgrid((unsigned)((dir.n1 + 63) / 64), (unsigned)((nlam + 63) / 64), (unsigned)cnt);
             hipLaunchKernelGGL(k_boundary_sweep_order<T>, bgrid, dim3(256), 0, st, n, (int)nlam, lb, dir.n1,
                                d == 0 ? p->d_angles_up : p->d_angles_down, dir.d_order, dir.d_srank,
                                d == 0 ? dI0_up : dI0_down, wI);
+        }
+    }
+    if (prep) {
+        if constexpr (!kF32) {
+            cp.n = n; cp.ld = ld; cp.nlam = (int)nlam; cp.npair = (int)(nl_pad / 2); cp.lgP = narrow_lgP;
+            cp.tblocks = narrow_blocks;
+            cp.A = A;
+            cp.fblocks = (unsigned)cp.npair * (unsigned)((n + 1023) / 1024);
+            cp.I = p->d_I;
+            for (int a = 0; a < A; a++) cp.down[a] = p->dir_of_active[(size_t)a] > 0 ? 0 : 1;
+            cp.fill = 0x7FF87FF8u;
+            cp.ctrl = p->d_chain_ctrl;                 // (exists from the plan's first chained launch on)
+            cp.nctrl = chain_ctrl_words();
+            prep_ctrl = cp.ctrl != nullptr;
+            const unsigned blocks = (unsigned)cp.njob * cp.tblocks + (unsigned)A * cp.fblocks + (unsigned)((cp.nctrl + 255) / 256);
+            hipLaunchKernelGGL(k_chain_prepare, dim3(blocks), dim3(256), 0, st, cp);
         }
     }
     if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE) {
@@ -493,7 +519,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                         if ((p->dir_of_active[(size_t)a] > 0) == (d == 0)) red.angles[d][red.count[d]++] = a;
                     fused_dir[d] = use_dir[d];
                 }
-            if ((rc = launch_patch_chain(p, sa.ta, npair, st, kF32, dJ ? &red : nullptr, chain_df))) return rc;
+            if ((rc = launch_patch_chain(p, sa.ta, npair, st, kF32, dJ ? &red : nullptr, chain_df, prep_ctrl))) return rc;
             launches = 1;
             VRT_HIP_TRY(hipEventRecord(p->ev1, st));
         } else {

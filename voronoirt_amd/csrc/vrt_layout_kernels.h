@@ -82,6 +82,86 @@ k_to_sweep_order_narrow(int64_t n, int nlam, int64_t ld, int lgB, int lgP, const
     reinterpret_cast<typename Pair<T>::type *>(out)[pair_index(pr, pos, n, lgB, npair)] = v2;
 }
 
+// Everything a chained step of one or two wavelength pairs needs before its launch, in ONE launch (fp64 planes, pairs not
+// blocked): the narrow layout changes of S (and of a caller-layout alpha) of both directions, every intensity plane --
+// the boundary layer's I_0 (irregular_ray_tracing.jl:33: ordered like perm[1:n1]; the boundary layer is storage positions
+// [0, n1)), the never-visited site's zero (voronoi_utils.jl:266), the NaN pattern of the data-as-flag hand-off everywhere
+// else -- and the zeroed control words of the chained launch.  As six launches of 5-9 us each these were a tenth of a
+// C2 step (246 420 sites: 43 of 457 us); the fill is bandwidth, the rest is latency, and side by side they take the fill's time.
+struct ChainPrep {
+    int64_t n, ld;
+    int nlam, npair, lgP;
+    int njob;                              // layout changes: up to S and alpha of two directions
+    unsigned tblocks;                      // blocks per layout change
+    const double *tin[4];
+    double *tout[4];
+    const int32_t *torder[4];
+    int A;
+    unsigned fblocks;                      // blocks per angle of the intensity part: npair x ceil(n / 1024)
+    double *I;
+    int64_t n1[2];
+    const int32_t *store[2], *rank[2];     // storage position -> site, site -> sweep position, per direction
+    const double *I0[2];
+    unsigned char down[kMaxAngles];
+    uint32_t fill;
+    uint32_t *ctrl;                        // may be NULL (the chained launch then zeroes its words itself)
+    int nctrl;
+};
+__global__ void __launch_bounds__(256)
+k_chain_prepare(ChainPrep cp)
+{
+    unsigned b = blockIdx.x;
+    const unsigned tall = (unsigned)cp.njob * cp.tblocks;
+    if (b < tall) {                        // ---- layout change (k_to_sweep_order_narrow) ----
+        const int job = (int)(b / cp.tblocks);
+        const int64_t e = (int64_t)(b - (unsigned)job * cp.tblocks) * 256 + threadIdx.x;
+        const int64_t pos = e >> cp.lgP;
+        const int pr = (int)(e & ((1 << cp.lgP) - 1));
+        if (pos >= cp.n || pr >= cp.npair) return;
+        const double *row = cp.tin[job] + (size_t)cp.torder[job][pos] * cp.ld;
+        double2 v2;
+        v2.x = row[2 * pr];
+        v2.y = 2 * pr + 1 < cp.nlam ? row[2 * pr + 1] : 0.0;
+        reinterpret_cast<double2 *>(cp.tout[job])[pair_index(pr, pos, cp.n, 0, cp.npair)] = v2;
+        return;
+    }
+    b -= tall;
+    const unsigned fall = (unsigned)cp.A * cp.fblocks;
+    if (b < fall) {                        // ---- intensity planes ----
+        const int a = (int)(b / cp.fblocks);
+        const unsigned fb = b - (unsigned)a * cp.fblocks, pblocks = cp.fblocks / (unsigned)cp.npair;   // (block-uniform divisions)
+        const int q = (int)(fb / pblocks);
+        const int d = cp.down[a];
+        const int64_t plane = (int64_t)cp.npair * cp.n;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {          // 1024 positions per block: a quarter of the workgroups to dispatch
+        const int64_t pos = (int64_t)(fb - (unsigned)q * pblocks) * 1024 + k * 256 + threadIdx.x;
+        if (pos >= cp.n) return;
+        const int64_t e = (int64_t)q * cp.n + pos;
+        double2 v;
+        if (pos < cp.n1[d]) {
+            const double *I0 = cp.I0[d];
+            const int64_t j = cp.rank[d][cp.store[d][pos]];
+            v.x = I0 ? I0[(size_t)j * cp.nlam + 2 * q] : 0.0;
+            v.y = (I0 && 2 * q + 1 < cp.nlam) ? I0[(size_t)j * cp.nlam + 2 * q + 1] : 0.0;
+        } else if (pos == cp.n - 1) {
+            v = make_double2(0.0, 0.0);
+        } else {
+            const double f = __hiloint2double((int)cp.fill, (int)cp.fill);
+            v = make_double2(f, f);
+        }
+        // (streaming stores: 47 MB at C2's size that the chained launch reads with system-scope gathers anyway)
+        double *dst = cp.I + 2 * ((size_t)a * (size_t)plane + (size_t)e);
+        __builtin_nontemporal_store(v.x, dst);
+        __builtin_nontemporal_store(v.y, dst + 1);
+        }
+        return;
+    }
+    b -= fall;
+    const int w = (int)b * 256 + (int)threadIdx.x;
+    if (cp.ctrl && w < cp.nctrl) cp.ctrl[w] = 0u;
+}
+
 // out[p] = in[order[p]]   (per-site vector, e.g. wavelength-independent α)
 template <typename T>
 __global__ void __launch_bounds__(256)

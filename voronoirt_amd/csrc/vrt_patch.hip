@@ -1778,7 +1778,10 @@ static int launch_chain_mode(bool quad, bool dataflag, int64_t items, size_t lds
 
 // ONE launch for every layer of every active angle (and J_dir of both directions when `reduce` is given: its weights,
 // angle lists [0] = up, [1] = down and J_dir planes)
-int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t st, bool f32, const PatchReduce *reduce, bool dataflag)
+int chain_ctrl_words() { return kChainAbortWord + 4; }
+
+int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t st, bool f32, const PatchReduce *reduce, bool dataflag,
+                       bool ctrl_zeroed)
 {
     // a give-up of an EARLIER chained launch of this plan (its results were wrong) is reported here at the latest
     if (int rc0 = patch_chain_check(p)) return rc0;
@@ -1831,7 +1834,7 @@ int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t s
         p->chain_progress_fresh = false;
     }
     const uint32_t base = p->chain_epoch << 8;
-    VRT_HIP_TRY(hipMemsetAsync(p->d_chain_ctrl, 0, sizeof(uint32_t) * (kChainAbortWord + 4), st));
+    if (!ctrl_zeroed) VRT_HIP_TRY(hipMemsetAsync(p->d_chain_ctrl, 0, sizeof(uint32_t) * (kChainAbortWord + 4), st));
     const size_t lds = (size_t)(quad ? 2 : 1) * (size_t)(p->patch_cap + 1) * sizeof(double2) + (size_t)p->patch_cap * (4 * sizeof(double) + 5 * sizeof(int32_t)) +
                        sizeof(uint32_t) * (kCtlWords + 64 + kChainDepLds);
     const ChainDev *cd = reinterpret_cast<const ChainDev *>(p->d_chain_dev);
