@@ -822,3 +822,21 @@ def test_native_tessellation_errors():
     rc = L.vrt_tessellate(40, pos.ctypes.data_as(_lib.p_dbl), b.ctypes.data_as(_lib.p_dbl), 5,
                           M.ctypes.data_as(_lib.p_i64), ctypes.byref(mx))
     assert rc == _lib.VRT_EGRID
+
+
+@pytest.mark.parametrize("grid", ["bcc", "voronoi"])
+def test_storage_order_keeps_the_layers_contiguous(grid, bcc_small, voro_small):
+    """The storage order permutes sites only INSIDE a layer: layer l occupies the same positions as in the sweep order
+    (so the boundary layer is storage positions [0, n1) -- what k_chain_prepare relies on when it writes I_0 there by
+    position, vrt_layout_kernels.h), and the never-visited last site of the order stays at position n - 1."""
+    pos, nbr, bounds = bcc_small if grid == "bcc" else voro_small
+    so = orc.make_sites(pos, nbr, bounds)
+    hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)
+    for dirn, perm, lay in ((+1, so.perm_up, so.layers_up), (-1, so.perm_down, so.layers_down)):
+        store = hs.storage_order(dirn)
+        assert sorted(store) == list(range(1, so.n + 1))
+        assert store[-1] == perm[-1]
+        edges = [0] + [int(x) - 1 for x in lay[1:]]
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            hi = min(hi, so.n - 1)
+            assert set(store[lo:hi]) == set(perm[lo:hi])
