@@ -82,6 +82,12 @@ def parse_args(argv=None):
                          "(converted once before the timed region, the way a producer such as the "
                          "opacity prologue writes it) or in the caller's (n_angles, n, nlam) layout "
                          "(transposed inside every step)")
+    ap.add_argument("--sj-layout", default="auto", choices=["auto", "native", "caller"],
+                    help="S and J of the timed step: 'native' = the sweep's own per-direction plane sets, what the "
+                         "device-resident Λ-iteration (vrt_lambda_iterate) keeps between its steps -- no layout change "
+                         "in the step; 'caller' = (n, nlam) arrays in, J (n, nlam) out (two layout changes per step); "
+                         "auto: native for the per-angle-alpha (line) workloads on one GPU, the caller-layout time is "
+                         "reported beside it")
     ap.add_argument("--alpha0", type=float, default=1.0e-2,
                     help="opacity scale at z_min [1/m] (diagnostics: tiny values take the Taylor branch)")
     ap.add_argument("--dump-J", default="", help="rank 0 saves the (gathered) J of the last step as .npy")
@@ -104,7 +110,7 @@ ONE_TIME_KERNELS = ("k_upwind_table", "k_permute_table", "k_delaunay_lines", "k_
                     "k_gpos", "k_patch_entries")
 
 
-def pmc_traffic_per_step(workload, path, nlam, world, alpha_layout):
+def pmc_traffic_per_step(workload, path, nlam, world, alpha_layout, sj_layout="caller"):
     """Fabric-side bytes of ONE step from the committed rocprofv3 PMC passes of this same command
     (profiles/<round>/c4_summary.json; PMC counters cannot be read from inside the run).
     bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B): on gfx950 FETCH_SIZE tallies the 128-B requests
@@ -115,7 +121,7 @@ def pmc_traffic_per_step(workload, path, nlam, world, alpha_layout):
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "c4_summary.json")))
         if prof.get("source_digest") != source_digest() or prof.get("alpha_layout") != alpha_layout \
-                or prof.get("path") != path:
+                or prof.get("path") != path or prof.get("sj_layout", "caller") != sj_layout:
             return None
         total = 0.0
         for name, c in prof["pmc_one_step"].items():
@@ -237,6 +243,18 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
             ga = alpha[ch].contiguous() if per_angle else alpha
             groups.append((gp, ga, w_mine[ch], torch.zeros_like(J)))
 
+    # S and J in the sweep's own layout (vrt_plan_execute_native_dev): the device-resident Λ-iteration produces S and
+    # consumes J in this form (vrt_lambda_iterate), so its sweep step has no layout change; converted once, untimed
+    sj_native = (args.sj_layout == "native" or (args.sj_layout == "auto" and per_angle)) and alpha_native is not None \
+        and not f32 and groups is None and world == 1
+    S_nat = J_nat = None
+    if sj_native:
+        cnt = plan.native_plane_count(nlam)
+        S_nat = [torch.empty(cnt, device=dev, dtype=torch.float64) for _ in range(2)]
+        J_nat = [torch.zeros(cnt, device=dev, dtype=torch.float64) for _ in range(2)]
+        plan.to_native_dev(nlam, nlam, S.data_ptr(), S_nat[0].data_ptr(), S_nat[1].data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+
     gathered = {}     # lambda-strong: the gathered (n, nlam_total) J of the last step
     coll = {"op": None, "bytes_per_step": 0, "ms": 0.0, "calls": 0}
     coll_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -258,7 +276,11 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
                 gp.execute_dev(nlam, nlam, S.data_ptr(), ga.data_ptr(), alpha_mode, gw,
                                dJ=gJ.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
             return
-        if alpha_native is not None:
+        if sj_native:
+            plan.execute_native_dev(nlam, S_nat[0].data_ptr(), S_nat[1].data_ptr(), alpha_native.data_ptr(),
+                                    _lib.ALPHA_ANGLE_NATIVE, w_mine, dJ_up=J_nat[0].data_ptr(), dJ_down=J_nat[1].data_ptr(),
+                                    dI0_up=I0_up.data_ptr(), stream=stream)
+        elif alpha_native is not None:
             plan.execute_dev(nlam, nlam, S.data_ptr(), alpha_native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE,
                              w_mine, dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
         else:
@@ -297,9 +319,38 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     barrier()
     elapsed = time.perf_counter() - t0
     step_event_ms = ev0.elapsed_time(ev1) / steps
+    caller_layout = None
+    if sj_native:
+        # J in the caller's layout for the checks below; and the same step over the caller's layout, timed beside it
+        plan.J_from_native_dev(nlam, nlam, J_nat[0].data_ptr(), J_nat[1].data_ptr(), J.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        J_keep = J.clone()
+        sweep_keep = plan.last_sweep_timing()
+        sj_native = False
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        sj_native = True
+        c_ms = e0.elapsed_time(e1) / steps
+        caller_layout = {"ms_per_step": c_ms, "value": n * n_angles * nlam / (c_ms * 1e-3), "unit": "cell-updates/s",
+                         "bitwise_equal_J": bool(torch.equal(J, J_keep)),
+                         "note": "the same step through vrt_plan_execute_dev: S (n, nlam) in, J (n, nlam) out -- two layout "
+                                 "changes (k_to_sweep_order, k_combine_J) inside every step"}
+        step()                       # (the plan's last step is a native one again)
+        torch.cuda.synchronize()
+        J.copy_(J_keep)
+        del J_keep
     if groups is not None:
         tl = [gp.last_sweep_timing() for gp, _, _, _ in groups]
         sweep_ms, launches = sum(t[0] for t in tl), sum(t[1] for t in tl)
+    elif caller_layout is not None:
+        sweep_ms, launches = sweep_keep                   # (of the last TIMED step, taken before the caller-layout run)
     else:
         sweep_ms, launches = plan.last_sweep_timing()    # HIP events around the sweep launches, last step
     if world > 1:
@@ -328,9 +379,13 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
                         f"{' (native storage-pair layout)' if alpha_native is not None else ''}, n_sweeps=3",
             "sites": n, "angles": n_angles, "nlam_per_rank": nlam, "shard": shard,
             "alpha_layout": "native" if alpha_native is not None else "caller",
+            "sj_layout": "sweep order per direction (vrt_plan_execute_native_dev: what vrt_lambda_iterate keeps between its steps)"
+                         if sj_native else "caller (n, nlam)",
         },
         "setup_s": {"grid_generate": t_gen, "grid_create": t_grid, "plan_create": t_plan},
     }
+    if caller_layout is not None:
+        out["caller_layout"] = caller_layout
     if world > 1:
         out["collective"] = {"op": coll["op"] or "none (every rank owns whole rows of J)",
                              "bytes_per_step": coll["bytes_per_step"],
@@ -376,7 +431,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": pmc_traffic_per_step(workload, plan.last_path, nlam, world,
-                                        "native" if alpha_native is not None else "caller"),
+                                        "native" if alpha_native is not None else "caller", "native" if sj_native else "caller"),
         "kernel": {"levels": "k_sweep_level (one launch per dependency level)",
                    "steps": "k_step_coeffs + k_step_levels (two launches per BFS layer)",
                    "tiles": "k_sweep_tiles (one persistent launch)",

@@ -159,6 +159,31 @@ int vrt_plan_alpha_to_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const do
 int vrt_plan_alpha_to_native_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dalpha,
                                      float *dalpha_native, void *stream);
 
+/* ---- S and J in SWEEP ORDER (device entry points): what a device-resident Λ-iteration keeps between its steps ----
+ * The sweep reads S and reduces J per sweep direction in that direction's storage order; a caller that produces S and
+ * consumes J on the device (S_new = (1 - ε) J + ε B, the rate integrals: src/lambda_iteration.jl:261-263,
+ * src/rates.jl:154-201) can keep both in that form and save the two layout changes of every execute (1 M sites x 51
+ * wavelengths: 0.75 of 8.3 ms).  Per direction (up: θ > 90, down: θ < 90) ONE plane set of
+ * vrt_plan_native_plane_count(p, nlam) doubles: element (l, pos) at ((l/2) * n + pos) * 2 + l%2, pos = the site's
+ * position in vrt_grid_get_storage_order of the direction; an odd nlam is padded with one wavelength (S: any finite
+ * value, J: unspecified).  Needs a plan on a layer path with VRT_PAIR_BLOCK=1 (the default for doubles). */
+int64_t vrt_plan_native_plane_count(const vrt_plan *p, int64_t nlam);
+/* caller's (nlam, n) array with leading dimension ld -> the plane sets of both directions (either may be NULL) */
+int vrt_plan_to_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *d_in, double *d_up, double *d_down,
+                           void *stream);
+/* the plane set of ONE direction (dir > 0: up) -> the caller's (nlam, n) array */
+int vrt_plan_from_native_dev(vrt_plan *p, int dir, int64_t nlam, int64_t ld, const double *d_native, double *d_out,
+                             void *stream);
+/* J[site][l] = J_up + J_down (a direction without angles: NULL), the sum vrt_plan_execute_dev forms itself */
+int vrt_plan_j_from_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dJ_up, const double *dJ_down,
+                               double *dJ, void *stream);
+/* vrt_plan_execute_dev with S read from and J reduced into sweep-order plane sets, in place.  alpha_mode:
+ * VRT_ALPHA_SITE or VRT_ALPHA_ANGLE_NATIVE.  dJ_up / dJ_down: both or neither; the plane set of a direction without
+ * angles comes back zeroed.  The results are those of vrt_plan_execute_dev bit for bit (J = J_up + J_down). */
+int vrt_plan_execute_native_dev(vrt_plan *p, int64_t nlam, const double *dS_up, const double *dS_down,
+                                const double *dalpha, int alpha_mode, const double *dI0_up, const double *dI0_down,
+                                const double *weights_host, double *dJ_up, double *dJ_down, void *stream);
+
 /* fp32 VALUE path (BASELINE config C5): S, alpha, I_0, J and the per-angle intensities are stored
  * as float, halving the bytes of this bandwidth-bound path; the geometry tables and all
  * arithmetic stay fp64.  Results agree with the fp64 solve to fp32 storage rounding (~1e-6
@@ -173,6 +198,12 @@ int vrt_plan_execute_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float 
  * waiting for a dependency -- a bounded spin expired: the results of that execute are invalid; also reported by the
  * next execute of the plan) */
 int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches);
+/* VRT_OK, or the give-up of a chained patch launch that has finished since the last check (VRT_ENODEVICE: the results of
+ * that execute are invalid).  The entry points that synchronise themselves (vrt_plan_execute, vrt_plan_execute_line,
+ * vrt_lambda_iterate, vrt_multi_*) report it from the call it spoiled; a caller of the ASYNCHRONOUS entry points
+ * (vrt_plan_execute_dev, _native_dev, _f32) calls this -- or vrt_plan_last_sweep_timing -- after it has synchronised
+ * its stream.  No synchronisation here. */
+int vrt_plan_check(vrt_plan *p);
 /* which device path the last execute took: 1 = "levels" (one launch per dependency level),
  * 2 = "tiles" (one persistent launch), 3 = "steps" (two launches per BFS layer), 4 = "patches" (layers cut
  * into patches, the default: ONE chained launch for every layer, or one fused launch per BFS layer); 0 = none yet.  The paths give the

@@ -1166,3 +1166,89 @@ def test_closing_the_grid_closes_its_plans(bcc_small):
     plan.close()
     with pytest.raises(Exception):
         plan.execute(np.ones((hs.n, 1)), np.ones(hs.n))
+
+
+@pytest.mark.parametrize("grid", ["bcc", "voronoi"])
+@pytest.mark.parametrize("nlam, pathopt", [(3, "auto"), (7, "auto"), (22, "auto"), (5, "steps"), (22, "patches-launches")])
+def test_sweep_order_S_and_J_are_the_caller_layout_results_bit_for_bit(grids, monkeypatch, grid, nlam, pathopt):
+    """vrt_plan_execute_native_dev: S read from and J reduced into the sweep's own per-direction plane sets -- what a
+    device-resident Λ-iteration keeps between its steps (lambda_iteration.jl:261-263 produces S, rates.jl:154-201 consume J).
+    J_up + J_down equals the J of vrt_plan_execute_dev bit for bit (chained launch, per-layer launches, the steps
+    path; odd and even wavelength counts; per-site and native per-angle alpha), the layout helpers round-trip, an
+    up-only plan hands back a zero J_down, and the J itself is checked against the oracle."""
+    import torch
+    monkeypatch.delenv("VRT_PATH", raising=False)
+    hs, so = grids[grid]
+    n = so.n
+    rng = np.random.default_rng(nlam)
+    S = 1.0 + rng.random((n, nlam))
+    al1 = 10.0 ** rng.uniform(-3, 1, n)
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    n1 = int(so.layers_up[1] - 1)
+    I0 = S[so.perm_up[:n1] - 1].copy()
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    if pathopt == "steps":
+        plan.set_option("VRT_PATH", "steps")
+    if pathopt == "patches-launches":
+        plan.set_option("VRT_PATCH_CHAIN", 0)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    dS, dA1, dI0 = t(S), t(al1), t(I0)
+    np_ = plan.native_plane_count(nlam)
+    assert np_ == (nlam + 1) // 2 * 2 * n
+    S_up, S_dn = (torch.full((np_,), 7.0, dtype=torch.float64, device=dev) for _ in range(2))
+    plan.to_native_dev(nlam, nlam, dS.data_ptr(), S_up.data_ptr(), S_dn.data_ptr(), stream=st)
+    # the layout: element (l, pos) at ((l / 2) n + pos) 2 + l % 2, pos along the direction's storage order
+    for d, buf in ((1, S_up), (-1, S_dn)):
+        order = hs.storage_order(d) - 1
+        planes = buf.cpu().numpy().reshape((nlam + 1) // 2, n, 2)
+        for l in (0, nlam - 1):
+            assert np.array_equal(planes[l // 2, :, l % 2], S[order, l])
+        back = torch.zeros((n, nlam), dtype=torch.float64, device=dev)
+        plan.from_native_dev(d, nlam, nlam, buf.data_ptr(), back.data_ptr(), stream=st)
+        assert torch.equal(back, dS)
+    for mode in ("site", "native"):
+        if mode == "site":
+            dal, am = dA1, _lib.ALPHA_SITE
+            al_ref = np.repeat(al1[:, None], nlam, axis=1)
+        else:
+            al3 = np.stack([np.repeat(al1[:, None], nlam, axis=1) * (1 + 0.03 * i + 0.01 * np.arange(nlam)[None, :]) for i in range(nq)])
+            d3 = t(al3)
+            dal = torch.empty(plan.native_alpha_count(nlam), dtype=torch.float64, device=dev)
+            plan.alpha_to_native_dev(nlam, nlam, d3.data_ptr(), dal.data_ptr(), stream=st)
+            am = _lib.ALPHA_ANGLE_NATIVE
+            al_ref = al3
+        J = torch.zeros((n, nlam), dtype=torch.float64, device=dev)
+        plan.execute_dev(nlam, nlam, dS.data_ptr(), dal.data_ptr(), am, w, dJ=J.data_ptr(), dI0_up=dI0.data_ptr(), stream=st)
+        path_a = plan.last_path
+        J_up, J_dn = (torch.full((np_,), -3.0, dtype=torch.float64, device=dev) for _ in range(2))
+        plan.execute_native_dev(nlam, S_up.data_ptr(), S_dn.data_ptr(), dal.data_ptr(), am, w, dJ_up=J_up.data_ptr(),
+                                dJ_down=J_dn.data_ptr(), dI0_up=dI0.data_ptr(), stream=st)
+        assert plan.last_path == path_a == ("steps" if pathopt == "steps" else "patches")
+        Jn = torch.zeros((n, nlam), dtype=torch.float64, device=dev)
+        plan.J_from_native_dev(nlam, nlam, J_up.data_ptr(), J_dn.data_ptr(), Jn.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        plan.check()
+        assert torch.equal(J, Jn)
+        if mode == "site" or nlam <= 7:
+            ref = orc.J_voronoi(w, th, ph, S, al_ref, so, I0_up=I0, nthreads=8)
+            assert _rel(Jn.cpu().numpy(), ref) < RTOL
+    # the caller-layout alphas carry the caller's leading dimension: refused with sweep-order S
+    with pytest.raises(vrt.VrtError):
+        plan.execute_native_dev(nlam, S_up.data_ptr(), S_dn.data_ptr(), dS.data_ptr(), _lib.ALPHA_SITE_LAM, w,
+                                dJ_up=J_up.data_ptr(), dJ_down=J_dn.data_ptr(), stream=st)
+    plan.close()
+    # a plan with up rays only: J_down comes back as zeros, S_down is not needed
+    up_only = [i for i in range(nq) if th[i] > 90]
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th[up_only], ph[up_only]), 3)
+    J = torch.zeros((n, nlam), dtype=torch.float64, device=dev)
+    plan.execute_dev(nlam, nlam, dS.data_ptr(), dA1.data_ptr(), _lib.ALPHA_SITE, w[up_only], dJ=J.data_ptr(), dI0_up=dI0.data_ptr(), stream=st)
+    J_up, J_dn = (torch.full((np_,), -3.0, dtype=torch.float64, device=dev) for _ in range(2))
+    plan.execute_native_dev(nlam, S_up.data_ptr(), 0, dA1.data_ptr(), _lib.ALPHA_SITE, w[up_only], dJ_up=J_up.data_ptr(),
+                            dJ_down=J_dn.data_ptr(), dI0_up=dI0.data_ptr(), stream=st)
+    Jn = torch.zeros((n, nlam), dtype=torch.float64, device=dev)
+    plan.J_from_native_dev(nlam, nlam, J_up.data_ptr(), J_dn.data_ptr(), Jn.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert torch.equal(J, Jn) and float(J_dn.abs().max()) == 0.0
+    plan.close()

@@ -27,7 +27,7 @@ void tuning_from_env(Tuning &t)
     static const char *names[] = {"VRT_PATH", "VRT_STEP_K", "VRT_STEP_SINGLE", "VRT_STEP_PAIRS", "VRT_STEP_XCD",
                                   "VRT_STEP_STREAMS", "VRT_STEP_LEVEL_MAP", "VRT_STEP_GROUP_DIR", "VRT_TILE_WIDE",
                                   "VRT_TILE_PRE", "VRT_GRAPH", "VRT_PATCH_K", "VRT_PATCH_NT", "VRT_PATCH_OWN",
-                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_QUAD", "VRT_PATCH_LEAN", "VRT_PATCH_CHAIN", "VRT_CHAIN_PAIRS", "VRT_CHAIN_SPIN", "VRT_CHAIN_DATAFLAG", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
+                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_QUAD", "VRT_PATCH_LEAN", "VRT_PATCH_CHAIN", "VRT_CHAIN_PAIRS", "VRT_CHAIN_SPIN", "VRT_CHAIN_DATAFLAG", "VRT_LAMBDA_NATIVE", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
                                   "VRT_TILE_DEBUG"};
     for (const char *nm : names) {
         const char *e = std::getenv(nm);
@@ -70,7 +70,8 @@ int tuning_set(Tuning &t, const char *name, const char *value, bool created)
         {"VRT_PATCH_TARGET", &t.patch_target, 1, 1 << 20, false}, {"VRT_PAIR_BLOCK", &t.pair_block, 1, 16, true},
         {"VRT_PATCH_QUAD", &t.patch_quad, 0, 1, true}, {"VRT_PATCH_LEAN", &t.patch_lean, 0, 1, false},
         {"VRT_PATCH_CHAIN", &t.patch_chain, 0, 2, false}, {"VRT_CHAIN_PAIRS", &t.chain_pairs, 1, 256, false},
-        {"VRT_CHAIN_SPIN", &t.chain_spin, 1, 1 << 20, false}, {"VRT_CHAIN_DATAFLAG", &t.chain_dataflag, 0, 2, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
+        {"VRT_CHAIN_SPIN", &t.chain_spin, 1, 1 << 20, false}, {"VRT_CHAIN_DATAFLAG", &t.chain_dataflag, 0, 2, false},
+        {"VRT_LAMBDA_NATIVE", &t.lambda_native, 0, 1, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
         {"VRT_DEBUG_SKIP_LEVELS", &t.debug_skip_levels, 0, 1, false}, {"VRT_TILE_DEBUG", &t.tile_debug, 0, 1, false},
     };
     for (auto &o : tab)
@@ -857,6 +858,32 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_, c
     return VRT_OK;
 }
 
+int execute_native_locked(vrt_plan *p, int64_t nlam, const double *dS_up, const double *dS_down, const void *dalpha, int alpha_mode,
+                          const double *dI0_up, const double *dI0_down, const double *weights, double *dJ_up, double *dJ_down,
+                          hipStream_t st)
+{
+    int rc = native_planes_ok(p);
+    if (rc) return rc;
+    if ((p->n_up > 0 && !dS_up) || (p->n_down > 0 && !dS_down)) return fail(VRT_EINVAL, "S of a direction with angles must not be NULL");
+    if (!dJ_up != !dJ_down) return fail(VRT_EINVAL, "J_up and J_down must be given together (or both NULL)");
+    if (alpha_mode != VRT_ALPHA_SITE && alpha_mode != VRT_ALPHA_ANGLE_NATIVE)
+        return fail(VRT_EINVAL, "sweep-order S goes with alpha per site (0) or native per angle (3): the other layouts carry the caller's leading dimension");
+    // (the level path -- grids whose schedule does not fit the layer kernels -- keeps the caller's layout)
+    const int keep = p->tune.path;
+    if (keep == 1 || keep == 2) p->tune.path = 0;
+    p->nat_S[0] = dS_up; p->nat_S[1] = dS_down;
+    p->nat_J[0] = dJ_up; p->nat_J[1] = dJ_down;
+    p->nat_mode = true;
+    const double *anyS = dS_up ? dS_up : dS_down;
+    rc = execute_dev_locked(p, nlam, (nlam + 1) / 2 * 2, anyS, dalpha, alpha_mode, dI0_up, dI0_down, weights, dJ_up, nullptr, st);
+    p->nat_mode = false;
+    p->nat_S[0] = p->nat_S[1] = nullptr;
+    p->nat_J[0] = p->nat_J[1] = nullptr;
+    p->tune.path = keep;
+    if (!rc && p->last_path != 3 && p->last_path != 4) return fail(VRT_EINVAL, "sweep-order S and J: the plan did not run on a layer path");
+    return rc;
+}
+
 }  // namespace vrt
 
 using namespace vrt;
@@ -1346,6 +1373,78 @@ int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS
     }
 }
 
+int64_t vrt_plan_native_plane_count(const vrt_plan *p, int64_t nlam)
+{
+    if (!p || nlam < 1) return 0;
+    return ((nlam + 1) / 2 * 2) * p->g->n;
+}
+
+int vrt_plan_to_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *d_in, double *d_up, double *d_down, void *stream)
+{
+    DeviceScope scope;
+    if (!p || !d_in || (!d_up && !d_down)) return fail(VRT_EINVAL, "NULL argument");
+    if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        int rc = use_device(p->g->device);
+        if (!rc) rc = native_planes_ok(p);
+        if (rc) return rc;
+        return planes_to_native(p, nlam, ld, d_in, d_up, d_down, (hipStream_t)stream);
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_plan_from_native_dev(vrt_plan *p, int dir, int64_t nlam, int64_t ld, const double *d_native, double *d_out, void *stream)
+{
+    DeviceScope scope;
+    if (!p || !d_native || !d_out) return fail(VRT_EINVAL, "NULL argument");
+    if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        int rc = use_device(p->g->device);
+        if (!rc) rc = native_planes_ok(p);
+        if (rc) return rc;
+        return plane_from_native(p, dir > 0 ? 0 : 1, nlam, ld, d_native, d_out, (hipStream_t)stream);
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_plan_j_from_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dJ_up, const double *dJ_down, double *dJ,
+                               void *stream)
+{
+    DeviceScope scope;
+    if (!p || !dJ || (!dJ_up && !dJ_down)) return fail(VRT_EINVAL, "NULL argument");
+    if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        int rc = use_device(p->g->device);
+        if (!rc) rc = native_planes_ok(p);
+        if (rc) return rc;
+        return J_from_native(p, nlam, ld, dJ_up, dJ_down, dJ, (hipStream_t)stream);
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_plan_execute_native_dev(vrt_plan *p, int64_t nlam, const double *dS_up, const double *dS_down, const double *dalpha,
+                                int alpha_mode, const double *dI0_up, const double *dI0_down, const double *weights_host,
+                                double *dJ_up, double *dJ_down, void *stream)
+{
+    DeviceScope scope;
+    if (!p) return fail(VRT_EINVAL, "NULL plan");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        return execute_native_locked(p, nlam, dS_up, dS_down, dalpha, alpha_mode, dI0_up, dI0_down, weights_host, dJ_up, dJ_down,
+                                     (hipStream_t)stream);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
 int vrt_plan_execute_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dS,
                              const float *dalpha, int alpha_mode, const float *dI0_up,
                              const float *dI0_down, const double *weights_host, float *dJ,
@@ -1417,12 +1516,19 @@ int vrt_plan_execute(vrt_plan *p, int64_t nlam, int64_t ld, const double *S, con
             VRT_HIP_TRY(hipMemcpyAsync(I_out, dIo, sizeof(double) * nS * (size_t)p->n_angles_user,
                                        hipMemcpyDeviceToHost, st));
         VRT_HIP_TRY(hipStreamSynchronize(st));
-        return VRT_OK;
+        return patch_chain_check(p);         // a chained sweep that gave up waiting: THIS call's results are invalid
     } catch (const std::bad_alloc &) {
         return fail(VRT_ENOMEM, "out of host memory");
     } catch (...) {
         return fail(VRT_EINVAL, "unexpected exception");
     }
+}
+
+int vrt_plan_check(vrt_plan *p)
+{
+    if (!p) return fail(VRT_EINVAL, "NULL plan");
+    std::lock_guard<std::mutex> lock(p->mu);
+    return patch_chain_check(p);
 }
 
 int vrt_plan_last_sweep_timing(const vrt_plan *p, double *ms, int64_t *launches)

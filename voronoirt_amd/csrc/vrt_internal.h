@@ -138,6 +138,8 @@ struct Tuning {
     int chain_dataflag = 2;       // VRT_CHAIN_DATAFLAG: the chained launch's intensities as their own flags: 0 never, 1 wherever
                                   //   the kernel exists, 2 auto (one or two wavelength pairs: the planes are filled per step)
     int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
+    int lambda_native = 1;        // VRT_LAMBDA_NATIVE: the Λ-iteration session keeps S and J in sweep order between its steps
+                                  //   (read when a session is created; 0: the caller's layout, two layout changes per iteration)
     int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)
 };
 void tuning_from_env(Tuning &t);
@@ -303,6 +305,12 @@ struct vrt_plan {
     std::vector<vrt::CopyLane> copy_lanes;      // host-pointer entry points (ensure_copy_lanes)
     hipEvent_t copy_done = nullptr;
     int64_t last_launches = 0;
+    // sweep-order ("native") S and J of the call in progress (vrt_plan_execute_native_dev; set and cleared under `mu`):
+    // per sweep direction (0 up, 1 down) a plane set [pairs][n][2] in that direction's storage order, read / written in
+    // place by the layer paths instead of the workspaces behind the layout changes
+    const void *nat_S[2] = {nullptr, nullptr};
+    void *nat_J[2] = {nullptr, nullptr};
+    bool nat_mode = false;
     std::mutex mu;
 };
 
@@ -394,6 +402,9 @@ int launch_gather_rows(int64_t rows, int64_t nlam, int64_t ld, const int32_t *d_
 int launch_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *dJ, const double *dB,
                          const double *deps, const double *dS_old, double *dS_new,
                          unsigned long long *d_result, hipStream_t st);
+// the same on sweep-order planes (J_up, J_down in, B in the up order, S_up updated in place, S_down written)
+int launch_lambda_update_native(vrt_grid *g, int64_t nlam, const double *dJ_up, const double *dJ_down, const double *dB_up,
+                                const double *deps, double *dS_up, double *dS_down, unsigned long long *d_result, hipStream_t st);
 
 // ---- physics either side of the formal solve (vrt_physics.hip) -------------------------------------
 int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, double lambda0, double c0,
@@ -407,7 +418,8 @@ int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_
                              const double *d_doppler, const double *d_gamma, double sigma_bb_const,
                              const double *d_temperature, const double *d_lte, double hc_over_kB,
                              double pref_ij, double pref_ji, const double *d_C, const double *d_atom_density,
-                             double *d_R, double *d_populations, hipStream_t st);
+                             double *d_R, double *d_populations, hipStream_t st,
+                             const double *dJ_up = nullptr, const double *dJ_down = nullptr);   // sweep-order J instead of dJ
 
 int launch_rates_partial(vrt_grid *g, int64_t nlam, int64_t l0, int64_t l1, int64_t ld, const int64_t blocks[6],
                          const double *d_small, const double *dJ, double lambda0, double c0, const double *d_doppler,
@@ -435,6 +447,15 @@ inline int native_lg(const vrt_plan *p, bool f32)
     return f32 && p->tune.patch_quad != 0 && p->patch_K == 1 ? std::max(p->lg_pair_block, 1) : p->lg_pair_block;
 }
 int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const void *dalpha, void *out, hipStream_t st, bool f32);
+// sweep-order S and J (per direction [pairs][n][2] in that direction's storage order)
+int native_planes_ok(const vrt_plan *p);
+int planes_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *din, double *out_up, double *out_down, hipStream_t st);
+int plane_from_native(vrt_plan *p, int dir_index, int64_t nlam, int64_t ld, const double *din, double *dout, hipStream_t st);
+int J_from_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *dJ_up, const double *dJ_down, double *dJ, hipStream_t st);
+// the sweep with S read from / J reduced into the caller's sweep-order planes (caller holds p->mu)
+int execute_native_locked(vrt_plan *p, int64_t nlam, const double *dS_up, const double *dS_down, const void *dalpha, int alpha_mode,
+                          const double *dI0_up, const double *dI0_down, const double *weights, double *dJ_up, double *dJ_down,
+                          hipStream_t st);
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, const void *dalpha,
                   int alpha_mode, const void *dI0_up, const void *dI0_down,
                   const double *weights_user, void *dJ, void *dI_out, hipStream_t st, bool f32);

@@ -480,6 +480,77 @@ k_lambda_update(int64_t n, int64_t nlam, int64_t ld, const double *__restrict__ 
     }
 }
 
+// The same on sweep-order planes (vrt_plan_execute_native_dev): one thread per (wavelength pair, up position).  J = J_up +
+// J_down as k_combine_J forms it, S_new = (1 - ε) J + ε B with B in the up order, the old S read from the plane it is
+// written back to, the down-order copy of S_new written beside it -- the operations of k_lambda_update on the same values,
+// so S, J and the criterion are those of the caller-layout loop bit for bit, without either layout change.
+__global__ void __launch_bounds__(256)
+k_lambda_update_native(int64_t n, int npair, int nlam, const int32_t *__restrict__ store_up, const int32_t *__restrict__ rank_down,
+                       const double2 *__restrict__ Ju, const double2 *__restrict__ Jd, const double2 *__restrict__ Bu,
+                       const double *__restrict__ eps, double2 *__restrict__ Su, double2 *__restrict__ Sd,
+                       unsigned long long *__restrict__ result)
+{
+    __shared__ double wmax[4];
+    __shared__ int wnan[4];
+    const int64_t total = (int64_t)npair * n;
+    double d = 0.0;
+    bool isnan_ = false;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = t / n, pos = t - q * n;
+        const int32_t site = store_up[pos];
+        const int32_t pd = rank_down[site];
+        double2 J = make_double2(0.0, 0.0);
+        if (Ju) J = Ju[t];
+        if (Jd) {
+            const double2 u = Jd[(size_t)q * (size_t)n + (size_t)pd];
+            J.x = J.x + u.x; J.y = J.y + u.y;
+        }
+        const double e = eps[site];
+        const double2 B = Bu[t], So = Su[t];
+        double2 Sn;
+        Sn.x = (1.0 - e) * J.x + e * B.x;
+        Sn.y = (1.0 - e) * J.y + e * B.y;
+        const bool second = 2 * q + 1 < nlam;                  // (an odd count: the padding wavelength is carried as zeros)
+        if (!second) Sn.y = 0.0;
+        Su[t] = Sn;
+        Sd[(size_t)q * (size_t)n + (size_t)pd] = Sn;
+        const double dx = fabs(1.0 - So.x / Sn.x);
+        if (!(dx == dx)) isnan_ = true;
+        else d = fmax(d, dx);
+        if (second) {
+            const double dy = fabs(1.0 - So.y / Sn.y);
+            if (!(dy == dy)) isnan_ = true;
+            else d = fmax(d, dy);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d = fmax(d, __shfl_xor(d, off, 64));
+    const unsigned long long any_nan = __ballot(isnan_);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { wmax[wave] = d; wnan[wave] = any_nan != 0ull; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double m = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+        atomicMax(&result[0], (unsigned long long)__double_as_longlong(m));
+        if (wnan[0] | wnan[1] | wnan[2] | wnan[3]) atomicMax(&result[1], 1ull);
+    }
+}
+
+int launch_lambda_update_native(vrt_grid *g, int64_t nlam, const double *dJ_up, const double *dJ_down, const double *dB_up,
+                                const double *deps, double *dS_up, double *dS_down, unsigned long long *d_result, hipStream_t st)
+{
+    VRT_HIP_TRY(hipMemsetAsync(d_result, 0, 2 * sizeof(unsigned long long), st));
+    const int npair = (int)((nlam + 1) / 2);
+    const int64_t total = (int64_t)npair * g->n;
+    const int64_t blocks = std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_lambda_update_native, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), 0, st, g->n, npair, (int)nlam,
+                       g->up.d_store, g->down.d_srank, reinterpret_cast<const double2 *>(dJ_up), reinterpret_cast<const double2 *>(dJ_down),
+                       reinterpret_cast<const double2 *>(dB_up), deps, reinterpret_cast<double2 *>(dS_up),
+                       reinterpret_cast<double2 *>(dS_down), d_result);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 // dst += src (partial J's of two handles on one device: vrt_multi's same-device rehearsal)
 __global__ void __launch_bounds__(256)
 k_axpy(size_t count, const double *__restrict__ src, double *__restrict__ dst)

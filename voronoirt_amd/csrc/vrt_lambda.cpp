@@ -160,6 +160,11 @@ struct vrt_lambda {
     double *d_S_old = nullptr, *d_S_new = nullptr, *d_J = nullptr, *d_I0 = nullptr, *d_native = nullptr;
     unsigned long long *d_scalars = nullptr;
     int iterations = 0;
+    // S and J in sweep order between the steps of an iteration (VRT_LAMBDA_NATIVE, default): the update kernel writes S where
+    // the sweep reads it, the sweep reduces J where the update and the rate integrals read it -- no layout change inside
+    // the loop; d_S_new / d_S_old / d_J (the caller's layout) then exist only while vrt_lambda_get fills them
+    bool native = false;
+    double *d_S_nat[2] = {nullptr, nullptr}, *d_J_nat[2] = {nullptr, nullptr}, *d_B_up = nullptr;
 };
 
 static void lambda_free(vrt_lambda *s)
@@ -167,7 +172,8 @@ static void lambda_free(vrt_lambda *s)
     if (!s) return;
     for (double *q : {s->d_small, s->d_velocity, s->d_doppler, s->d_gamma_static, s->d_gamma_unsold, s->d_alpha_cont,
                       s->d_eps, s->d_temperature, s->d_atom, s->d_B0, s->d_lte, s->d_C, s->d_gamma, s->d_strength,
-                      s->d_pops, s->d_pops_new, s->d_R, s->d_S_old, s->d_S_new, s->d_J, s->d_I0, s->d_native})
+                      s->d_pops, s->d_pops_new, s->d_R, s->d_S_old, s->d_S_new, s->d_J, s->d_I0, s->d_native, s->d_S_nat[0],
+                      s->d_S_nat[1], s->d_J_nat[0], s->d_J_nat[1], s->d_B_up})
         if (q) (void)hipFree(q);
     if (s->d_scalars) (void)hipFree(s->d_scalars);
     delete s;
@@ -303,7 +309,7 @@ int vrt_plan_execute_line(vrt_plan *p, int64_t nlam, int64_t ld, const double *l
         }
 #endif
         VRT_HIP_TRY(hipStreamSynchronize(st));
-        return VRT_OK;
+        return patch_chain_check(p);         // a chained sweep that gave up waiting: THIS call's J is invalid
     } catch (const std::bad_alloc &) {
         return fail(VRT_ENOMEM, "out of host memory");
     } catch (...) {
@@ -368,9 +374,22 @@ int vrt_lambda_create(vrt_plan *p, const vrt_line_case *lc, const double *weight
         VRT_S(upload(&s->d_lte, lc->lte_populations, 3 * n, st));
         VRT_S(upload(&s->d_C, lc->C, 9 * n, st));
         VRT_S(upload(&s->d_pops, lc->lte_populations, 3 * n, st));        // populations = copy(LTE_pops), :232
+        s->native = p->tune.lambda_native != 0 && native_planes_ok(p) == VRT_OK && p->tune.path != 1 && p->tune.path != 2;
+        if (s->native) {
+            const size_t np = (size_t)vrt_plan_native_plane_count(p, nlam);
+            for (int d = 0; d < 2; d++) {
+                VRT_S(dalloc(&s->d_S_nat[d], np));
+                VRT_S(dalloc(&s->d_J_nat[d], np));
+                if (hipMemsetAsync(s->d_J_nat[d], 0, sizeof(double) * np, st) != hipSuccess) { lambda_free(s); return fail(VRT_ENODEVICE, "hipMemsetAsync failed"); }
+            }
+            VRT_S(dalloc(&s->d_B_up, np));
+            VRT_S(planes_to_native(p, nlam, nlam, s->d_B0, s->d_S_nat[0], s->d_S_nat[1], st));      // S_new = B_0, :236-239
+            VRT_S(planes_to_native(p, nlam, nlam, s->d_B0, s->d_B_up, nullptr, st));
+        } else {
         VRT_S(upload(&s->d_S_new, lc->B0, n * nl, st));                   // S_new = B_0, :236-239
         VRT_S(dalloc(&s->d_S_old, n * nl));
         VRT_S(dalloc(&s->d_J, n * nl));
+        }
         VRT_S(dalloc(&s->d_gamma, n));
         VRT_S(dalloc(&s->d_strength, n));
         VRT_S(dalloc(&s->d_pops_new, 3 * n));
@@ -378,8 +397,9 @@ int vrt_lambda_create(vrt_plan *p, const vrt_line_case *lc, const double *weight
         VRT_S(dalloc(&s->d_I0, (size_t)g->up.n1 * nl));
         VRT_S(dalloc(&s->d_native, (size_t)vrt_plan_native_alpha_count(p, nlam)));
         VRT_S(dalloc(&s->d_scalars, 2));
-        if (hipMemsetAsync(s->d_S_old, 0, sizeof(double) * n * nl, st) != hipSuccess ||      // S_old = zero(S_new), :240
-            hipMemsetAsync(s->d_J, 0, sizeof(double) * n * nl, st) != hipSuccess) {
+        if (!s->native &&
+            (hipMemsetAsync(s->d_S_old, 0, sizeof(double) * n * nl, st) != hipSuccess ||      // S_old = zero(S_new), :240
+             hipMemsetAsync(s->d_J, 0, sizeof(double) * n * nl, st) != hipSuccess)) {
             lambda_free(s);
             return fail(VRT_ENODEVICE, "hipMemsetAsync failed");
         }
@@ -411,7 +431,8 @@ int vrt_lambda_iterate(vrt_lambda *s, double *max_rel_change)
         hipStream_t st = g->stream;
         const int64_t n = s->n, nlam = s->nlam;
         const size_t bytes = sizeof(double) * (size_t)n * (size_t)nlam;
-        VRT_HIP_TRY(hipMemcpyAsync(s->d_S_old, s->d_S_new, bytes, hipMemcpyDeviceToDevice, st));     // S_old = copy(S_new), :258
+        if (!s->native)
+            VRT_HIP_TRY(hipMemcpyAsync(s->d_S_old, s->d_S_new, bytes, hipMemcpyDeviceToDevice, st));     // S_old = copy(S_new), :258
         // γ and the line strength of the current populations (:72-75, line.jl:219-225), α_tot of every angle (:89-96)
         if ((rc = launch_line_terms(n, s->d_gamma_static, s->d_gamma_unsold, s->d_pops, s->strength_const, s->Bij,
                                     s->Bji, s->d_gamma, s->d_strength, st)))
@@ -419,6 +440,21 @@ int vrt_lambda_iterate(vrt_lambda *s, double *max_rel_change)
         if ((rc = launch_line_opacity(p, nlam, s->d_small, s->lambda0, s->c0, s->d_velocity, s->d_doppler, s->d_gamma,
                                       s->d_strength, s->d_alpha_cont, s->d_native, st)))
             return rc;
+        if (s->native) {
+            // J_λ (:84-111) from the sweep-order S into the sweep-order J; S_new and the criterion (:261-263, :325-349: the old
+            // S is read from the plane the new one is written to); R and the populations (:269, :274) from the same J planes
+            if ((rc = execute_native_locked(p, nlam, s->d_S_nat[0], s->d_S_nat[1], s->d_native, VRT_ALPHA_ANGLE_NATIVE, s->d_I0, nullptr,
+                                            s->weights.data(), s->d_J_nat[0], s->d_J_nat[1], st)))
+                return rc;
+            if ((rc = launch_lambda_update_native(g, nlam, s->d_J_nat[0], s->d_J_nat[1], s->d_B_up, s->d_eps, s->d_S_nat[0],
+                                                  s->d_S_nat[1], s->d_scalars, st)))
+                return rc;
+            if ((rc = launch_rates_populations(g, nlam, nlam, s->blocks, s->d_small, nullptr, s->lambda0, s->c0, s->d_doppler,
+                                               s->d_gamma, s->sigma_bb_const, s->d_temperature, s->d_lte, s->hc_over_kB,
+                                               s->pref_ij, s->pref_ji, s->d_C, s->d_atom, s->d_R, s->d_pops_new, st,
+                                               s->d_J_nat[0], s->d_J_nat[1])))
+                return rc;
+        } else {
         // J_λ (:84-111)
         if ((rc = execute_dev_locked(p, nlam, nlam, s->d_S_old, s->d_native, VRT_ALPHA_ANGLE_NATIVE, s->d_I0, nullptr,
                                      s->weights.data(), s->d_J, nullptr, st)))
@@ -431,10 +467,12 @@ int vrt_lambda_iterate(vrt_lambda *s, double *max_rel_change)
                                            s->d_gamma, s->sigma_bb_const, s->d_temperature, s->d_lte, s->hc_over_kB,
                                            s->pref_ij, s->pref_ji, s->d_C, s->d_atom, s->d_R, s->d_pops_new, st)))
             return rc;
+        }
         std::swap(s->d_pops, s->d_pops_new);
         unsigned long long h[2] = {0, 0};
         VRT_HIP_TRY(hipMemcpyAsync(h, s->d_scalars, sizeof(h), hipMemcpyDeviceToHost, st));
         VRT_HIP_TRY(hipStreamSynchronize(st));
+        if ((rc = patch_chain_check(p))) return rc;          // a chained sweep that gave up: THIS iteration's results are invalid
         double d;
         std::memcpy(&d, &h[0], sizeof(double));
         *max_rel_change = h[1] ? std::nan("") : d;
@@ -454,8 +492,27 @@ int vrt_lambda_get(vrt_lambda *s, double *J, double *S, double *populations, dou
     int rc = use_device(p->g->device);
     if (rc) return rc;
     const size_t n = (size_t)s->n, nl = (size_t)s->nlam;
+    if (s->native && (J || S)) {
+        // the caller's layout is formed here, on request: one scratch array, freed again
+        double *tmp = nullptr;
+        if ((rc = dalloc(&tmp, n * nl))) return rc;
+        hipStream_t st = p->g->stream;
+        if (J) {
+            rc = J_from_native(p, s->nlam, s->nlam, s->d_J_nat[0], s->d_J_nat[1], tmp, st);
+            if (!rc && hipMemcpyAsync(J, tmp, sizeof(double) * n * nl, hipMemcpyDeviceToHost, st) != hipSuccess) rc = VRT_ENODEVICE;
+            if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = VRT_ENODEVICE;
+        }
+        if (!rc && S) {
+            rc = plane_from_native(p, 0, s->nlam, s->nlam, s->d_S_nat[0], tmp, st);
+            if (!rc && hipMemcpyAsync(S, tmp, sizeof(double) * n * nl, hipMemcpyDeviceToHost, st) != hipSuccess) rc = VRT_ENODEVICE;
+            if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = VRT_ENODEVICE;
+        }
+        (void)hipFree(tmp);
+        if (rc) return rc == VRT_ENODEVICE ? fail(rc, "HIP error in vrt_lambda_get") : rc;
+    } else {
     if (J) VRT_HIP_TRY(hipMemcpy(J, s->d_J, sizeof(double) * n * nl, hipMemcpyDeviceToHost));
     if (S) VRT_HIP_TRY(hipMemcpy(S, s->d_S_new, sizeof(double) * n * nl, hipMemcpyDeviceToHost));
+    }
     if (populations) VRT_HIP_TRY(hipMemcpy(populations, s->d_pops, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
     if (R) VRT_HIP_TRY(hipMemcpy(R, s->d_R, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
     if (gamma) VRT_HIP_TRY(hipMemcpy(gamma, s->d_gamma, sizeof(double) * n, hipMemcpyDeviceToHost));

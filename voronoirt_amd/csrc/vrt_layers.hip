@@ -117,6 +117,55 @@ int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const void *dalpha, v
                : alpha_to_native_t<double>(p, nlam, ld, (const double *)dalpha, (double *)out, st);
 }
 
+// ---- sweep-order ("native") S and J: per sweep direction a plane set [pairs][n][2] in that direction's storage order ------
+// (the layout the layer paths read S from and reduce J into; what vrt_plan_execute_native_dev takes and returns in place)
+int native_planes_ok(const vrt_plan *p)
+{
+    if (!(p->patch_ok || p->tile_ok)) return fail(VRT_EINVAL, "sweep-order S and J need a layer path (at most 4 visits per site and 255 levels per layer)");
+    if (native_lg(p, false) != 0) return fail(VRT_EINVAL, "sweep-order S and J need one wavelength pair per block (VRT_PAIR_BLOCK=1)");
+    return VRT_OK;
+}
+
+// caller's (n, ld) rows -> the planes of both directions (either output may be NULL)
+int planes_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *din, double *out_up, double *out_down, hipStream_t st)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
+    for (int d = 0; d < 2; d++) {
+        double *out = d == 0 ? out_up : out_down;
+        if (!out) continue;
+        const Direction &dir = d == 0 ? g->up : g->down;
+        hipLaunchKernelGGL(k_to_sweep_order<double>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2, dir.d_store, din, out,
+                           (const double *)nullptr, (double *)nullptr);
+    }
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+// the planes of ONE direction -> the caller's (n, ld) rows
+int plane_from_native(vrt_plan *p, int dir_index, int64_t nlam, int64_t ld, const double *din, double *dout, hipStream_t st)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
+    const Direction &dir = dir_index == 0 ? g->up : g->down;
+    hipLaunchKernelGGL(k_from_sweep_order<double>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2, dir.d_store, din, dout);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
+// J[site][l] = J_up + J_down from the two directions' planes (either may be NULL: that direction had no angle)
+int J_from_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *dJ_up, const double *dJ_down, double *dJ, hipStream_t st)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
+    hipLaunchKernelGGL(k_combine_J<double>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2, g->up.d_store, g->down.d_srank, dJ_up, dJ_down, dJ);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+
 // internal streams + angle groups of the layer-step path
 static int ensure_step_streams(vrt_plan *p, int G)
 {
@@ -272,8 +321,11 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     ChainPrep cp{};
     bool prep_ctrl = false;
     const bool use_dir[2] = {p->n_up > 0, p->n_down > 0};
+    // sweep-order S and J handed over by the caller (vrt_plan_execute_native_dev): the layer paths read / write them in place
+    const bool nat = p->nat_mode;
+    if (nat && (!steps || lb != 2)) return fail(VRT_EINVAL, "sweep-order S and J need a layer path with one wavelength pair per block");
     for (int d = 0; d < 2; d++)
-        if (use_dir[d] && (rc = ensure_dev(p->ws_S[d], p->ws_S_cap[d], dcount(plane)))) return rc;
+        if (use_dir[d] && !nat && (rc = ensure_dev(p->ws_S[d], p->ws_S_cap[d], dcount(plane)))) return rc;
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
     // a handful of wavelengths in the pair layout: the narrow forms of the layout changes (vrt_layout_kernels.h)
     const bool narrow = lb != 1 && nlam <= 16;
@@ -341,19 +393,26 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         }
         const T *in2 = with_alpha ? dalpha : nullptr;
         T *out2 = with_alpha ? reinterpret_cast<T *>(p->ws_A[d]) : nullptr;
+        // (sweep-order S of the caller: read in place, no layout change; a caller-layout alpha still has its own)
+        const T *inS = nat ? (with_alpha ? in2 : nullptr) : dS;
+        T *outS = nat ? out2 : reinterpret_cast<T *>(p->ws_S[d]);
+        const T *inB = nat ? nullptr : in2;
+        T *outB = nat ? nullptr : out2;
         if (prep) {
             if constexpr (!kF32) {
-                cp.tin[cp.njob] = dS; cp.tout[cp.njob] = p->ws_S[d]; cp.torder[cp.njob] = dir.d_store; cp.njob++;
-                if (with_alpha) { cp.tin[cp.njob] = in2; cp.tout[cp.njob] = out2; cp.torder[cp.njob] = dir.d_store; cp.njob++; }
+                if (inS) { cp.tin[cp.njob] = inS; cp.tout[cp.njob] = reinterpret_cast<double *>(outS); cp.torder[cp.njob] = dir.d_store; cp.njob++; }
+                if (inB) { cp.tin[cp.njob] = inB; cp.tout[cp.njob] = reinterpret_cast<double *>(outB); cp.torder[cp.njob] = dir.d_store; cp.njob++; }
                 cp.n1[d] = dir.n1; cp.store[d] = dir.d_store; cp.rank[d] = dir.d_rank; cp.I0[d] = d == 0 ? dI0_up : dI0_down;
             }
+        } else if (!inS) {
+            // nothing to lay out
         } else if (narrow)
-            hipLaunchKernelGGL(k_to_sweep_order_narrow<T>, dim3(narrow_blocks, with_alpha ? 2 : 1), dim3(256), 0, st, n, (int)nlam, ld,
-                               log2_pairs(lb), narrow_lgP, dir.d_store, dS, reinterpret_cast<T *>(p->ws_S[d]), in2, out2);
+            hipLaunchKernelGGL(k_to_sweep_order_narrow<T>, dim3(narrow_blocks, inB ? 2 : 1), dim3(256), 0, st, n, (int)nlam, ld,
+                               log2_pairs(lb), narrow_lgP, dir.d_store, inS, outS, inB, outB);
         else
-            hipLaunchKernelGGL(k_to_sweep_order<T>, dim3(tgrid.x, tgrid.y, with_alpha ? 2 : 1), dim3(256), 0, st, n, (int)nlam, ld, lb,
-                               dir.d_store, dS, reinterpret_cast<T *>(p->ws_S[d]), in2, out2);
-        ta.S[d] = p->ws_S[d];
+            hipLaunchKernelGGL(k_to_sweep_order<T>, dim3(tgrid.x, tgrid.y, inB ? 2 : 1), dim3(256), 0, st, n, (int)nlam, ld, lb,
+                               dir.d_store, inS, outS, inB, outB);
+        ta.S[d] = nat ? reinterpret_cast<const double *>(p->nat_S[d]) : p->ws_S[d];
         if (alpha_mode == VRT_ALPHA_SITE) {
             if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], dcount((size_t)n)))) return rc;
             hipLaunchKernelGGL(k_gather_vec<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
@@ -464,7 +523,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             for (int a = 0; a < A; a++) red_tmpl.w[a] = weights_user[p->user_of_active[(size_t)a]];
             for (int d = 0; d < 2; d++) {
                 if (!use_dir[d]) continue;
-                if ((rc = ensure_dev(p->ws_J[d], p->ws_J_cap[d], dcount(plane)))) return rc;
+                if (!nat && (rc = ensure_dev(p->ws_J[d], p->ws_J_cap[d], dcount(plane)))) return rc;
                 for (int gi = 0; gi < G; gi++) {
                     int have = 0;
                     for (int j = p->step_group_off[(size_t)gi]; j < p->step_group_off[(size_t)gi + 1]; j++)
@@ -489,7 +548,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                 if (upto <= reduced_upto[d]) continue;
                 red.lo[r] = (int)reduced_upto[d];
                 red.hi[r] = (int)upto;
-                red.Jd[r] = p->ws_J[d];
+                red.Jd[r] = nat ? reinterpret_cast<double *>(p->nat_J[d]) : p->ws_J[d];
                 red.count[r] = 0;
                 for (int a = 0; a < A; a++)
                     if ((p->dir_of_active[(size_t)a] > 0) == (d == 0)) red.angles[r][red.count[r]++] = a;
@@ -514,7 +573,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             if (dJ)
                 for (int d = 0; d < 2; d++) {
                     red.count[d] = 0;
-                    red.Jd[d] = use_dir[d] ? p->ws_J[d] : nullptr;
+                    red.Jd[d] = use_dir[d] ? (nat ? reinterpret_cast<double *>(p->nat_J[d]) : p->ws_J[d]) : nullptr;
                     for (int a = 0; a < A; a++)
                         if ((p->dir_of_active[(size_t)a] > 0) == (d == 0)) red.angles[d][red.count[d]++] = a;
                     fused_dir[d] = use_dir[d];
@@ -678,8 +737,12 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     if (dJ) {
         T *Jd[2] = {nullptr, nullptr};
         for (int d = 0; d < 2; d++) {
-            if (!use_dir[d]) continue;
-            if ((rc = ensure_dev(p->ws_J[d], p->ws_J_cap[d], dcount(plane)))) return rc;
+            if (!use_dir[d]) {
+                // (a direction without angles contributes nothing: its sweep-order J is handed back as zeros)
+                if (nat && p->nat_J[d]) VRT_HIP_TRY(hipMemsetAsync(p->nat_J[d], 0, plane * sizeof(T), st));
+                continue;
+            }
+            if (!nat && (rc = ensure_dev(p->ws_J[d], p->ws_J_cap[d], dcount(plane)))) return rc;
             DirWeights dw;
             dw.count = 0;
             for (int a = 0; a < A; a++)
@@ -688,12 +751,14 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
                     dw.idx[dw.count] = a;
                     dw.count++;
                 }
-            Jd[d] = reinterpret_cast<T *>(p->ws_J[d]);
+            Jd[d] = reinterpret_cast<T *>(nat ? p->nat_J[d] : (void *)p->ws_J[d]);
             if (fused_dir[d]) continue;                  // formed layer by layer inside the sweep's launches
             hipLaunchKernelGGL(k_reduce_dir<T>, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st,
                                (int64_t)plane, (int64_t)plane, dw, wI, Jd[d]);
         }
-        if (narrow)
+        if (nat) {
+            // the caller keeps J per direction in sweep order: no combination, no layout change
+        } else if (narrow)
             hipLaunchKernelGGL(k_combine_J_narrow<T>, dim3(narrow_blocks), dim3(256), 0, st, n, (int)nlam, ld, log2_pairs(lb), narrow_lgP,
                                g->up.d_store, g->down.d_srank, Jd[0], Jd[1], dJ);
         else

@@ -323,6 +323,8 @@ int vrt_multi_execute(vrt_multi *mm, int64_t nlam, int64_t ld, const double *S, 
             if (shard == 1)     // the device owns rows l0..l1 of J: straight home
                 chk(hipMemcpy2DAsync(J + l0, w8 * (size_t)ld, me.dJ, w8 * (size_t)nb, w8 * (size_t)nb, (size_t)n, hipMemcpyDeviceToHost, st), "download J");
             chk(hipStreamSynchronize(st), "hipStreamSynchronize");
+            // (a chained sweep that gave up waiting: reported by THIS call, whose J it spoiled)
+            if (!me.rc && (me.rc = patch_chain_check(plan))) me.err = vrt_last_error();
         };
         if (!run_workers(W, work)) return fail(VRT_ENOMEM, "out of host memory in a device worker");
         for (const Member &me : mm->m)
@@ -445,6 +447,7 @@ int vrt_multi_execute_line(vrt_multi *mm, int64_t nlam, int64_t ld, const double
             }
             chk(hipMemcpy2DAsync(J + l0, w8 * (size_t)ld, me.dJ, w8 * (size_t)nb, w8 * (size_t)nb, sn, hipMemcpyDeviceToHost, st), "download J");
             chk(hipStreamSynchronize(st), "hipStreamSynchronize");
+            if (!me.rc && (me.rc = patch_chain_check(plan))) me.err = vrt_last_error();
         };
         if (!run_workers(W, work)) return fail(VRT_ENOMEM, "out of host memory in a device worker");
         for (const Member &me : mm->m)
@@ -731,6 +734,7 @@ int vrt_multi_lambda_iterate(vrt_multi_lambda *s, double *max_rel_change)
         for (int d = 0; d < W; d++) {
             VRT_HIP_TRY(hipSetDevice(mm->m[(size_t)d].device));
             VRT_HIP_TRY(hipStreamSynchronize(mm->m[(size_t)d].stream));
+            if (int rcc = patch_chain_check(mm->m[(size_t)d].plan_all)) return rcc;     // this iteration's sweep gave up on that device
             double v;
             std::memcpy(&v, &h[(size_t)(2 * d)], sizeof(double));
             worst = std::max(worst, v);

@@ -273,6 +273,9 @@ struct RatesArgs {
     const double *lambda, *planck2;     // [nlam] device
     const double *sigma_bf1, *sigma_bf2;   // device, one entry per wavelength of the block
     const double *J;                    // (nlam, n), leading dimension ld
+    // ... or per sweep direction in sweep order (vrt_plan_execute_native_dev): J = J_up + J_down; threads walk the up order
+    const double *J_up = nullptr, *J_down = nullptr;
+    const int32_t *store_up = nullptr, *rank_down = nullptr;
     double lambda0, c0, sigma_bb_const, hc_over_kB, pref_ij, pref_ji;
     const double *doppler, *gamma, *temperature, *lte, *C, *atom_density;
     double *R, *populations;
@@ -335,6 +338,10 @@ __device__ __forceinline__ void populations_from_rates(const RatesArgs &ra, int6
     ra.populations[i] = N - (x[0] + x[1]);
 }
 
+// NATIVE: J comes per sweep direction in sweep order; a thread takes the site at up position blockIdx * 256 + tid, so that
+// the J_up loads of a wave are contiguous (and the J_down loads piecewise contiguous: layers are the units of both orders) --
+// the per-site inputs become gathers instead, 25 values against the 2 x nlam of J.  The arithmetic of a site is the same.
+template <bool NATIVE>
 __global__ void __launch_bounds__(256)
 k_rates_populations(RatesArgs ra)
 {
@@ -343,7 +350,17 @@ k_rates_populations(RatesArgs ra)
     const int tid = threadIdx.x;
     const int64_t n = ra.n, site0 = (int64_t)blockIdx.x * 256;
     const bool valid = site0 + tid < n;
-    const int64_t i = valid ? site0 + tid : n - 1;                  // (a thread past the end works on the last site and stores nothing)
+    const int64_t slot = valid ? site0 + tid : n - 1;               // (a thread past the end works on the last site and stores nothing)
+    const int64_t i = NATIVE ? (int64_t)ra.store_up[slot] : slot;
+    const int64_t pdn = NATIVE ? (int64_t)ra.rank_down[i] : 0;
+    auto J_native = [&](int64_t l) -> double {
+        // J = J_up + J_down as k_combine_J forms it
+        const size_t o = (size_t)(l >> 1) * (size_t)n;
+        double v = 0.0;
+        if (ra.J_up) v = ra.J_up[(o + (size_t)slot) * 2 + (size_t)(l & 1)];
+        if (ra.J_down) v = v + ra.J_down[(o + (size_t)pdn) * 2 + (size_t)(l & 1)];
+        return v;
+    };
     // J is (n, ld) with the wavelength fastest: a thread walking its own row makes every load of the wave touch 64
     // different lines.  The block's 256 rows are staged through LDS 16 wavelengths at a time instead (a site's 128
     // bytes by 16 neighbouring lanes), and a thread picks its row's values up from there (row stride 17: no conflicts)
@@ -368,8 +385,8 @@ k_rates_populations(RatesArgs ra)
         const double n_ratio = ra.lte[i + n * (level - 1)] / ra.lte[i + n * 2];
         double rij = 0.0, rji = 0.0, s_prev = 0.0, G_prev = 0.0, J_prev = 0.0;
         for (int64_t l = lo; l < hi; l++) {
-            if (((l - lo) & 15) == 0) stage(l, hi);
-            const double lam = ra.lambda[l], s = sig[l - lo], Jl = Jt[tid * 17 + (int)((l - lo) & 15)];
+            if (!NATIVE && ((l - lo) & 15) == 0) stage(l, hi);
+            const double lam = ra.lambda[l], s = sig[l - lo], Jl = NATIVE ? J_native(l) : Jt[tid * 17 + (int)((l - lo) & 15)];
             const double G = n_ratio * boltzmann(hT, lam);                               // Gij, rates.jl:473
             if (l > lo) {
                 const double lp = ra.lambda[l - 1], dl = lam - lp;
@@ -390,8 +407,8 @@ k_rates_populations(RatesArgs ra)
         const double r_dD = 1.0 / dD, r_a = 1.0 / (4.0 * kPi * ra.c0 * dD), r_prof = 1.0 / (sqrt(kPi) * dD);
         double rij = 0.0, rji = 0.0, s_prev = 0.0, G_prev = 0.0, J_prev = 0.0;
         for (int64_t l = lo; l < hi; l++) {
-            if (((l - lo) & 15) == 0) stage(l, hi);
-            const double lam = ra.lambda[l], Jl = Jt[tid * 17 + (int)((l - lo) & 15)];
+            if (!NATIVE && ((l - lo) & 15) == 0) stage(l, hi);
+            const double lam = ra.lambda[l], Jl = NATIVE ? J_native(l) : Jt[tid * 17 + (int)((l - lo) & 15)];
             const double a = gm * (lam * lam) * r_a;
             const double v = (lam - ra.lambda0) * r_dD;                                  // rates.jl:408
             const double s = ra.sigma_bb_const * (humlicek_w4_re(v, a) * r_prof);
@@ -526,12 +543,17 @@ int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_
                              const double *d_gamma, double sigma_bb_const, const double *d_temperature,
                              const double *d_lte, double hc_over_kB, double pref_ij, double pref_ji,
                              const double *d_C, const double *d_atom_density, double *d_R,
-                             double *d_populations, hipStream_t st)
+                             double *d_populations, hipStream_t st, const double *dJ_up, const double *dJ_down)
 {
     RatesArgs ra;
     fill_rates_args(ra, g, nlam, ld, blocks, d_small, dJ, lambda0, c0, d_doppler, d_gamma, sigma_bb_const, d_temperature, d_lte,
                     hc_over_kB, pref_ij, pref_ji, d_C, d_atom_density, d_R, d_populations);
-    hipLaunchKernelGGL(k_rates_populations, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, st, ra);
+    if (dJ_up || dJ_down) {
+        ra.J_up = dJ_up; ra.J_down = dJ_down;
+        ra.store_up = g->up.d_store; ra.rank_down = g->down.d_srank;
+        hipLaunchKernelGGL(k_rates_populations<true>, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, st, ra);
+    } else
+    hipLaunchKernelGGL(k_rates_populations<false>, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, st, ra);
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
