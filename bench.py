@@ -149,7 +149,8 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     a, c, quad, nlam_total, per_angle, seed = WORKLOADS[workload]
     if args.nlam > 0 and workload == args.workload:
         nlam_total = args.nlam
-    shard = args.shard if world > 1 else "lambda"
+    dist_on = world > 1 or (dist.is_available() and dist.is_initialized())
+    shard = args.shard if dist_on else "lambda"
     if shard == "auto":                     # N > 1: the fixed workload, RCCL on J inside the timed step
         shard = "lambda-strong" if nlam_total >= world else "angle"
     weights, theta, phi, n_angles = vrt.read_quadrature(quad)
@@ -246,7 +247,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     # S and J in the sweep's own layout (vrt_plan_execute_native_dev): the device-resident Λ-iteration produces S and
     # consumes J in this form (vrt_lambda_iterate), so its sweep step has no layout change; converted once, untimed
     sj_native = (args.sj_layout == "native" or (args.sj_layout == "auto" and per_angle)) and alpha_native is not None \
-        and not f32 and groups is None and world == 1
+        and not f32 and groups is None and not dist_on
     S_nat = J_nat = None
     if sj_native:
         cnt = plan.native_plane_count(nlam)
@@ -286,7 +287,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         else:
             plan.execute_dev(nlam, nlam, S.data_ptr(), alpha.data_ptr(), alpha_mode, w_mine,
                              dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
-        if world > 1 and shard == "angle":
+        if dist_on and shard == "angle":
             def reduce_():
                 if rehearse:       # gloo reduces host tensors
                     Jh = J.cpu()
@@ -295,7 +296,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
                 else:
                     distributed.allreduce_J(J)
             timed_collective(reduce_, "all_reduce(sum) of J (n, nlam) over the angle shards", J.numel() * J.element_size())
-        elif world > 1 and shard == "lambda-strong":
+        elif dist_on and shard == "lambda-strong":
             gathered["buf"], gathered["sizes"] = timed_collective(
                 lambda: distributed.allgather_J_blocks(J.cpu() if rehearse else J, nlam_total, out=gathered.get("buf")),
                 "all_gather of the wavelength blocks of J (n, nlam_total)", n * nlam_total * J.element_size())
@@ -386,7 +387,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     }
     if caller_layout is not None:
         out["caller_layout"] = caller_layout
-    if world > 1:
+    if dist_on:
         out["collective"] = {"op": coll["op"] or "none (every rank owns whole rows of J)",
                              "bytes_per_step": coll["bytes_per_step"],
                              "ms": coll["ms"] / max(coll["calls"], 1),
@@ -470,22 +471,37 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     if rank == 0 and world == 1 and cpu_baseline:      # reported at N = 1 only
         from oracle import oracle as orc
         cores = len(os.sched_getaffinity(0))
-        # bounded sample (about 10-30 s of CPU work): <= 3e8 cell-updates for the threaded run
-        lam_s = args.cpu_lam if args.cpu_lam > 0 else max(1, min(nlam, cores, int(3.0e8 // (n * A))))
         t0 = time.time()
         so = orc.make_sites(pos, nbr, bounds)
         t_osites = time.time() - t0
+        # (a) the baseline, threaded the way the reference is: angles serial, ALL nlam wavelengths dealt to min(nlam, cores)
+        # threads (Threads.@threads over λ, lambda_iteration.jl:91); bounded (~3e8 cell-updates) by taking a SUBSET OF THE
+        # ANGLES, ups and downs alternating -- not fewer wavelengths, which would leave the thread team short
+        threads = args.cpu_lam if args.cpu_lam > 0 else min(nlam, cores)
+        lam_b = nlam if args.cpu_lam <= 0 else min(nlam, args.cpu_lam)
+        th_m = theta[my_angles]
+        ups_, downs_ = [j for j in range(A) if th_m[j] > 90], [j for j in range(A) if th_m[j] < 90]
+        inter = [x for pair in zip(ups_, downs_) for x in pair] + ups_[len(downs_):] + downs_[len(ups_):]
+        A_b = max(1, min(A, int(3.0e8 // (n * lam_b))))
+        selb = np.array(sorted(inter[:A_b]))
+        S_b = S[:, :lam_b].contiguous().cpu().numpy().astype(np.float64)
+        al_b = (alpha[selb][:, :, :lam_b] if per_angle else alpha[:, :lam_b]).contiguous().cpu().numpy().astype(np.float64)
+        I0_b = I0_up[:, :lam_b].contiguous().cpu().numpy().astype(np.float64)
+        t0 = time.time()
+        orc.J_voronoi(w_mine[selb], th_m[selb], phi[my_angles][selb], S_b, al_b, so, I0_up=I0_b, nthreads=threads)
+        t_cpu = time.time() - t0
+        cpu_updates = n * len(selb) * lam_b
+        del S_b, al_b
+        # (b) the parity sample: all angles x the first wavelengths (<= 1e8 cell-updates), against the J of the timed steps
+        lam_s = max(1, min(nlam, int(1.0e8 // (n * A))))
         S_h = S[:, :lam_s].contiguous().cpu().numpy().astype(np.float64)
         if per_angle:
             al_h = alpha[:, :, :lam_s].contiguous().cpu().numpy().astype(np.float64)
         else:
             al_h = alpha[:, :lam_s].contiguous().cpu().numpy().astype(np.float64)
         I0_h = I0_up[:, :lam_s].contiguous().cpu().numpy().astype(np.float64)
-        t0 = time.time()
         J_ref = orc.J_voronoi(w_mine, theta[my_angles], phi[my_angles], S_h, al_h, so, I0_up=I0_h,
-                              nthreads=min(cores, lam_s))     # (one thread per wavelength of the sample: no idle team members)
-        t_cpu = time.time() - t0
-        cpu_updates = n * A * lam_s
+                              nthreads=min(cores, lam_s))
         # T = 1: one wavelength, one thread (T = 1 and T = all cores); all angles, or
         # one up + one down ray when that alone would take more than ~30 s
         sel = np.arange(A)
@@ -503,11 +519,12 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         parity = float(_pe)
         parity_maxnorm = float(_pe.maxnorm)
         out["cpu_baseline"] = {
-            "value": cpu_updates / t_cpu, "unit": "cell-updates/s", "cores": min(cores, lam_s), "kind": "port",
-            "sample": f"same grid and fields, all {A} angles x the first {lam_s} of {nlam} "
-                      f"wavelengths ({cpu_updates} cell-updates in {t_cpu:.1f} s wall); oracle "
-                      f"restatement threaded over wavelengths like Threads.@threads; its grid "
-                      f"prep (read_cell equivalent) took {t_osites:.1f} s and is not counted",
+            "value": cpu_updates / t_cpu, "unit": "cell-updates/s", "cores": threads, "kind": "port",
+            "sample": f"same grid and fields, {len(selb)} of the {A} angles (ups and downs alternating) x all {lam_b} "
+                      f"wavelengths on {threads} threads = min(nlam, host cores), one wavelength each like "
+                      f"Threads.@threads ({cpu_updates} cell-updates in {t_cpu:.1f} s wall); oracle restatement; its grid "
+                      f"prep (read_cell equivalent) took {t_osites:.1f} s and is not counted; parity: all {A} angles x the "
+                      f"first {lam_s} wavelengths against the J of the timed steps",
             "seconds": t_cpu,
             "single_thread": {"value": n * len(sel) / t_cpu1, "unit": "cell-updates/s", "cores": 1, "seconds": t_cpu1,
                               "sample": f"{len(sel)} of {A} angles x 1 wavelength ({n * len(sel)} cell-updates)"},
@@ -590,7 +607,10 @@ def main():
     # VRT_BENCH_REHEARSE=1: every rank uses GPU 0 and the gloo backend (single-GPU rehearsal of
     # the N > 1 code path; RCCL refuses two ranks on one device)
     rehearse = os.environ.get("VRT_BENCH_REHEARSE") == "1"
-    rank, world = distributed.init_process_group("gloo" if rehearse else None)
+    # VRT_BENCH_FORCE_DIST=1: a process group also for ONE rank (nccl = RCCL unless rehearsing), so that the collectives of the
+    # N > 1 modes execute on a one-GPU box (tests/test_physics.py)
+    force_dist = os.environ.get("VRT_BENCH_FORCE_DIST") == "1"
+    rank, world = distributed.init_process_group("gloo" if rehearse else None, force=force_dist)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = 0 if rehearse else int(os.environ.get("LOCAL_RANK", "0"))

@@ -127,6 +127,12 @@ int vrt_plan_get_upwind(const vrt_plan *p, int64_t angle, int64_t *up, double *d
  *   alpha  see VRT_ALPHA_*
  *   I0_up  (nlam, n1_up)   boundary intensity for up rays, ordered like perm_up[1:n1_up]
  *          (lambda_iteration.jl:99-101); NULL = zeros.  I0_down likewise (:105-106).
+ *   RESERVED VALUE: where a step of one or two wavelength pairs runs as ONE chained launch (option VRT_CHAIN_DATAFLAG,
+ *          default auto), an intensity is its own "written" flag, and "not yet written" is the quiet NaN whose 32-bit
+ *          halves are both 0x7FF87FF8 (as a float: 0x7FF87FF8).  An ordinary NaN (0x7FF8000000000000, 0x7FC00000)
+ *          propagates like anywhere else; an I0 or S that makes an intensity carry exactly the reserved pattern
+ *          stalls its readers until the bounded wait expires (VRT_CHAIN_SPIN, ~2 s) and the call fails with
+ *          VRT_ENODEVICE instead of returning it.  VRT_CHAIN_DATAFLAG=0 removes the reservation.
  *   weights[n_angles]      quadrature weights
  *   J      (nlam, n) out:  J = Σ_angles w · I  (lambda_iteration.jl:102,107), may be NULL
  *   I_out  (nlam, n, n_angles) out: per-angle intensities, may be NULL
@@ -422,7 +428,8 @@ int vrt_multi_execute_line(vrt_multi *m, int64_t nlam, int64_t ld, const double 
  * travels -- and every device solves the statistical equilibrium of every site itself
  * (src/populations.jl:191-221).  Results equal the one-device session's to the rounding of that regrouping (1e-12).
  * vrt_multi_lambda_get assembles J and S_new (n, nlam) from the devices' blocks; populations (n, 3), R (3, 3, n) and γ [n]
- * come from the first device.  Destroy the session before its vrt_multi. */
+ * come from the first device.  LIFETIME: a session uses its vrt_multi in every call but vrt_multi_lambda_destroy --
+ * destroy the session FIRST; vrt_multi_lambda_iterate / _get on a session whose vrt_multi is gone are undefined. */
 typedef struct vrt_multi_lambda vrt_multi_lambda;
 int vrt_multi_lambda_create(vrt_multi *m, const vrt_line_case *lc, const double *weights, vrt_multi_lambda **out);
 int vrt_multi_lambda_iterate(vrt_multi_lambda *s, double *max_rel_change);

@@ -840,3 +840,32 @@ def test_storage_order_keeps_the_layers_contiguous(grid, bcc_small, voro_small):
         for lo, hi in zip(edges[:-1], edges[1:]):
             hi = min(hi, so.n - 1)
             assert set(store[lo:hi]) == set(perm[lo:hi])
+
+
+def test_rccl_constants_declared_by_hand_match_the_installed_header():
+    """csrc/vrt_multi.cpp declares the few RCCL entry points and enum values it uses itself (librccl is dlopen'ed; the
+    library builds without the RCCL headers).  Where the header is installed, its values are the ones declared."""
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no RCCL header on this machine")
+    h = open(hdr).read()
+    src = open(os.path.join(ROOT, "voronoirt_amd", "csrc", "vrt_multi.cpp")).read()
+    mine = {k: int(v) for k, v in re.findall(r"\b(ncclSuccess|ncclDouble|ncclSum)\s*=\s*(\d+)", src)}
+    assert set(mine) == {"ncclSuccess", "ncclDouble", "ncclSum"}
+    for name, value in mine.items():
+        m = re.search(r"\b" + name + r"\s*=\s*(\d+)", h)
+        assert m and int(m.group(1)) == value, name
+    # the prototypes: argument lists of the header, reduced to their types
+    for fn, nargs in (("ncclCommInitAll", 3), ("ncclAllReduce", 7), ("ncclReduce", 8), ("ncclCommDestroy", 1)):
+        m = re.search(r"ncclResult_t\s+" + fn + r"\s*\(([^)]*)\)", h)
+        assert m and len([a for a in m.group(1).split(",") if a.strip()]) == nargs, fn
+
+
+def test_host_sanitizer_screen_still_builds():
+    """tools/asan_host.sh (ASan + UBSan and TSan builds of every host translation unit against generated stubs of the device
+    side) must not go stale: its `check` mode -- the same build without a sanitizer -- has to link and load with every
+    symbol resolved.  The sanitizer runs themselves are logged under profiles/."""
+    import subprocess
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "asan_host.sh"), "check"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "loads with every symbol resolved" in r.stdout

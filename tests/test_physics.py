@@ -474,3 +474,65 @@ def test_gpu_multi_device_lambda_session_and_line_entry(voro_small, devices):
     assert np.array_equal(Jl, vrt.J_lambda_voronoi_line(Sx, pp, hs, case, "ul7n12.dat"))
     mp.close()
     hs.close()
+
+
+@pytest.mark.gpu
+def test_gpu_rccl_calls_execute_on_a_one_rank_communicator(voro_small, monkeypatch):
+    """VRT_MULTI_FORCE_RCCL=1: the multi-device object builds a ONE-rank communicator (ncclCommInitAll over device 0), so
+    the RCCL legs of csrc/vrt_multi.cpp run on a one-GPU box: ncclReduce of the angle shards' partial J
+    (lambda_iteration.jl:102,107) and ncclAllReduce of the six rate-integral shares (rates.jl:154-201) inside group
+    calls, stream-ordered behind the sweeps.  A one-rank sum is the identity: results bit for bit those of the same object
+    without the communicator."""
+    pos, nbr, bounds = voro_small
+    so = orc.make_sites(pos, nbr, bounds)
+    n = so.n
+    case = _lambda_case(pos, bounds, 11)
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    dirs = [1 if t > 90 else -1 for t in th]
+    k = vrt.quadrature_directions(th, ph)
+    rng = np.random.default_rng(5)
+    nlam = 6
+    S = 1 + rng.random((n, nlam))
+    al = 5 * 10 ** rng.uniform(-2, 2, (n, 1)) * (1 + rng.random((n, nlam)))
+    I0u = rng.random((so.layers_up[1] - 1, nlam))
+    out = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("VRT_MULTI_FORCE_RCCL", force)
+        mp = vrt.MultiDevicePlan(pos, nbr, bounds, k, dirs=dirs, devices=(0,))
+        assert mp.uses_rccl == (force == "1")
+        mp.set_shard("angle")                                  # one device holds every angle: ncclReduce(root 0) of its own J
+        Ja = mp.execute(S, al, w, I0_up=I0u)
+        assert mp.last_shard == "angle"
+        mp.set_shard("lambda")
+        Jl = mp.execute(S, al, w, I0_up=I0u)
+        it = mp.lambda_iteration(0.0, 3, case, w)              # ncclAllReduce of the 6 n shares, every iteration
+        out[force] = (Ja, Jl) + tuple(it[:3]) + (np.array(it[3]),)
+        mp.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+    ref = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0u, nthreads=4)
+    assert _rel(out["1"][0], ref) < 1e-10 and len(out["1"][5]) == 3
+
+
+@pytest.mark.gpu
+def test_gpu_torch_distributed_nccl_world_of_one(tmp_path):
+    """bench.py's collectives through torch.distributed's "nccl" backend (= RCCL) with a world of ONE rank
+    (VRT_BENCH_FORCE_DIST=1): process-group init, the all-reduce of the angle mode and the all-gather of the wavelength
+    blocks execute inside the timed step; J equals the plain one-process run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--workload", "C2", "--nlam", "3", "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline", "--no-secondary", "--no-critical-path"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ref = tmp_path / "ref.npy"
+    subprocess.run(base + ["--dump-J", str(ref)], check=True, env=env, capture_output=True, timeout=600)
+    for shard in ("angle", "lambda-strong"):
+        got = tmp_path / f"{shard}.npy"
+        e = dict(env, VRT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        r = subprocess.run(base + ["--shard", shard, "--dump-J", str(got)], check=True, env=e, capture_output=True, text=True, timeout=600)
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["collective"]["backend"].startswith("nccl") and line["collective"]["bytes_per_step"] > 0, line.get("collective")
+        assert np.array_equal(np.load(got), np.load(ref))

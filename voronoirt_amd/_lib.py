@@ -159,10 +159,11 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m voronoirt_amd.build` "
             "(hipcc --offload-arch=gfx950).  voronoirt_amd has no CPU fallback.")
-    try:
-        import torch  # noqa: F401  (plumbing only: device memory, streams, torch.distributed)
-    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
-        pass
+    if os.environ.get("VRT_NO_TORCH") != "1":     # (the host-only sanitizer drivers: torch under TSan takes minutes to import)
+        try:
+            import torch  # noqa: F401  (plumbing only: device memory, streams, torch.distributed)
+        except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)

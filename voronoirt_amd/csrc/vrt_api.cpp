@@ -697,10 +697,12 @@ int vrt::ensure_step_tables(vrt_plan *p)
     const int A = p->A, n_sweeps = p->n_sweeps;
     const size_t tab = (size_t)A * (size_t)n;
     int rc;
-    if ((rc = dev_alloc(&p->t_self, tab)) || (rc = dev_alloc(&p->t_vis_s, tab)) || (rc = dev_alloc(&p->t_loc_s, tab)) ||
-        (rc = dev_alloc(&p->t_gpos, tab)) || (rc = dev_alloc(&p->t_rank_s, tab)) || (rc = dev_alloc(&p->t_loc_ss, tab)))
+    // (a table an earlier, failed attempt already allocated is kept: a retry neither leaks it nor overwrites its pointer)
+    auto need = [&](auto *&ptr) -> int { return ptr ? VRT_OK : dev_alloc(&ptr, tab); };
+    if ((rc = need(p->t_self)) || (rc = need(p->t_vis_s)) || (rc = need(p->t_loc_s)) || (rc = need(p->t_gpos)) ||
+        (rc = need(p->t_rank_s)) || (rc = need(p->t_loc_ss)))
         return rc;
-    if (p->tile_max_layer_size <= 4096 && (rc = dev_alloc(&p->t_code_ss, tab))) return rc;
+    if (p->tile_max_layer_size <= 4096 && (rc = need(p->t_code_ss))) return rc;
     std::vector<std::vector<int32_t>> sorted_self((size_t)A);
     unsigned hw = std::thread::hardware_concurrency();
     const int nthr = std::max(1, std::min<int>((int)std::min<unsigned>(hw ? hw : 4, 16), A));
@@ -1239,8 +1241,11 @@ int vrt_patch_schedule_build(const vrt_grid *g, int dir, const int64_t *up, int 
             u2[(size_t)i] = b >= 1 ? (int32_t)(b - 1) : kNoUpwind;
         }
         vrt_patch_schedule *ps = new vrt_patch_schedule();
+        // (introspection: VRT_HOST_THREADS sets the builder's thread count -- the sanitizer screen drives it with 16)
+        int threads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        if (const char *e = std::getenv("VRT_HOST_THREADS")) threads = std::max(1, std::min(64, std::atoi(e)));
         build_patch_schedule(direction_of(g, dir), dir > 0, n, n_sweeps, u1.data(), u2.data(), own_target, entry_cap,
-                             ps->s, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())), &ps->layers);
+                             ps->s, threads, &ps->layers);
         if (ps->s.bad_site >= 0) {
             const std::string msg = "site " + std::to_string(ps->s.bad_site + 1) + " has no upwind neighbour";
             delete ps;

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -185,7 +186,12 @@ int vrt_multi_create(int n_devices, const int *devices, int64_t n, const double 
             }
             for (Member &me : mm->m) std::sort(me.my_angles.begin(), me.my_angles.end());
         }
-        if (mm->distinct && n_devices > 1) {
+        // VRT_MULTI_FORCE_RCCL=1: a communicator also for ONE device (a one-rank ncclCommInitAll), so that the RCCL legs of this
+        // file -- ncclReduce of the angle shards, ncclAllReduce of the rate-integral shares, the group calls -- execute on a
+        // one-GPU box too (tests/test_physics.py); read here, once per object
+        const char *force = std::getenv("VRT_MULTI_FORCE_RCCL");
+        const bool force_rccl = force && force[0] == '1';
+        if (mm->distinct && (n_devices > 1 || force_rccl)) {
             if (!mm->rccl.load()) {
                 multi_free(mm);
                 return fail(VRT_ENODEVICE, "cannot load librccl.so (needed for more than one device)");
@@ -754,6 +760,7 @@ int vrt_multi_lambda_get(vrt_multi_lambda *s, double *J, double *S, double *popu
 {
     DeviceScope scope;
     if (!s) return fail(VRT_EINVAL, "NULL session");
+    try {
     vrt_multi *mm = s->mm;
     std::lock_guard<std::mutex> lock(mm->mu);
     const size_t n = (size_t)s->n, nl = (size_t)s->nlam, w8 = sizeof(double);
@@ -770,6 +777,11 @@ int vrt_multi_lambda_get(vrt_multi_lambda *s, double *J, double *S, double *popu
         }
     }
     return VRT_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
 }
 
 void vrt_multi_lambda_destroy(vrt_multi_lambda *s)

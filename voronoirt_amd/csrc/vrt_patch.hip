@@ -748,6 +748,19 @@ __device__ __forceinline__ bool chain_is_sentinel(float2 v)
 // is reported through the launch's status words like a give-up of chain_wait_slow.
 constexpr uint32_t kChainDataSpins = 1u << 21;
 __device__ __forceinline__ void chain_data_give_up_cd(const ChainDev *cd, uint32_t item);
+// the abort word of a launch, from the device copy of its argument block (ChainDev: defined below; `ctrl` read through its offset)
+__device__ __forceinline__ const uint32_t *chain_abort_word(const uint32_t *cd_words);
+template <typename T2> __device__ __forceinline__ T2 chain_plain_nan();
+template <> __device__ __forceinline__ double2 chain_plain_nan<double2>()
+{
+    const double q = __hiloint2double(0x7FF80000, 0);
+    return make_double2(q, q);
+}
+template <> __device__ __forceinline__ float2 chain_plain_nan<float2>()
+{
+    const float q = __uint_as_float(0x7FC00000u);
+    return make_float2(q, q);
+}
 // Every other repeat asks the reading XCD's own L2 (agent scope: sc1 alone).  A patch's upwind owners are mostly patches of
 // the same queue, i.e. the same XCD (the queues cut every layer at the same eighths of the storage order): their
 // write-through stores pass through this very L2, and a line a repeat has brought in is updated there -- the value is seen
@@ -792,9 +805,22 @@ __device__ __forceinline__ void chain_data_wait(__amdgpu_buffer_rsrc_t rs, unsig
             if (chain_is_sentinel(r1)) r1 = a1;
             if (chain_is_sentinel(r2)) r2 = a2;
         }
-        if (++spins > kChainDataSpins) {
+        ++spins;
+        bool stop = spins > kChainDataSpins;
+        if ((spins & 255u) == 0u) {
+            // another workgroup of the launch has given up (the abort word of the launch's control block): this one would
+            // otherwise spin to its own limit behind it, layer after layer
+            const uint32_t *ctl = reinterpret_cast<const uint32_t *>(s_dep - kCtlWords);
+            const uint32_t *cdw = reinterpret_cast<const uint32_t *>(((uint64_t)ctl[kCtlArgsHi] << 32) | (uint64_t)ctl[kCtlArgsLo]);
+            stop = stop || ld_agent(chain_abort_word(cdw)) != 0u;
+        }
+        if (stop) {
             // (noted in the item's LDS words; chain_item reports it where the solver's registers are free again)
             const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(s_dep - kCtlWords))[kCtlGaveUp] = 1u;
+            // a lane that still holds the pattern goes on with an ordinary NaN: what this patch stores is then not the
+            // pattern, and the patches behind it pass through instead of waiting for it in their turn
+            if (chain_is_sentinel(r1)) r1 = chain_plain_nan<T2>();
+            if (chain_is_sentinel(r2)) r2 = chain_plain_nan<T2>();
             break;
         }
     }
@@ -1162,6 +1188,11 @@ struct ChainDev {
     int dbg;                   // timing diagnostics (-DVRT_DIAG build only, WRONG results): the flags of PatchArgs::dbg, and
                                //   256 no waiting for dependencies, 512 plain (L1-cached) intensity gathers, 1024 plain intensity stores, 2048 no pair loop
 };
+
+__device__ __forceinline__ const uint32_t *chain_abort_word(const uint32_t *cd_words)
+{
+    return reinterpret_cast<const ChainDev *>(cd_words)->ctrl + kChainAbortWord;
+}
 
 // uniform (scalar-register) reads of the argument block
 __device__ __forceinline__ int cd_int(const int *p) { return __builtin_amdgcn_readfirstlane(*p); }
@@ -1714,7 +1745,7 @@ static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool 
         level_queues();
     }
     emit_reduce(maxL);
-    if (maxL < 2) emit_reduce(1);
+    if (maxL < 1) emit_reduce(1);                         // (a grid of one layer: its J_dir items, once)
     level_queues();
     std::vector<int4> all;
     for (int x = 0; x < 8; x++) {

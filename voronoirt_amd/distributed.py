@@ -48,9 +48,10 @@ def angle_assignment(theta_deg, world: int):
     return [np.array(sorted(o), dtype=np.int64) for o in out]
 
 
-def init_process_group(backend: str | None = None):
+def init_process_group(backend: str | None = None, force: bool = False):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).
-    backend None -> "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo"."""
+    backend None -> "nccl" (= RCCL on ROCm) when a GPU is visible, else "gloo".  force: a group also for a world
+    of one rank (the collectives then execute, on one member)."""
     import torch
     import torch.distributed as dist
 
@@ -58,7 +59,7 @@ def init_process_group(backend: str | None = None):
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world == 1:
+    if world == 1 and not force:
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
@@ -75,7 +76,7 @@ def allreduce_J(J_partial):
     "angle" mode).  No-op for a single process."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(J_partial, op=dist.ReduceOp.SUM)
     return J_partial
 
@@ -113,7 +114,7 @@ def allgather_J_blocks(J_block, nlam_total: int, out=None):
     width = max(b - a for a, b in sizes)
     if out is None or tuple(out.shape) != (world, n, width) or out.dtype != J_block.dtype or out.device != J_block.device:
         out = torch.zeros((world, n, width), dtype=J_block.dtype, device=J_block.device)
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         out[0, :, : J_block.shape[1]] = J_block
         return out, sizes
     if J_block.shape[1] == width and J_block.is_contiguous():
