@@ -49,9 +49,9 @@ typedef struct vrt_plan vrt_plan;   /* per-(grid, angle set) upwind tables + swe
  * block of vrt_plan_native_alpha_count / n_angles doubles holding wavelength PAIRS (an odd nlam is
  * padded with one finite wavelength), B = vrt_plan_native_pair_block(p) pairs of a site side by
  * side: the pairs form blocks of B, then (B not dividing the pair count) one block per set bit of
- * the remainder, widest first; pair q of a block [q0, q0 + w) at position pos is pair
+ * the remainder, widest first; pair q of a block [q0, q0 + w) at storage position pos is pair
  * element q0 * n + pos * w + (q - q0), each element two values (wavelengths 2q, 2q + 1); pos = the
- * site's position in the ANGLE's order of its native planes (vrt_plan_get_native_order).
+ * site's position in the storage order of the angle's direction (vrt_grid_get_storage_order).
  * B = 1: element (l, pos) at ((l/2) * n + pos) * 2 + l%2.  Written by vrt_plan_alpha_to_native_dev
  * or vrt_line_opacity_dev -- callers need not know the layout; it saves the 2 x 8 B per (site,
  * angle, wavelength) of the layout change on every execute. */
@@ -149,12 +149,6 @@ int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS
  * storage order of a direction: out[pos] = 1-based site id at storage position pos (layers
  * contiguous like perm_up / perm_down, sites of a layer along a Morton curve over (x, y)). */
 int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out);
-/* the order of an angle's NATIVE per-angle planes (the native alpha of VRT_ALPHA_ANGLE_NATIVE): out[pos] = 1-based site id
- * at position pos, angle = index into the plan's directions.  Layers are contiguous as in the direction's storage order;
- * inside a layer the plan lists first the sites that sites of a later layer have as an upwind FOR THIS ANGLE -- a later
- * layer's gathers then fall into one dense run (option VRT_ANGLE_ORDER, default 1, plan creation only; 0: the
- * direction's storage order for every angle).  S, J and the other alpha layouts are not affected. */
-int vrt_plan_get_native_order(const vrt_plan *p, int64_t angle, int64_t *out);
 /* number of doubles of the native per-angle alpha buffer for nlam wavelengths */
 int64_t vrt_plan_native_alpha_count(const vrt_plan *p, int64_t nlam);
 /* pairs per block B of the plan's native layout (1, 2, 4, 8 or 16; option VRT_PAIR_BLOCK at creation) */

@@ -184,7 +184,7 @@ def test_C4_1M_per_angle_alpha_51_wavelengths(grid_1m):
     B = plan.native_pair_block
     npad = 52
     for a_i, l in ((7, 33), (2, 50), (11, 0)):
-        order = plan.native_order(a_i) - 1
+        order = hs.storage_order(1 if th[a_i] > 90 else -1) - 1
         q = l // 2
         widths = [B] * (26 // B) + [1 << b for b in range(B.bit_length() - 2, -1, -1) if (26 % B) & (1 << b)]
         q0 = 0

@@ -1186,9 +1186,6 @@ def test_sweep_order_S_and_J_are_the_caller_layout_results_bit_for_bit(grids, mo
     w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
     n1 = int(so.layers_up[1] - 1)
     I0 = S[so.perm_up[:n1] - 1].copy()
-    if pathopt == "steps":
-        # (the steps kernels read a native per-angle alpha only in the direction's storage order: a plan without the angles' own orders)
-        monkeypatch.setenv("VRT_ANGLE_ORDER", "0")
     plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
     if pathopt == "steps":
         plan.set_option("VRT_PATH", "steps")

@@ -73,7 +73,6 @@ PROTOTYPES = {
     "vrt_plan_execute_native_dev": (ctypes.c_int, [vp, c_i64, vp, vp, vp, ctypes.c_int, vp, vp, p_dbl, vp, vp, vp]),
     "vrt_plan_check": (ctypes.c_int, [vp]),
     "vrt_grid_get_storage_order": (ctypes.c_int, [vp, ctypes.c_int, p_i64]),
-    "vrt_plan_get_native_order": (ctypes.c_int, [vp, c_i64, p_i64]),
     "vrt_plan_native_alpha_count": (c_i64, [vp, c_i64]),
     "vrt_plan_native_pair_block": (ctypes.c_int, [vp]),
     "vrt_plan_native_pair_block_f32": (ctypes.c_int, [vp]),

@@ -321,13 +321,6 @@ class FormalPlan:
         """Raises if a chained launch of an earlier ASYNCHRONOUS execute gave up (call after synchronising)."""
         check(_lib.load().vrt_plan_check(self._h))
 
-    def native_order(self, angle: int) -> np.ndarray:
-        """1-based site id at every position of the NATIVE per-angle planes of `angle` (index into the plan's
-        directions): the angle's own order of its intensities and of the native per-angle alpha (VRT_ANGLE_ORDER)."""
-        out = np.zeros(self.sites.n, dtype=np.int64)
-        check(_lib.load().vrt_plan_get_native_order(self._h, int(angle), _i(out)))
-        return out
-
     def native_alpha_count(self, nlam: int) -> int:
         """Number of float64 values of the native per-angle alpha buffer (ALPHA_ANGLE_NATIVE)."""
         return int(_lib.load().vrt_plan_native_alpha_count(self._h, nlam))
@@ -344,7 +337,7 @@ class FormalPlan:
 
     def native_to_site_major(self, native, nlam: int, n_angles: int):
         """Host helper (tests, debugging): a native per-angle buffer (numpy float64 or float32) ->
-        (n_angles, n, nlam) with rows in each angle's own order (`native_order`)."""
+        (n_angles, n, nlam) with rows in STORAGE order of each angle's direction."""
         native = np.asarray(native)
         n = self.sites.n
         B = self.native_pair_block_f32 if native.dtype == np.float32 else self.native_pair_block

@@ -27,7 +27,7 @@ void tuning_from_env(Tuning &t)
     static const char *names[] = {"VRT_PATH", "VRT_STEP_K", "VRT_STEP_SINGLE", "VRT_STEP_PAIRS", "VRT_STEP_XCD",
                                   "VRT_STEP_STREAMS", "VRT_STEP_LEVEL_MAP", "VRT_STEP_GROUP_DIR", "VRT_TILE_WIDE",
                                   "VRT_TILE_PRE", "VRT_GRAPH", "VRT_PATCH_K", "VRT_PATCH_NT", "VRT_PATCH_OWN",
-                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_QUAD", "VRT_PATCH_LEAN", "VRT_PATCH_CHAIN", "VRT_CHAIN_PAIRS", "VRT_CHAIN_SPIN", "VRT_CHAIN_DATAFLAG", "VRT_LAMBDA_NATIVE", "VRT_ANGLE_ORDER", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
+                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_QUAD", "VRT_PATCH_LEAN", "VRT_PATCH_CHAIN", "VRT_CHAIN_PAIRS", "VRT_CHAIN_SPIN", "VRT_CHAIN_DATAFLAG", "VRT_LAMBDA_NATIVE", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
                                   "VRT_TILE_DEBUG"};
     for (const char *nm : names) {
         const char *e = std::getenv(nm);
@@ -71,7 +71,7 @@ int tuning_set(Tuning &t, const char *name, const char *value, bool created)
         {"VRT_PATCH_QUAD", &t.patch_quad, 0, 1, true}, {"VRT_PATCH_LEAN", &t.patch_lean, 0, 1, false},
         {"VRT_PATCH_CHAIN", &t.patch_chain, 0, 2, false}, {"VRT_CHAIN_PAIRS", &t.chain_pairs, 1, 256, false},
         {"VRT_CHAIN_SPIN", &t.chain_spin, 1, 1 << 20, false}, {"VRT_CHAIN_DATAFLAG", &t.chain_dataflag, 0, 2, false},
-        {"VRT_LAMBDA_NATIVE", &t.lambda_native, 0, 1, false}, {"VRT_ANGLE_ORDER", &t.angle_order, 0, 1, true}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
+        {"VRT_LAMBDA_NATIVE", &t.lambda_native, 0, 1, false}, {"VRT_DEBUG_FLAGS", &t.debug_flags, 0, 1 << 20, false},
         {"VRT_DEBUG_SKIP_LEVELS", &t.debug_skip_levels, 0, 1, false}, {"VRT_TILE_DEBUG", &t.tile_debug, 0, 1, false},
     };
     for (auto &o : tab)
@@ -263,7 +263,6 @@ static void free_plan(vrt_plan *p)
     if (p->h_chain_dev_pinned) { (void)hipHostFree(p->h_chain_dev_pinned); p->h_chain_dev_pinned = nullptr; }
     if (p->chain_dev_ev) (void)hipEventDestroy(p->chain_dev_ev);
     dev_free(p->e_pos); dev_free(p->e_u1); dev_free(p->e_u2); dev_free(p->e_vis); dev_free(p->e_loc);
-    dev_free(p->d_apos); dev_free(p->d_astore); dev_free(p->e_dA);
     dev_free(p->e_w1); dev_free(p->e_w2); dev_free(p->e_r1); dev_free(p->e_r2);
     if (p->step_fork) (void)hipEventDestroy(p->step_fork);
     for (int i = 0; i < 4; i++) {
@@ -599,10 +598,6 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                 VRT_TRY_FREE(dev_alloc(&p->e_w2, ne));
                 VRT_TRY_FREE(dev_alloc(&p->e_r1, ne));
                 VRT_TRY_FREE(dev_alloc(&p->e_r2, ne));
-                VRT_TRY_FREE(dev_alloc(&p->e_dA, ne));
-                VRT_TRY_FREE(dev_alloc(&p->d_apos, tab));
-                VRT_TRY_FREE(dev_alloc(&p->d_astore, tab));
-                p->angle_order = p->tune.angle_order != 0;
                 VRT_TRY_FREE(dev_alloc(&p->d_patch_rec, (size_t)n_patches));
                 VRT_TRY_FREE(dev_alloc(&p->d_patch_rec2, (size_t)n_patches));
                 p->h_patch_first.assign((size_t)A * (size_t)(maxL + 2), 0);
@@ -636,16 +631,7 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                         for (int64_t j = ps.dep_off[q]; j < ps.dep_off[q + 1]; j++)
                             p->h_patch_deps.push_back(pbase + ps.dep_list[(size_t)j]);
                     }
-                    {
-                        // the angle's own order of its per-angle planes (identity when switched off)
-                        std::vector<int32_t> apos, astore;
-                        const Direction &dd = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-                        build_angle_order(dd, n, p->h_up1.data() + (size_t)a * n, p->h_up2.data() + (size_t)a * n, p->angle_order, apos, astore);
-                        if (hipMemcpy(p->d_apos + (size_t)a * n, apos.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice) != hipSuccess ||
-                            hipMemcpy(p->d_astore + (size_t)a * n, astore.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice) != hipSuccess)
-                            rc2 = VRT_ENODEVICE;
-                    }
-                    if (ne_a && !rc2) {
+                    if (ne_a) {
                         if (hipMemcpy(p->e_pos + ent_base, ps.entry_pos.data(), sizeof(int32_t) * ne_a, hipMemcpyHostToDevice) != hipSuccess ||
                             hipMemcpy(p->e_vis + ent_base, ps.entry_vis.data(), sizeof(uint32_t) * ne_a, hipMemcpyHostToDevice) != hipSuccess ||
                             hipMemcpy(p->e_loc + ent_base, ps.entry_loc.data(), sizeof(uint32_t) * ne_a, hipMemcpyHostToDevice) != hipSuccess)
@@ -800,8 +786,7 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_, c
         // the native layout IS the storage order of the layer paths
         // (laid out for the patch path when the grid fits it: then the steps path can only read it with one pair per block)
         if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE) {
-            // (... and in the angles' own orders where the plan has them: only the patch kernels read those)
-            const bool steps_can = steps_ok && !f32 && native_lg(p, f32) == 0 && !(p->patch_ok && p->angle_order);
+            const bool steps_can = steps_ok && !f32 && native_lg(p, f32) == 0;
             if (path == 3 && !steps_can) path = 4;
             else if (path != 3 && path != 4) path = p->patch_ok ? 4 : 3;
         }
@@ -1327,29 +1312,6 @@ int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out)
     if (!g || !out) return fail(VRT_EINVAL, "NULL argument");
     const Direction &d = direction_of(g, dir);
     for (int64_t i = 0; i < g->n; i++) out[i] = (int64_t)d.store[(size_t)i] + 1;
-    return VRT_OK;
-}
-
-int vrt_plan_get_native_order(const vrt_plan *p, int64_t angle, int64_t *out)
-{
-    if (!p || !out) return fail(VRT_EINVAL, "NULL argument");
-    if (angle < 0 || angle >= p->n_angles_user) return fail(VRT_EINVAL, "angle out of range");
-    int a = -1;
-    for (int j = 0; j < p->A; j++)
-        if (p->user_of_active[(size_t)j] == (int)angle) a = j;
-    const int64_t n = p->g->n;
-    if (a < 0) return fail(VRT_EINVAL, "the angle is not active (theta = 90)");
-    const Direction &d = p->dir_of_active[(size_t)a] > 0 ? p->g->up : p->g->down;
-    if (!p->d_astore || !p->angle_order) {
-        for (int64_t i = 0; i < n; i++) out[i] = (int64_t)d.store[(size_t)i] + 1;
-        return VRT_OK;
-    }
-    DeviceScope scope;
-    int rc = use_device(p->g->device);
-    if (rc) return rc;
-    std::vector<int32_t> h((size_t)n);
-    VRT_HIP_TRY(hipMemcpy(h.data(), p->d_astore + (size_t)a * (size_t)n, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n; i++) out[i] = (int64_t)h[(size_t)i] + 1;
     return VRT_OK;
 }
 

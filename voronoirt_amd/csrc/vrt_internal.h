@@ -138,9 +138,6 @@ struct Tuning {
     int chain_dataflag = 2;       // VRT_CHAIN_DATAFLAG: the chained launch's intensities as their own flags: 0 never, 1 wherever
                                   //   the kernel exists, 2 auto (one or two wavelength pairs: the planes are filled per step)
     int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
-    int angle_order = 1;          // VRT_ANGLE_ORDER: the per-angle planes (intensities, native per-angle opacity) ordered per ANGLE --
-                                  //   the sites a later layer gathers first in every layer (vrt_patch.cpp: build_angle_order;
-                                  //   creation only: the native per-angle alpha of the plan is laid out with it)
     int lambda_native = 1;        // VRT_LAMBDA_NATIVE: the Λ-iteration session keeps S and J in sweep order between its steps
                                   //   (read when a session is created; 0: the caller's layout, two layout changes per iteration)
     int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)
@@ -275,12 +272,6 @@ struct vrt_plan {
     int2 *d_patch_rec2 = nullptr;        // per patch: levels, active angle
     int32_t *e_pos = nullptr, *e_u1 = nullptr, *e_u2 = nullptr;
     uint32_t *e_vis = nullptr, *e_loc = nullptr;
-    // per-angle position order of the per-angle planes (vrt_patch.cpp: build_angle_order): [A][n] storage position -> position,
-    // position -> site; per entry the differences (position - storage position) of the site and its two upwinds as 16-bit
-    // numbers: x = own | upwind 1 << 16, y = upwind 2
-    bool angle_order = false;
-    int32_t *d_apos = nullptr, *d_astore = nullptr;
-    uint2 *e_dA = nullptr;
     double *e_w1 = nullptr, *e_w2 = nullptr, *e_r1 = nullptr, *e_r2 = nullptr;
     std::vector<int2> h_patch_rec2;      // per patch: levels, active angle
     std::vector<int64_t> h_patch_dep_off;   // per patch: the patches (plan-wide indices) whose stored intensities it gathers
@@ -385,8 +376,6 @@ struct PatchSchedule {
 void build_patch_schedule(const Direction &dir, bool ascending, int64_t n, int n_sweeps, const int32_t *up1,
                           const int32_t *up2, int own_target, int entry_cap, PatchSchedule &out, int threads = 1,
                           LayerSchedule *layers = nullptr);
-void build_angle_order(const Direction &dir, int64_t n, const int32_t *up1, const int32_t *up2, bool enabled,
-                       std::vector<int32_t> &apos, std::vector<int32_t> &astore);
 // (`layers`: also filled with what build_layer_schedule returns for the angle -- the same analysis, done layer by layer
 //  here -- whenever its packed encoding fits; !layers->ok with bad_site < 0 means "ask build_layer_schedule")
 

@@ -103,9 +103,7 @@ static int alpha_to_native_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dal
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
     for (int a = 0; a < p->A; a++) {
         const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
-        // (the native per-angle alpha follows the ANGLE's own order where the plan has one: vrt_patch.cpp, build_angle_order)
-        const int32_t *order = p->angle_order ? p->d_astore + (size_t)a * (size_t)n : dir.d_store;
-        hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2 << native_lg(p, sizeof(T) == 4), order,
+        hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2 << native_lg(p, sizeof(T) == 4), dir.d_store,
                            dalpha + (size_t)p->user_of_active[(size_t)a] * (size_t)n * (size_t)ld,
                            out + (size_t)a * plane, (const T *)nullptr, (T *)nullptr);
     }
@@ -323,8 +321,6 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     ChainPrep cp{};
     bool prep_ctrl = false;
     const bool use_dir[2] = {p->n_up > 0, p->n_down > 0};
-    // the per-angle planes (intensities, per-angle alpha) in the ANGLE's own order: the patch kernels only (build_angle_order)
-    const bool aorder = patches && p->angle_order;
     // sweep-order S and J handed over by the caller (vrt_plan_execute_native_dev): the layer paths read / write them in place
     const bool nat = p->nat_mode;
     if (nat && (!steps || lb != 2)) return fail(VRT_EINVAL, "sweep-order S and J need a layer path with one wavelength pair per block");
@@ -428,7 +424,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             const dim3 bgrid((unsigned)((dir.n1 + 63) / 64), (unsigned)((nlam + 63) / 64), (unsigned)cnt);
             hipLaunchKernelGGL(k_boundary_sweep_order<T>, bgrid, dim3(256), 0, st, n, (int)nlam, lb, dir.n1,
                                d == 0 ? p->d_angles_up : p->d_angles_down, dir.d_order, dir.d_srank,
-                               d == 0 ? dI0_up : dI0_down, wI, aorder ? p->d_apos : nullptr);
+                               d == 0 ? dI0_up : dI0_down, wI);
         }
     }
     if (prep) {
@@ -440,7 +436,6 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             cp.I = p->d_I;
             for (int a = 0; a < A; a++) cp.down[a] = p->dir_of_active[(size_t)a] > 0 ? 0 : 1;
             cp.fill = 0x7FF87FF8u;
-            cp.apos = aorder ? p->d_apos : nullptr;
             cp.ctrl = p->d_chain_ctrl;                 // (exists from the plan's first chained launch on)
             cp.nctrl = chain_ctrl_words();
             prep_ctrl = cp.ctrl != nullptr;
@@ -458,7 +453,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         for (int a = 0; a < A; a++) {
             const Direction &dir = p->dir_of_active[(size_t)a] > 0 ? g->up : g->down;
             hipLaunchKernelGGL(k_to_sweep_order<T>, tgrid, dim3(256), 0, dir_st[p->dir_of_active[(size_t)a] > 0 ? 0 : 1],
-                               n, (int)nlam, ld, lb, aorder ? p->d_astore + (size_t)a * (size_t)n : dir.d_store, dalpha + (size_t)a * (size_t)n * (size_t)ld,
+                               n, (int)nlam, ld, lb, dir.d_store, dalpha + (size_t)a * (size_t)n * (size_t)ld,
                                reinterpret_cast<T *>(p->ws_AA) + (size_t)a * plane, (const T *)nullptr, (T *)nullptr);
         }
         ta.alpha_angle = p->ws_AA;
@@ -777,8 +772,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
         for (int64_t u = 0; u < p->n_angles_user; u++) {
             const int a = active_of_user[(size_t)u];
             const Direction &dir = (a >= 0 && p->dir_of_active[(size_t)a] < 0) ? g->down : g->up;
-            hipLaunchKernelGGL(k_from_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb,
-                               (aorder && a >= 0) ? p->d_astore + (size_t)a * (size_t)n : dir.d_store,
+            hipLaunchKernelGGL(k_from_sweep_order<T>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store,
                                a >= 0 ? wI + (size_t)a * plane : (const T *)nullptr,
                                dI_out + (size_t)u * (size_t)n * (size_t)ld);
         }

@@ -103,7 +103,6 @@ struct ChainPrep {
     const int32_t *store[2], *rank[2];     // storage position -> site, site -> sweep position, per direction
     const double *I0[2];
     unsigned char down[kMaxAngles];
-    const int32_t *apos;                   // [A][n] storage position -> position in the angle's planes, or NULL
     uint32_t fill;
     uint32_t *ctrl;                        // may be NULL (the chained launch then zeroes its words itself)
     int nctrl;
@@ -152,10 +151,7 @@ k_chain_prepare(ChainPrep cp)
             v = make_double2(f, f);
         }
         // (streaming stores: 47 MB at C2's size that the chained launch reads with system-scope gathers anyway)
-        // the boundary layer's values go to the angle's own positions (a layer is permuted inside itself: every position of
-        // the plane is still written exactly once)
-        const int64_t ea = (cp.apos && pos < cp.n1[d]) ? (int64_t)q * cp.n + cp.apos[(size_t)a * (size_t)cp.n + (size_t)pos] : e;
-        double *dst = cp.I + 2 * ((size_t)a * (size_t)plane + (size_t)ea);
+        double *dst = cp.I + 2 * ((size_t)a * (size_t)plane + (size_t)e);
         __builtin_nontemporal_store(v.x, dst);
         __builtin_nontemporal_store(v.y, dst + 1);
         }
@@ -181,7 +177,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_boundary_sweep_order(int64_t n, int nlam, int lb, int64_t n1, const int32_t *__restrict__ angles,
                        const int32_t *__restrict__ order, const int32_t *__restrict__ srank,
-                       const T *__restrict__ I0, T *__restrict__ I, const int32_t *__restrict__ apos = nullptr /* [A][n]: the angle's own order */)
+                       const T *__restrict__ I0, T *__restrict__ I)
 {
     __shared__ T tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -200,8 +196,7 @@ k_boundary_sweep_order(int64_t n, int nlam, int lb, int64_t n1, const int32_t *_
         const int l = l0 + c;
         // I_0 is ordered like perm[1:n1] (irregular_ray_tracing.jl:33); storage is Morton order
         if (l < nlam && p0 + tx < n1) {
-            int32_t pos = srank[order[p0 + tx]];
-            if (apos) pos = apos[(size_t)a * (size_t)n + (size_t)pos];
+            const int32_t pos = srank[order[p0 + tx]];
             Ia[sw_index(l, pos, n, lb, npair)] = tile[tx][c];
             if (l == nlam - 1 && nl_pad > nlam) Ia[sw_index(nlam, pos, n, lb, npair)] = (T)0;   // padding wavelength
         }

@@ -387,45 +387,4 @@ void build_patch_schedule(const Direction &dir, bool ascending, int64_t n, int n
     }
 }
 
-// ---- per-angle position order of the per-angle planes (the intensities and the native per-angle opacity) -----------------
-// A patch gathers, from the layer before, the intensity and the opacity of the upwinds that leave its layer
-// (irregular_ray_tracing.jl:47-50, :66-75).  In the direction's storage order (layer, Morton) those sites lie among sites
-// nobody of the next layer reads -- on an inclined direction two gathers in three fetch a 128-byte line for one 16-byte
-// element.  The planes that exist per ANGLE are free to order every layer for that angle: first the sites some site of a
-// LATER layer has as an upwind (Morton order among themselves), then the rest.  The gathered sites of a layer then are
-// one dense run, a patch's own sites two runs (the patches themselves are still cut along the direction's order, and S,
-// which is shared by the angles of a direction, stays in it).  apos[storage position] = position in the angle's planes,
-// astore[that position] = site; a layer of 32 768 sites or more keeps the storage order (the kernels carry the
-// difference of the two positions as a 16-bit number).
-void build_angle_order(const Direction &dir, int64_t n, const int32_t *up1, const int32_t *up2, bool enabled,
-                       std::vector<int32_t> &apos, std::vector<int32_t> &astore)
-{
-    apos.resize((size_t)n);
-    astore.resize((size_t)n);
-    for (int64_t q = 0; q < n; q++) {
-        apos[(size_t)q] = (int32_t)q;
-        astore[(size_t)q] = dir.store[(size_t)q];
-    }
-    if (!enabled) return;
-    const std::vector<int64_t> &r = dir.reduced;
-    const int64_t nl = (int64_t)r.size();            // layers 1 .. nl-1
-    std::vector<uint8_t> gathered((size_t)n, 0);     // by site: an upwind of a site of a later layer
-    for (int64_t i = 0; i < n; i++) {
-        const int32_t li = dir.layer_of[(size_t)i];
-        if (li < 2) continue;
-        const int32_t u1 = up1[i], u2 = up2[i];
-        if (u1 >= 0 && dir.layer_of[(size_t)u1] < li) gathered[(size_t)u1] = 1;
-        if (u2 >= 0 && dir.layer_of[(size_t)u2] < li) gathered[(size_t)u2] = 1;
-    }
-    for (int64_t layer = 1; layer < nl; layer++) {
-        const int64_t lo = r[(size_t)layer - 1] - 1, hi = r[(size_t)layer] - 1;     // (the never-visited site at n - 1 stays)
-        if (hi - lo < 2 || hi - lo >= 32768) continue;
-        int64_t at = lo;
-        for (int cls = 1; cls >= 0; cls--)
-            for (int64_t q = lo; q < hi; q++)
-                if (gathered[(size_t)dir.store[(size_t)q]] == cls) apos[(size_t)q] = (int32_t)at++;
-    }
-    for (int64_t q = 0; q < n; q++) astore[(size_t)apos[(size_t)q]] = dir.store[(size_t)q];
-}
-
 }  // namespace vrt

@@ -50,8 +50,6 @@ struct PatchArgs {
     const int32_t *e_pos, *e_u1, *e_u2;     // per entry: storage position of the site and of its two upwinds
     const uint32_t *e_vis, *e_loc;           //   packed visit levels; patch-local tile slots of the upwinds
     const double *e_w1, *e_w2, *e_r1, *e_r2; //   weights and path lengths (irregular_ray_tracing.jl:51,66)
-    const uint2 *e_dA;        //   position in the angle's own planes minus storage position: own | upwind 1 << 16, upwind 2 (16-bit numbers)
-    const int32_t *apos;      // [A][n] storage position -> position in the angle's planes (the J reduction reads through it)
 };
 
 // entry tables of one angle from its storage-order tables
@@ -60,18 +58,14 @@ k_patch_entries(int64_t count, const int32_t *__restrict__ e_pos, const int32_t 
                 const int32_t *__restrict__ t_u2, const double *__restrict__ t_w1, const double *__restrict__ t_w2,
                 const double *__restrict__ t_r1, const double *__restrict__ t_r2, int32_t *__restrict__ e_u1,
                 int32_t *__restrict__ e_u2, double *__restrict__ e_w1, double *__restrict__ e_w2,
-                double *__restrict__ e_r1, double *__restrict__ e_r2, const int32_t *__restrict__ apos, uint2 *__restrict__ e_dA)
+                double *__restrict__ e_r1, double *__restrict__ e_r2)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= count) return;
     const int p = e_pos[e];
-    const int u1 = t_u1[p], u2 = t_u2[p];
-    e_u1[e] = u1; e_u2[e] = u2;
+    e_u1[e] = t_u1[p]; e_u2[e] = t_u2[p];
     e_w1[e] = t_w1[p]; e_w2[e] = t_w2[p];
     e_r1[e] = t_r1[p]; e_r2[e] = t_r2[p];
-    // (a layer is permuted inside itself and holds fewer than 32 768 sites where it is permuted at all: 16 bits each)
-    const uint32_t d0 = (uint32_t)(apos[p] - p) & 0xFFFFu, d1 = (uint32_t)(apos[u1] - u1) & 0xFFFFu, d2 = (uint32_t)(apos[u2] - u2) & 0xFFFFu;
-    e_dA[e] = make_uint2(d0 | (d1 << 16), d2);
 }
 
 int launch_patch_entries(vrt_plan *p, int a, int64_t first, int64_t count)
@@ -81,7 +75,7 @@ int launch_patch_entries(vrt_plan *p, int a, int64_t first, int64_t count)
     hipLaunchKernelGGL(k_patch_entries, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, p->g->stream, count,
                        p->e_pos + first, p->t_u1 + o, p->t_u2 + o, p->t_w1 + o, p->t_w2 + o, p->t_r1 + o,
                        p->t_r2 + o, p->e_u1 + first, p->e_u2 + first, p->e_w1 + first, p->e_w2 + first,
-                       p->e_r1 + first, p->e_r2 + first, p->d_apos + o, p->e_dA + first);
+                       p->e_r1 + first, p->e_r2 + first);
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
@@ -282,19 +276,14 @@ __device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
     T2 *Jd = reinterpret_cast<T2 *>(pa.red.Jd[r]);
     const T2 *I0 = reinterpret_cast<const T2 *>(ta.I);
     const size_t plane = (size_t)pa.npair * (size_t)nn;
-    const size_t blk = (size_t)k0 * (size_t)nn;
     for (int i = 0; i < pa.red.ppb; i++) {
         const size_t f = ((size_t)b * pa.red.ppb + i) * NT + tid;
         if (f >= run) break;
         const size_t e = base + f;
-        // an angle keeps its intensities in its own order (build_angle_order): J_dir, in the direction's storage order, reads
-        // them through the angle's position map -- two interleaved runs per layer instead of one
-        const size_t posn = (size_t)pa.red.lo[r] + (f >> lw), sub = f & (((size_t)1 << lw) - 1);
         double ax = 0.0, ay = 0.0;
         for (int j = 0; j < pa.red.count[r]; j++) {          // the reference's angle order (lambda_iteration.jl:84,102,107)
             const int a = pa.red.angles[r][j];
-            const size_t ea = pa.apos ? blk + ((size_t)pa.apos[(size_t)a * (size_t)nn + posn] << lw) + sub : e;
-            const double2 v = to_d2(I0[(size_t)a * plane + ea]);
+            const double2 v = to_d2(I0[(size_t)a * plane + e]);
             ax += pa.red.w[a] * v.x;
             ay += pa.red.w[a] * v.y;
         }
@@ -360,7 +349,6 @@ k_patch_solve(PatchArgs pa)
     int *s_pos = reinterpret_cast<int *>(s_r2 + pa.cap);
     int *s_u1 = s_pos + pa.cap, *s_u2 = s_u1 + pa.cap;
     uint32_t *s_vis = reinterpret_cast<uint32_t *>(s_u2 + pa.cap), *s_loc = s_vis + pa.cap;
-    uint32_t *s_dA0 = s_loc + pa.cap, *s_dA1 = s_dA0 + pa.cap;       // positions in the angle's own planes minus storage positions
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int i = tid + k * NT;
@@ -369,8 +357,6 @@ k_patch_solve(PatchArgs pa)
         s_pos[i] = pa.e_pos[e];
         s_u1[i] = pa.e_u1[e];
         s_u2[i] = pa.e_u2[e];
-        const uint2 dA = pa.e_dA[e];
-        s_dA0[i] = dA.x; s_dA1[i] = dA.y;
         s_vis[i] = ok ? pa.e_vis[e] : 0u;
         // an upwind outside the cone reads the zero slot (coupling x a finite 0)
         const uint32_t lc = pa.e_loc[e], l1 = lc & 0xFFFFu, l2 = lc >> 16;
@@ -411,13 +397,9 @@ k_patch_solve(PatchArgs pa)
             // the intensity of an upwind counts when it lies in an EARLIER layer (final); an upwind in this
             // layer enters through the tile, one in a later layer reads 0 (:23): those gather the never-visited
             // site perm[n] at storage position n - 1, whose intensity is 0 in every plane
-            // the intensities and a per-angle opacity live in the ANGLE's own order (vrt_patch.cpp: build_angle_order)
-            const int pA = p + (int)(short)(s_dA0[i] & 0xFFFFu), v1A = v1 + ((int)s_dA0[i] >> 16), v2A = v2 + (int)(short)(s_dA1[i] & 0xFFFFu);
-            int i1 = v1 < lo ? v1A : (int)n - 1, i2 = v2 < lo ? v2A : (int)n - 1;
+            int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
             if (dbg & 16) { i1 = (int)n - 1; i2 = (int)n - 1; }
-            constexpr bool AA = AM == VRT_ALPHA_ANGLE_SITE_LAM;
-            const int ap = AA ? pA : p;
-            const int av1 = (dbg & 32) ? ap : (AA ? v1A : v1), av2 = (dbg & 32) ? ap : (AA ? v2A : v2);       // traffic split (diagnostic build)
+            const int av1 = (dbg & 32) ? p : v1, av2 = (dbg & 32) ? p : v2;       // traffic split (diagnostic build)
             const int sv1 = (dbg & 64) ? p : v1, sv2 = (dbg & 64) ? p : v2;
             const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
 #pragma unroll
@@ -437,7 +419,7 @@ k_patch_solve(PatchArgs pa)
                         AM == VRT_ALPHA_SITE_LAM
                             ? reinterpret_cast<const T2 *>(ta.alpha[d]) + qbase[qi]
                             : reinterpret_cast<const T2 *>(ta.alpha_angle) + (size_t)a * pa.npair * (size_t)n + qbase[qi];
-                    a_c = ldpair(Al, ap, sh); a_1 = ldpair(Al, av1, sh); a_2 = ldpair(Al, av2, sh);
+                    a_c = ldpair(Al, p, sh); a_1 = ldpair(Al, av1, sh); a_2 = ldpair(Al, av2, sh);
                 }
                 const double2 S_c = ldpair(S, p, sh), S_1 = ldpair(S, sv1, sh), S_2 = ldpair(S, sv2, sh);
                 const double2 I_1 = ldpair(I, i1, sh), I_2 = ldpair(I, i2, sh);
@@ -496,7 +478,7 @@ k_patch_solve(PatchArgs pa)
                 for (int qi = 0; qi < Q; qi++) {
                     if (qok[qi] && !((dbg & 8) && ptile[qi * stride + i].x != 1.2345e300)) {
                         T2 *I = reinterpret_cast<T2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n + qbase[qi];
-                        const unsigned off = (unsigned)(s_pos[i] + (int)(short)(s_dA0[i] & 0xFFFFu)) << qsh[qi];
+                        const unsigned off = (unsigned)(own_lo + i) << qsh[qi];
                         *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + off) = from_d2<T>(ptile[qi * stride + i]);
                     }
                 }
@@ -539,7 +521,7 @@ template <int CAP>
 struct EntryTable {
     double *w1, *w2, *r1, *r2;
     int *pos, *u1, *u2;
-    uint32_t *vis, *loc, *dA0, *dA1;
+    uint32_t *vis, *loc;
     __device__ __forceinline__ EntryTable(double2 *tiles, int planes)
     {
         w1 = reinterpret_cast<double *>(tiles + planes * (CAP + 1));
@@ -548,12 +530,7 @@ struct EntryTable {
         u1 = pos + CAP; u2 = u1 + CAP;
         vis = reinterpret_cast<uint32_t *>(u2 + CAP);
         loc = vis + CAP;
-        dA0 = loc + CAP; dA1 = dA0 + CAP;
     }
-    // positions in the ANGLE's planes (intensities, per-angle opacity) of the entry and its upwinds, from their storage positions
-    __device__ __forceinline__ int posA(int tid, int p) const { return p + (int)(short)(dA0[tid] & 0xFFFFu); }
-    __device__ __forceinline__ int u1A(int tid, int v1) const { return v1 + ((int)dA0[tid] >> 16); }
-    __device__ __forceinline__ int u2A(int tid, int v2) const { return v2 + (int)(short)(dA1[tid] & 0xFFFFu); }
     template <typename Tables>       // PatchArgs, or any record with its e_* pointers
     __device__ __forceinline__ void park(const Tables &pa, const PatchItem &it, int tid) const
     {
@@ -567,12 +544,8 @@ struct EntryTable {
         const uint32_t lc = pa.e_loc[e], l1 = lc & 0xFFFFu, l2 = lc >> 16;
         loc[tid] = (l1 == 0xFFFFu ? (uint32_t)it.n_ent : l1) | ((l2 == 0xFFFFu ? (uint32_t)it.n_ent : l2) << 16);
         w1[tid] = pa.e_w1[e]; w2[tid] = pa.e_w2[e]; r1[tid] = pa.e_r1[e]; r2[tid] = pa.e_r2[e];
-        const uint2 dA = pa.e_dA[e];
-        dA0[tid] = dA.x; dA1[tid] = dA.y;
     }
 };
-// bytes of the table per entry (the launches size their dynamic LDS with it)
-constexpr size_t kEntryTableBytes = 4 * sizeof(double) + 7 * sizeof(int32_t);
 
 // what the pair loop of an item reads besides its entry table: the planes of the item's direction / angle
 struct PairIO {
@@ -638,9 +611,9 @@ struct ChainDev;
 constexpr int kCtlItem = 0, kCtlSelf = 1, kCtlNdep = 2, kCtlDepOff = 3, kCtlArgsLo = 4, kCtlArgsHi = 5, kCtlProgLo = 6, kCtlProgHi = 7,
               kCtlBase = 8, kCtlGaveUp = 9, kCtlWords = 12;
 template <int CAP>
-__device__ __forceinline__ uint32_t *chain_ctl_slots(const EntryTable<CAP> &tab) { return tab.dA1 + CAP; }
+__device__ __forceinline__ uint32_t *chain_ctl_slots(const EntryTable<CAP> &tab) { return tab.loc + CAP; }
 template <int CAP>
-__device__ __forceinline__ int32_t *chain_dep_slots(const EntryTable<CAP> &tab) { return reinterpret_cast<int32_t *>(tab.dA1 + CAP + kCtlWords); }
+__device__ __forceinline__ int32_t *chain_dep_slots(const EntryTable<CAP> &tab) { return reinterpret_cast<int32_t *>(tab.loc + CAP + kCtlWords); }
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p)
 {
@@ -890,10 +863,7 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
             // ---- the four optical depths: r (alpha_c + alpha_u) / 2 = (r / 2)(alpha_c + alpha_u) ----------------
             double d1x, d2x, d1y, d2y;
             {
-                // (a per-angle opacity lives in the ANGLE's own order like the intensities: build_angle_order)
-                constexpr bool AA = AM == VRT_ALPHA_ANGLE_SITE_LAM;
-                const int ap = AA ? tab.posA(tid, p) : p;
-                const int av1 = (kDiag && (dbg & 32)) ? ap : (AA ? tab.u1A(tid, v1) : v1), av2 = (kDiag && (dbg & 32)) ? ap : (AA ? tab.u2A(tid, v2) : v2);
+                const int av1 = (kDiag && (dbg & 32)) ? p : v1, av2 = (kDiag && (dbg & 32)) ? p : v2;
                 double2 a_c, a_1, a_2;
                 if constexpr (AM == VRT_ALPHA_SITE) {
                     const T *__restrict__ A1 = reinterpret_cast<const T *>(pa.alpha);
@@ -902,7 +872,7 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
                 } else {
                     const T2 *Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const T2 *>(pa.alpha) + qb
                                                             : reinterpret_cast<const T2 *>(pa.alpha) + (size_t)it.a * pa.npair * (size_t)n + qb;
-                    a_c = to_d2(at(Al, (unsigned)ap << sh)); a_1 = to_d2(at(Al, (unsigned)av1 << sh)); a_2 = to_d2(at(Al, (unsigned)av2 << sh));
+                    a_c = to_d2(at(Al, (unsigned)p << sh)); a_1 = to_d2(at(Al, (unsigned)av1 << sh)); a_2 = to_d2(at(Al, (unsigned)av2 << sh));
                 }
                 const double rh1 = 0.5 * tab.r1[tid], rh2 = 0.5 * tab.r2[tid];
                 d1x = rh1 * (a_c.x + a_1.x); d2x = rh2 * (a_c.x + a_2.x);
@@ -912,7 +882,7 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
             // ---- S and I in flight, the weights one after the other -------------------------------------------------
             // an upwind's intensity counts when it lies in an EARLIER layer (final); otherwise the gather reads the
             // never-visited site at storage position n - 1, whose intensity is 0 in every plane (:23)
-            int i1 = v1 < it.lo ? tab.u1A(tid, v1) : (int)n - 1, i2 = v2 < it.lo ? tab.u2A(tid, v2) : (int)n - 1;
+            int i1 = v1 < it.lo ? v1 : (int)n - 1, i2 = v2 < it.lo ? v2 : (int)n - 1;
             if (kDiag && (dbg & 16)) { i1 = (int)n - 1; i2 = (int)n - 1; }
             const int sv1 = (kDiag && (dbg & 64)) ? p : v1, sv2 = (kDiag && (dbg & 64)) ? p : v2;
             const T2 rS_c = at(Sd + qb, (unsigned)p << sh), rS_1 = at(Sd + qb, (unsigned)sv1 << sh), rS_2 = at(Sd + qb, (unsigned)sv2 << sh);
@@ -997,13 +967,12 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
         }
         __builtin_amdgcn_s_setprio(0);
         if (tid < it.own_cnt && !(kDiag && (dbg & 8) && ptile[tid].x != 1.2345e300)) {
-            const unsigned ownA = (unsigned)tab.posA(tid, tab.pos[tid]);      // (entries 0 .. own_cnt-1 are the owned sites)
             if (CHAIN && !(kDiag && (dbg & 1024))) {
                 const __amdgpu_buffer_rsrc_t rsI = plane_rsrc(Ia + qb, n << sh);
-                BufSc1<T2>::store(rsI, ownA << sh, from_d2<T>(ptile[tid]));
+                BufSc1<T2>::store(rsI, (unsigned)(it.own_lo + tid) << sh, from_d2<T>(ptile[tid]));
             } else {
                 T2 *I = reinterpret_cast<T2 *>(pa.I) + (size_t)it.a * pa.npair * (size_t)n + qb;
-                *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + (ownA << sh)) = from_d2<T>(ptile[tid]);
+                *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + ((unsigned)(it.own_lo + tid) << sh)) = from_d2<T>(ptile[tid]);
             }
         }
         __syncthreads();                                                 // the tile is rewritten by the next pair
@@ -1047,7 +1016,7 @@ __device__ __forceinline__ void quad_pairs(const PairIO &pa, const PatchItem &it
     const int tid = threadIdx.x;
     const int sib2 = it.sib, b0 = it.b0, b1 = it.b1;
     const unsigned n = (unsigned)pa.n;
-    const int n_ent = it.n_ent, own_cnt = it.own_cnt, nlev = it.nlev, a = it.a;
+    const int n_ent = it.n_ent, own_lo = it.own_lo, own_cnt = it.own_cnt, nlev = it.nlev, a = it.a;
     const int lo = it.lo, hi = it.hi;
     constexpr int CAP = NT;
     double2 *tileA = ptile, *tileB = ptile + (CAP + 1);
@@ -1082,10 +1051,7 @@ __device__ __forceinline__ void quad_pairs(const PairIO &pa, const PatchItem &it
             } else {
                 const float2 *Al = AM == VRT_ALPHA_SITE_LAM ? reinterpret_cast<const float2 *>(pa.alpha) + qb
                                                             : reinterpret_cast<const float2 *>(pa.alpha) + (size_t)a * pa.npair * (size_t)n + qb;
-                // (a per-angle opacity lives in the ANGLE's own order like the intensities: build_angle_order)
-                constexpr bool AA = AM == VRT_ALPHA_ANGLE_SITE_LAM;
-                const int ap = AA ? tab.posA(tid, p) : p, av1 = AA ? tab.u1A(tid, v1) : v1, av2 = AA ? tab.u2A(tid, v2) : v2;
-                a_c = at4(Al, (unsigned)ap << sh); a_1 = at4(Al, (unsigned)av1 << sh); a_2 = at4(Al, (unsigned)av2 << sh);
+                a_c = at4(Al, (unsigned)p << sh); a_1 = at4(Al, (unsigned)v1 << sh); a_2 = at4(Al, (unsigned)v2 << sh);
             }
             const double rh1 = 0.5 * s_r1[tid], rh2 = 0.5 * s_r2[tid];
             d1x = rh1 * ((double)a_c.x + (double)a_1.x); d2x = rh2 * ((double)a_c.x + (double)a_2.x);
@@ -1097,9 +1063,9 @@ __device__ __forceinline__ void quad_pairs(const PairIO &pa, const PatchItem &it
         // ---- S and I in flight, the weights of the four wavelengths one after the other --------------------------
         double2 cA, g1A, g2A, cB, g1B, g2B;
         {
-            const float4 S_c = at4(Sd + qb, (unsigned)p << sh), S_1 = at4(Sd + qb, (unsigned)v1 << sh), S_2 = at4(Sd + qb, (unsigned)v2 << sh);
-            const int i1 = v1 < lo ? tab.u1A(tid, v1) : (int)n - 1, i2 = v2 < lo ? tab.u2A(tid, v2) : (int)n - 1;
+            const int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
             const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
+            const float4 S_c = at4(Sd + qb, (unsigned)p << sh), S_1 = at4(Sd + qb, (unsigned)v1 << sh), S_2 = at4(Sd + qb, (unsigned)v2 << sh);
             float4 I_1, I_2;
             if constexpr (CHAIN) {
                 chain_wait(s_dep, bk - b0 + 1, seen);
@@ -1155,13 +1121,12 @@ __device__ __forceinline__ void quad_pairs(const PairIO &pa, const PatchItem &it
         if (tid < own_cnt) {
             const double2 ra = tileA[tid], rb = tileB[tid];
             const float4 out = make_float4((float)ra.x, (float)ra.y, (float)rb.x, (float)rb.y);
-            const unsigned ownA = (unsigned)tab.posA(tid, s_pos[tid]);     // (entries 0 .. own_cnt-1 are the owned sites)
             if constexpr (CHAIN) {
                 const __amdgpu_buffer_rsrc_t rsI = plane_rsrc(Ia + qb, n << sh);
-                BufSc1<float4>::store(rsI, ownA << sh, out);
+                BufSc1<float4>::store(rsI, (unsigned)(own_lo + tid) << sh, out);
             } else {
                 float2 *I = reinterpret_cast<float2 *>(pa.I) + (size_t)a * pa.npair * (size_t)n + qb;
-                *reinterpret_cast<float4 *>(reinterpret_cast<char *>(I) + (ownA << sh)) = out;
+                *reinterpret_cast<float4 *>(reinterpret_cast<char *>(I) + ((unsigned)(own_lo + tid) << sh)) = out;
             }
         }
         __syncthreads();                                     // the tiles are rewritten by the next block
@@ -1211,8 +1176,6 @@ struct ChainDev {
     const int32_t *e_pos, *e_u1, *e_u2;
     const uint32_t *e_vis, *e_loc;
     const double *e_w1, *e_w2, *e_r1, *e_r2;
-    const uint2 *e_dA;
-    const int32_t *apos;       // [A][n] storage position -> position in the angle's planes, or NULL (the same)
     PatchReduce red;           // weights, angle lists ([0] up, [1] down), J_dir planes
     const int4 *items;
     int q_off[9];              // items of queue x: [q_off[x], q_off[x + 1])
@@ -1291,28 +1254,22 @@ __device__ __forceinline__ void chain_reduce(const ChainDev &cd, const ChainDev 
     const T2 *I0 = reinterpret_cast<const T2 *>(cd.ta.I);
     const int count = cd.red.count[r];
     constexpr int lgT2 = Log2Size<T2>::value;
-    const int32_t *apos = cd.apos;
     for (int bk = b0; bk < b1; bk++) {
         const int k0 = bk << LGB;
         const size_t run = (size_t)(hi - lo) << LGB;
         const size_t base = (size_t)k0 * (size_t)nn + ((size_t)lo << LGB);
         for (size_t f = (size_t)tid; f < run; f += NT) {
-            // (the angle's own order of its intensities: see patch_reduce_role)
-            const size_t posn = (size_t)lo + (f >> LGB), sub = f & (((size_t)1 << LGB) - 1);
             double ax = 0.0, ay = 0.0;
             for (int j = 0; j < count; j++) {                // the reference's angle order (lambda_iteration.jl:84,102,107)
                 const int a = cd.red.angles[r][j];
                 const double wa = cd.red.w[a];
-                // (a layer is permuted inside itself, and [lo, hi) are whole layers or pieces of one: the angle's position
-                // stays inside the layer; the descriptor spans the plane block)
-                const __amdgpu_buffer_rsrc_t rs = plane_rsrc(I0 + (size_t)a * plane + (size_t)k0 * (size_t)nn, (unsigned)(((size_t)nn << LGB) << lgT2));
-                const size_t fa = apos ? ((size_t)apos[(size_t)a * (size_t)nn + posn] << LGB) + sub : ((size_t)lo << LGB) + f;
-                T2 raw = BufSc1<T2>::load(rs, (unsigned)(fa << lgT2));
+                const __amdgpu_buffer_rsrc_t rs = plane_rsrc(I0 + (size_t)a * plane + base, (unsigned)(run << lgT2));
+                T2 raw = BufSc1<T2>::load(rs, (unsigned)(f << lgT2));
                 if constexpr (MODE == 2) {                    // the value is its own flag: repeat while it holds the fill pattern
                     uint32_t spins = 0;
                     while (chain_is_sentinel(raw) && !(kDiag && (cd.dbg & 256))) {
                         __builtin_amdgcn_s_sleep(2);
-                        raw = BufSc1<T2>::load(rs, (unsigned)(fa << lgT2));
+                        raw = BufSc1<T2>::load(rs, (unsigned)(f << lgT2));
                         if (++spins > kChainDataSpins) {
                             chain_data_give_up_cd(cdp, item);
                             break;
@@ -1628,10 +1585,8 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     pa.e_pos = p->e_pos; pa.e_u1 = p->e_u1; pa.e_u2 = p->e_u2;
     pa.e_vis = p->e_vis; pa.e_loc = p->e_loc;
     pa.e_w1 = p->e_w1; pa.e_w2 = p->e_w2; pa.e_r1 = p->e_r1; pa.e_r2 = p->e_r2;
-    pa.e_dA = p->e_dA;
-    pa.apos = p->angle_order ? p->d_apos : nullptr;
     const dim3 grid((unsigned)(pa.red.nred + (w1 - w0) * pa.ngrp));
-    const size_t lds = (size_t)(pa.quad ? 2 : Q) * (size_t)pa.stride * sizeof(double2) + (size_t)pa.cap * kEntryTableBytes;
+    const size_t lds = (size_t)(pa.quad ? 2 : Q) * (size_t)pa.stride * sizeof(double2) + (size_t)pa.cap * (4 * sizeof(double) + 5 * sizeof(int32_t));
     const int rc = f32 ? launch_mode<float>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa)
                        : launch_mode<double>(ta.alpha_mode, p->patch_K, Q, p->patch_NT, grid, lds, st, pa);
     return rc;
@@ -1878,8 +1833,6 @@ int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t s
     h.e_pos = p->e_pos; h.e_u1 = p->e_u1; h.e_u2 = p->e_u2;
     h.e_vis = p->e_vis; h.e_loc = p->e_loc;
     h.e_w1 = p->e_w1; h.e_w2 = p->e_w2; h.e_r1 = p->e_r1; h.e_r2 = p->e_r2;
-    h.e_dA = p->e_dA;
-    h.apos = p->angle_order ? p->d_apos : nullptr;
     if (reduce) h.red = *reduce;
     h.items = p->d_chain_items;
     for (int x = 0; x <= 8; x++) h.q_off[x] = p->chain_q_off[x];
@@ -1913,7 +1866,7 @@ int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t s
     }
     const uint32_t base = p->chain_epoch << 8;
     if (!ctrl_zeroed) VRT_HIP_TRY(hipMemsetAsync(p->d_chain_ctrl, 0, sizeof(uint32_t) * (kChainAbortWord + 4), st));
-    const size_t lds = (size_t)(quad ? 2 : 1) * (size_t)(p->patch_cap + 1) * sizeof(double2) + (size_t)p->patch_cap * kEntryTableBytes +
+    const size_t lds = (size_t)(quad ? 2 : 1) * (size_t)(p->patch_cap + 1) * sizeof(double2) + (size_t)p->patch_cap * (4 * sizeof(double) + 5 * sizeof(int32_t)) +
                        sizeof(uint32_t) * (kCtlWords + 64 + kChainDepLds);
     const ChainDev *cd = reinterpret_cast<const ChainDev *>(p->d_chain_dev);
     switch (ta.alpha_mode) {

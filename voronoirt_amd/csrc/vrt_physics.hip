@@ -172,14 +172,14 @@ k_line_opacity(int64_t n, int nlam, int npair, int lgB, const int32_t *__restric
                const double *__restrict__ doppler, const double *__restrict__ gamma,
                const double *__restrict__ strength, const double *__restrict__ alpha_cont,
                T2 *__restrict__ out0 /* pair planes of the plan's native layout (vrt_device.h: pair_index), angle after angle */,
-               size_t plane_pairs, const int32_t *__restrict__ astore /* [A][n] position -> site of the angle's own order, or NULL */)
+               size_t plane_pairs)
 {
     exp2_table_fill();
     __syncthreads();
     const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= n) return;
     const int ia = blockIdx.y;
-    const int32_t site = astore ? astore[(size_t)ia * (size_t)n + (size_t)pos] : (ang.down[ia] ? store_down : store_up)[pos];
+    const int32_t site = (ang.down[ia] ? store_down : store_up)[pos];
     T2 *__restrict__ out = out0 + (size_t)ia * plane_pairs;
     // v_los = dot(velocity, -k)   (line.jl:126, :205)
     const double v_los = velocity[3 * (size_t)site] * (-ang.k[ia][0]) + velocity[3 * (size_t)site + 1] * (-ang.k[ia][1]) +
@@ -228,11 +228,11 @@ int launch_line_opacity(vrt_plan *p, int64_t nlam, const double *d_lambda, doubl
     if (f32_out)
         hipLaunchKernelGGL(k_line_opacity<float2>, grid, dim3(256), 0, st, n, (int)nlam, npair, native_lg(p, f32_out), g->up.d_store,
                            g->down.d_store, ang, d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma, d_strength, d_alpha_cont,
-                           reinterpret_cast<float2 *>(d_out), plane_pairs, p->angle_order ? p->d_astore : nullptr);
+                           reinterpret_cast<float2 *>(d_out), plane_pairs);
     else
         hipLaunchKernelGGL(k_line_opacity<double2>, grid, dim3(256), 0, st, n, (int)nlam, npair, native_lg(p, f32_out), g->up.d_store,
                            g->down.d_store, ang, d_lambda, lambda0, c0, d_velocity, d_doppler, d_gamma, d_strength, d_alpha_cont,
-                           reinterpret_cast<double2 *>(d_out), plane_pairs, p->angle_order ? p->d_astore : nullptr);
+                           reinterpret_cast<double2 *>(d_out), plane_pairs);
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
