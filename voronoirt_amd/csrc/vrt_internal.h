@@ -138,6 +138,7 @@ struct Tuning {
     int chain_dataflag = 2;       // VRT_CHAIN_DATAFLAG: the chained launch's intensities as their own flags: 0 never, 1 wherever
                                   //   the kernel exists, 2 auto (one or two wavelength pairs: the planes are filled per step)
     int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
+    int chain_static = 1;         // VRT_CHAIN_STATIC: the progress-word form of the chained launch maps block -> item statically (0: tickets)
     int lambda_native = 1;        // VRT_LAMBDA_NATIVE: the Λ-iteration session keeps S and J in sweep order between its steps
                                   //   (read when a session is created; 0: the caller's layout, two layout changes per iteration)
     int debug_flags = 0, debug_skip_levels = 0, tile_debug = 0;   // timing diagnostics (-DVRT_DIAG build only)

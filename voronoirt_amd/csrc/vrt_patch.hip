@@ -1185,6 +1185,7 @@ struct ChainDev {
     uint32_t *host_status;     // mapped host word: non-zero once a spin has expired
     int64_t n_patches;
     uint32_t spin_limit;
+    int static_items;          // block b takes item b >> 3 of queue b & 7 (no ticket)
     int dbg;                   // timing diagnostics (-DVRT_DIAG build only, WRONG results): the flags of PatchArgs::dbg, and
                                //   256 no waiting for dependencies, 512 plain (L1-cached) intensity gathers, 1024 plain intensity stores, 2048 no pair loop
 };
@@ -1306,6 +1307,16 @@ __device__ __forceinline__ void chain_item(const ChainDev &ca, const ChainDev *c
         // queue -> the next one (load balance at the end)
         uint32_t *ctrl = ca.ctrl;
         int q = (int)(blockIdx.x & 7u), idx = -1;
+        // Progress-word launches: block b IS item b >> 3 of queue b & 7 -- the queues are padded to one length, the hardware
+        // starts the blocks of an XCD in order, and a workgroup waits only for items of earlier layers, i.e. for blocks that
+        // were started before it: the ticket's round trip through the L2 (1 of the ~5 us an item spends before its first
+        // gather) buys nothing there (1 M sites x 7 wavelengths: 1.86 -> 1.75 ms).  The data-as-flag launches of one or two
+        // pairs keep the tickets: an XCD's freed slot then takes the OLDEST item left, whichever queue it is in (C2: 0.431
+        // against 0.437 ms).
+        if (ca.static_items) {
+            const int o0 = ca.q_off[q], len = ca.q_off[q + 1] - o0, t = (int)(blockIdx.x >> 3);
+            if (t < len) idx = o0 + t;
+        } else
         for (int tries = 0; tries < 8; tries++) {
             const int o0 = ca.q_off[q], len = ca.q_off[q + 1] - o0;
             const uint32_t t = len > 0 ? __hip_atomic_fetch_add(ctrl + q * kChainHeadStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -1842,6 +1853,12 @@ int launch_patch_chain(vrt_plan *p, const TileArgs &ta, int npair, hipStream_t s
     h.host_status = p->d_chain_status;
     h.n_patches = p->n_patches;
     h.spin_limit = (uint32_t)std::max(1, p->tune.chain_spin) << 10;
+    {
+        // (static only while every queue holds the same number of items: ensure_patch_chain pads them so)
+        bool even = true;
+        for (int x = 1; x < 8; x++) even = even && (p->chain_q_off[x + 1] - p->chain_q_off[x]) == (p->chain_q_off[1] - p->chain_q_off[0]);
+        h.static_items = (!dataflag && even && p->tune.chain_static != 0) ? 1 : 0;
+    }
     h.dbg = kDiag ? p->tune.debug_flags : 0;
     // the argument block travels only when it has changed (stream-ordered: behind the launches that read the old one)
     if (!p->d_chain_dev) VRT_HIP_TRY(hipMalloc((void **)&p->d_chain_dev, sizeof(ChainDev)));
