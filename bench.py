@@ -48,7 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E vendor peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_ROUND = "r4"
+PROFILE_ROUND = "r5"
 
 WORKLOADS = {
     # name: (a, c, quadrature, nlam, alpha per angle, seed)   -- SURVEY.md 8d, BASELINE.md sec. 3
@@ -88,6 +88,9 @@ def parse_args(argv=None):
                          "in the step; 'caller' = (n, nlam) arrays in, J (n, nlam) out (two layout changes per step); "
                          "auto: native for the per-angle-alpha (line) workloads on one GPU, the caller-layout time is "
                          "reported beside it")
+    ap.add_argument("--no-caller-layout", action="store_true",
+                    help="with --sj-layout native: do not time the caller-layout step beside it (profiling runs: the process "
+                         "then executes the headline step only)")
     ap.add_argument("--alpha0", type=float, default=1.0e-2,
                     help="opacity scale at z_min [1/m] (diagnostics: tiny values take the Taylor branch)")
     ap.add_argument("--dump-J", default="", help="rank 0 saves the (gathered) J of the last step as .npy")
@@ -325,6 +328,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         # J in the caller's layout for the checks below; and the same step over the caller's layout, timed beside it
         plan.J_from_native_dev(nlam, nlam, J_nat[0].data_ptr(), J_nat[1].data_ptr(), J.data_ptr(), stream=stream)
         torch.cuda.synchronize()
+    if sj_native and not args.no_caller_layout:
         J_keep = J.clone()
         sweep_keep = plan.last_sweep_timing()
         sj_native = False

@@ -190,6 +190,23 @@ int vrt_plan_execute_native_dev(vrt_plan *p, int64_t nlam, const double *dS_up, 
                                 const double *dalpha, int alpha_mode, const double *dI0_up, const double *dI0_down,
                                 const double *weights_host, double *dJ_up, double *dJ_down, void *stream);
 
+/* The two steps either side of the sweep in a device-resident Λ-iteration, on the same sweep-order plane sets (what
+ * vrt_lambda_iterate runs internally): vrt_lambda_update_dev -- S_new = (1 - ε) J + ε B and the criterion's maximum
+ * (src/lambda_iteration.jl:261-263, :325-349) -- with J = J_up + J_down, B in the UP order (vrt_plan_to_native_dev, once),
+ * the OLD S read from dS_up and overwritten there, its down-order copy written to dS_down; and vrt_rates_populations_dev
+ * (src/rates.jl:154-201, src/populations.jl:191-221) reading J from the two plane sets.  Arguments otherwise as their
+ * caller-layout counterparts; results bit for bit theirs. */
+int vrt_lambda_update_native_dev(vrt_grid *g, int64_t nlam, const double *dJ_up, const double *dJ_down,
+                                 const double *dB_up, const double *deps, double *dS_up, double *dS_down,
+                                 double *max_rel_change, void *stream);
+int vrt_rates_populations_native_dev(vrt_grid *g, int64_t nlam, const double *lambda, const int64_t blocks[6],
+                                     const double *dJ_up, const double *dJ_down, const double *planck2,
+                                     double lambda0, double c0, const double *d_doppler_width, const double *d_gamma,
+                                     double sigma_bb_const, const double *sigma_bf1, const double *sigma_bf2,
+                                     const double *d_temperature, const double *d_lte_populations, double hc_over_kB,
+                                     double pref_ij, double pref_ji, const double *d_C, const double *d_atom_density,
+                                     double *d_R, double *d_populations, void *stream);
+
 /* fp32 VALUE path (BASELINE config C5): S, alpha, I_0, J and the per-angle intensities are stored
  * as float, halving the bytes of this bandwidth-bound path; the geometry tables and all
  * arithmetic stay fp64.  Results agree with the fp64 solve to fp32 storage rounding (~1e-6

@@ -412,9 +412,14 @@ def test_gpu_lambda_voronoi_device_resident_loop(voro_small):
         J2, S2, pops2, hist2 = vrt.Lambda_voronoi(eps, 10, hs, case, "ul7n12.dat")
         assert len(hist2) == expect
         assert np.abs(S2 / _oracle_lambda_iteration(case, so, "ul7n12.dat", expect)[1] - 1).max() < 1e-9
-    # the same loop for a host without device arrays: library-owned device state, one call per iteration
+    # the same loop for a host without device arrays: library-owned device state, one call per iteration (the session
+    # keeps S and J in sweep order between its steps: no layout change inside the loop, the same numbers)
     Jh, Sh, ph_, hh = vrt.Lambda_voronoi_host(0.0, 4, hs, case, "ul7n12.dat")
     assert np.array_equal(Jh, J) and np.array_equal(Sh, S) and np.array_equal(ph_, pops) and hh == hist
+    # ... and through the public sweep-order entry points (vrt_plan_execute_native_dev, vrt_lambda_update_native_dev,
+    # vrt_rates_populations_native_dev): bit for bit again
+    Jn, Sn, pn, hn = vrt.Lambda_voronoi(0.0, 4, hs, case, "ul7n12.dat", native=True)
+    assert np.array_equal(Jn, J) and np.array_equal(Sn, S) and np.array_equal(pn, pops) and hn == hist
     assert vrt.Lambda_voronoi_host(1.0, 10, hs, case, "ul7n12.dat")[3] == []
     hs.close()
 

@@ -125,8 +125,61 @@ for name, fn, nbytes in steps:
     ms = e0.elapsed_time(e1) / args.reps
     total += ms
     print(f"{name:28s} {ms:8.3f} ms   {nbytes / 1e9:7.2f} GB it must move -> {nbytes / ms / 1e6:7.1f} GB/s of those")
-print(f"{'one iteration':28s} {total:8.3f} ms   (path {plan.last_path})")
+print(f"{'one iteration':28s} {total:8.3f} ms   (path {plan.last_path}; S and J in the caller's (n, nlam) layout)")
 assert torch.isfinite(Jline).all() and torch.isfinite(d_pop).all()
+
+# ---- the same iteration with S and J kept in SWEEP ORDER between the steps (what vrt_lambda_iterate does) ------------------
+cnt = plan.native_plane_count(nbb)
+S_nat = [torch.empty(cnt, device=dev, dtype=torch.float64) for _ in range(2)]
+B_up = torch.empty(cnt, device=dev, dtype=torch.float64)
+Jn = [torch.zeros(cnt, device=dev, dtype=torch.float64) for _ in range(2)]
+plan.to_native_dev(nbb, nbb, S.data_ptr(), S_nat[0].data_ptr(), S_nat[1].data_ptr(), stream=st)
+plan.to_native_dev(nbb, nbb, B.data_ptr(), B_up.data_ptr(), 0, stream=st)
+eps_site = eps[:, 0].contiguous()
+cnt_all = plan.native_plane_count(nlam_all)
+J_all = [torch.zeros(cnt_all, device=dev, dtype=torch.float64) for _ in range(2)]
+plan.to_native_dev(nlam_all, nlam_all, J.data_ptr(), J_all[0].data_ptr(), 0, stream=st)      # (the continuum part of J: as given)
+
+
+def solve_native():
+    plan.execute_native_dev(nbb, S_nat[0].data_ptr(), S_nat[1].data_ptr(), native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE, w,
+                            dJ_up=Jn[0].data_ptr(), dJ_down=Jn[1].data_ptr(), dI0_up=I0.data_ptr(), stream=st)
+
+
+def update_native():
+    api.lambda_update_native_dev(sites, nbb, Jn[0].data_ptr(), Jn[1].data_ptr(), B_up.data_ptr(), eps_site.data_ptr(),
+                                 S_nat[0].data_ptr(), S_nat[1].data_ptr(), stream=st)
+
+
+def rates_native():
+    api.rates_populations_native_dev(sites, lam, blocks, J_all[0].data_ptr(), J_all[1].data_ptr(), planck2, lambda0, C0,
+                                     d_dop.data_ptr(), d_gam.data_ptr(), H_PLANCK * C0 / (4 * np.pi * lambda0) * 4.5e20, sig1, sig2,
+                                     d_T.data_ptr(), d_lte.data_ptr(), H_PLANCK * C0 / K_B, 2 * np.pi / (H_PLANCK * C0) / 1000.0,
+                                     2 * np.pi / (H_PLANCK * C0), d_C.data_ptr(), d_atom.data_ptr(), d_R.data_ptr(),
+                                     d_pop.data_ptr(), stream=st)
+
+
+steps_n = (
+    ("vrt_line_opacity_dev", opacity, 8.0 * (A * n * (nbb + 1) + 8 * n)),
+    ("vrt_plan_execute_native_dev", solve_native, float(n) * A * nbb * (40.0 + 40.0 / nbb)),
+    ("vrt_lambda_update_native_dev", update_native, 8.0 * (6 * n * nbb + n)),              # J_up, J_down, B, S_old in; S_up, S_down out
+    ("vrt_rates_populations_native", rates_native, 8.0 * (2 * n * nlam_all + 30 * n)),
+)
+total_n = 0.0
+for name, fn, nbytes in steps_n:
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.reps
+    total_n += ms
+    print(f"{name:28s} {ms:8.3f} ms   {nbytes / 1e9:7.2f} GB it must move -> {nbytes / ms / 1e6:7.1f} GB/s of those")
+print(f"{'one iteration':28s} {total_n:8.3f} ms   (path {plan.last_path}; S and J in sweep order: no layout change inside the loop)")
+assert all(torch.isfinite(x).all() for x in Jn) and torch.isfinite(d_pop).all()
 plan.close()
 
 # ---- the same from HOST arrays (what the Julia shim calls): PCIe-inclusive wall times ------------------

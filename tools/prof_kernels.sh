@@ -5,7 +5,7 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python3 bench.py --workload C4 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-critical-path "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python3 bench.py --workload C4 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-critical-path --no-caller-layout "$@" > $out/bench.log 2>&1
 f=$(find $out -name '*kernel_stats.csv' | head -1)
 python3 - "$f" <<'PY'
 import csv,sys

@@ -7,7 +7,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" ${PMC_EXTRA:+"$
   name=$(echo $pass | cut -d' ' -f1)
   out=gpurun_out/pmc_${tag}_$name
   rm -rf $out; mkdir -p $out
-  timeout -k 10 300 rocprofv3 --pmc $pass --output-format csv -d $out -o p -- python3 bench.py --workload C4 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-critical-path "$@" > $out/bench.log 2>&1 || { echo "pass $name failed"; tail -3 $out/bench.log; if [ "$pass" = "${PMC_EXTRA:-}" ]; then continue; fi; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $pass --output-format csv -d $out -o p -- python3 bench.py --workload C4 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-critical-path --no-caller-layout "$@" > $out/bench.log 2>&1 || { echo "pass $name failed"; tail -3 $out/bench.log; if [ "$pass" = "${PMC_EXTRA:-}" ]; then continue; fi; exit 1; }
   echo "pass $name done"
 done
 python3 - gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE gpurun_out/pmc_${tag}_TCC_HIT_sum gpurun_out/pmc_${tag}_TCC_EA0_RDREQ_DRAM_sum <<'PY'

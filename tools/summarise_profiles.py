@@ -79,11 +79,18 @@ for k, c in pmc.items():
         for name in list(c):
             c[name] *= 2.0 / per_run
         c["note_scaled_to_per_step_launches"] = 1.0
-per_step = {k: v for k, v in pmc.items() if not any(o in k for o in bench.ONE_TIME_KERNELS)}
+sj_native = str(b["config"].get("sj_layout", "")).startswith("sweep order")
+if sj_native:
+    # S and J stay in sweep order: every layout-change launch of the profiled process is set-up (alpha and S once, J for
+    # the parity check after the timed steps), none belongs to a step
+    for k in list(pmc):
+        if "k_to_sweep_order" in k or "k_combine_J" in k or "k_from_sweep_order" in k:
+            pmc[k]["note_not_part_of_a_step"] = 1.0
+per_step = {k: v for k, v in pmc.items() if not any(o in k for o in bench.ONE_TIME_KERNELS) and "note_not_part_of_a_step" not in v}
 total = sum((2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0 for c in per_step.values())
 summary = {
     "note": "rocprofv3 on MI355X, `python bench.py` default command (C4: 995566 sites x 12 angles x 51 wavelengths, "
-            "fp64, per-angle alpha in the native layout).  kernel_stats: --kernel-trace --stats over 1 warm-up + 3 "
+            "fp64, per-angle alpha in the native layout, S and J in sweep order: vrt_plan_execute_native_dev).  kernel_stats: --kernel-trace --stats over 1 warm-up + 3 "
             "timed steps (tools/prof_kernels.sh); one-time kernels (tables, layout change of alpha) are plan "
             "creation / set-up, not part of a step.  pmc_one_step: separate --pmc passes of ONE step "
             "(tools/prof_pmc.sh), sums over all dispatches of a kernel, FETCH_SIZE / WRITE_SIZE in KiB; per "
@@ -94,6 +101,7 @@ summary = {
             "`queues` the number of hardware queues they ran on.",
     "source_digest": bench.source_digest(),
     "alpha_layout": b["config"].get("alpha_layout"),
+    "sj_layout": "native" if sj_native else "caller",
     "path": b["roofline"]["path"],
     "bench": {"ms_per_step": b["ms_per_step"], "step_event_ms": b["roofline"]["step_event_ms"],
               "sweep_ms": b["roofline"]["sweep_only"]["ms"], "frac": b["roofline"]["frac"]},

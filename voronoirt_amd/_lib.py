@@ -72,6 +72,10 @@ PROTOTYPES = {
     "vrt_plan_j_from_native_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp, vp]),
     "vrt_plan_execute_native_dev": (ctypes.c_int, [vp, c_i64, vp, vp, vp, ctypes.c_int, vp, vp, p_dbl, vp, vp, vp]),
     "vrt_plan_check": (ctypes.c_int, [vp]),
+    "vrt_lambda_update_native_dev": (ctypes.c_int, [vp, c_i64, vp, vp, vp, vp, vp, vp, p_dbl, vp]),
+    "vrt_rates_populations_native_dev": (ctypes.c_int, [vp, c_i64, p_dbl, p_i64, vp, vp, p_dbl, c_dbl, c_dbl, vp, vp,
+                                                        c_dbl, p_dbl, p_dbl, vp, vp, c_dbl, c_dbl, c_dbl, vp, vp, vp,
+                                                        vp, vp]),
     "vrt_grid_get_storage_order": (ctypes.c_int, [vp, ctypes.c_int, p_i64]),
     "vrt_plan_native_alpha_count": (c_i64, [vp, c_i64]),
     "vrt_plan_native_pair_block": (ctypes.c_int, [vp]),

@@ -739,6 +739,31 @@ def lambda_update_dev(sites: VoronoiSites, nlam: int, ld: int, dJ: int, dB: int,
     return out.value
 
 
+def lambda_update_native_dev(sites: VoronoiSites, nlam: int, dJ_up: int, dJ_down: int, dB_up: int, deps: int, dS_up: int,
+                             dS_down: int, stream: int = 0) -> float:
+    """`lambda_update_dev` on sweep-order plane sets (`vrt_lambda_update_native_dev`): J = J_up + J_down, B in the up
+    order, the old S read from and the new S written to dS_up (and its down-order copy to dS_down)."""
+    out = ctypes.c_double()
+    check(_lib.load().vrt_lambda_update_native_dev(sites.handle, nlam, dJ_up or None, dJ_down or None, dB_up, deps, dS_up,
+                                                   dS_down, ctypes.byref(out), stream or None))
+    return out.value
+
+
+def rates_populations_native_dev(sites: VoronoiSites, lam, blocks, dJ_up: int, dJ_down: int, planck2, lambda0: float, c0: float,
+                                 d_doppler: int, d_gamma: int, sigma_bb_const: float, sigma_bf1, sigma_bf2,
+                                 d_temperature: int, d_lte: int, hc_over_kB: float, pref_ij: float, pref_ji: float,
+                                 d_C: int, d_atom_density: int, d_R: int, d_populations: int, stream: int = 0) -> None:
+    """`rates_populations_dev` with J read from the sweep-order plane sets of both directions."""
+    lam, planck2 = _f64(lam), _f64(planck2)
+    blocks = np.ascontiguousarray(blocks, dtype=np.int64)
+    s1, s2 = _f64(sigma_bf1), _f64(sigma_bf2)
+    check(_lib.load().vrt_rates_populations_native_dev(sites.handle, lam.size, _d(lam), _i(blocks), dJ_up or None, dJ_down or None,
+                                                       _d(planck2), float(lambda0), float(c0), d_doppler, d_gamma,
+                                                       float(sigma_bb_const), _d(s1), _d(s2), d_temperature, d_lte,
+                                                       float(hc_over_kB), float(pref_ij), float(pref_ji), d_C, d_atom_density,
+                                                       d_R, d_populations, stream or None))
+
+
 def rates_populations_dev(sites: VoronoiSites, lam, blocks, ld: int, dJ: int, planck2, lambda0: float, c0: float,
                           d_doppler: int, d_gamma: int, sigma_bb_const: float, sigma_bf1, sigma_bf2,
                           d_temperature: int, d_lte: int, hc_over_kB: float, pref_ij: float, pref_ji: float,
@@ -845,6 +870,61 @@ def J_lambda_voronoi_line(S_lambda, populations, sites: VoronoiSites, case: Line
     return J
 
 
+def _Lambda_voronoi_native(eps_conv: float, maxiter: int, sites: VoronoiSites, case: LineCase, quadrature: str, n_sweeps: int):
+    import torch
+    w, th, ph, nq = read_quadrature(quadrature)
+    dev = torch.device("cuda", sites.device)
+    n, nlam = sites.n, int(np.asarray(case.lam).size)
+    plan = FormalPlan(sites, quadrature_directions(th, ph), n_sweeps, dirs=[1 if t > 90 else (-1 if t < 90 else 0) for t in th])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    d_vel, d_dop, d_gs, d_gu, d_ac, d_eps, d_T = (t(getattr(case, k)) for k in
+                                                  ("velocity", "doppler", "gamma_static", "gamma_unsold", "alpha_cont", "eps",
+                                                   "temperature"))
+    d_B, d_lte, d_C, d_atom = t(case.B0), t(case.lte), t(case.C), t(case.atom_density)
+    pops = d_lte.clone()
+    st = torch.cuda.current_stream().cuda_stream
+    cnt = plan.native_plane_count(nlam)
+    S_up, S_dn, B_up, J_up, J_dn = (torch.zeros(cnt, dtype=torch.float64, device=dev) for _ in range(5))
+    plan.to_native_dev(nlam, nlam, d_B.data_ptr(), S_up.data_ptr(), S_dn.data_ptr(), stream=st)      # S_new = B_0
+    plan.to_native_dev(nlam, nlam, d_B.data_ptr(), B_up.data_ptr(), 0, stream=st)
+    native = torch.empty(plan.native_alpha_count(nlam), dtype=torch.float64, device=dev)
+    d_R = torch.empty((n, 3, 3), dtype=torch.float64, device=dev)
+    d_gam, strength = torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
+    n1 = int(sites.layers_up[1] - 1)
+    I0_up = d_B[torch.as_tensor(sites.perm_up[:n1] - 1, device=dev)].contiguous()
+    history = []
+    diff, i = 1.0, 0
+    try:
+        while diff > eps_conv and i < maxiter:
+            line_terms_dev(sites, d_gs.data_ptr(), d_gu.data_ptr(), pops.data_ptr(), case.strength_const, case.Bij, case.Bji,
+                           d_gam.data_ptr(), strength.data_ptr(), stream=st)
+            plan.line_opacity_dev(case.lam, case.lambda0, case.c0, d_vel.data_ptr(), d_dop.data_ptr(), d_gam.data_ptr(),
+                                  strength.data_ptr(), d_ac.data_ptr(), native.data_ptr(), stream=st)
+            plan.execute_native_dev(nlam, S_up.data_ptr(), S_dn.data_ptr(), native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE, w,
+                                    dJ_up=J_up.data_ptr(), dJ_down=J_dn.data_ptr(), dI0_up=I0_up.data_ptr(), stream=st)
+            diff = lambda_update_native_dev(sites, nlam, J_up.data_ptr(), J_dn.data_ptr(), B_up.data_ptr(), d_eps.data_ptr(),
+                                            S_up.data_ptr(), S_dn.data_ptr(), stream=st)
+            new_pops = torch.empty_like(pops)
+            rates_populations_native_dev(sites, case.lam, case.blocks, J_up.data_ptr(), J_dn.data_ptr(), case.planck2, case.lambda0,
+                                         case.c0, d_dop.data_ptr(), d_gam.data_ptr(), case.sigma_bb_const, case.sigma_bf1,
+                                         case.sigma_bf2, d_T.data_ptr(), d_lte.data_ptr(), case.hc_over_kB, case.pref_ij,
+                                         case.pref_ji, d_C.data_ptr(), d_atom.data_ptr(), d_R.data_ptr(), new_pops.data_ptr(), stream=st)
+            pops = new_pops
+            history.append(diff)
+            i += 1
+            if diff != diff:
+                import warnings
+                warnings.warn(f"Lambda_voronoi: NaN DIFF! at iteration {i} -- stopping, results are not converged")
+        J, S = torch.zeros((n, nlam), dtype=torch.float64, device=dev), torch.zeros((n, nlam), dtype=torch.float64, device=dev)
+        plan.J_from_native_dev(nlam, nlam, J_up.data_ptr(), J_dn.data_ptr(), J.data_ptr(), stream=st)
+        plan.from_native_dev(1, nlam, nlam, S_up.data_ptr(), S.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        plan.check()
+        return J.cpu().numpy(), S.cpu().numpy(), pops.cpu().numpy(), history
+    finally:
+        plan.close()
+
+
 def Lambda_voronoi_host(eps_conv: float, maxiter: int, sites: VoronoiSites, case: LineCase, quadrature: str,
                         n_sweeps: int = 3):
     """Λ_voronoi (src/lambda_iteration.jl:205-300) for a host WITHOUT device arrays: the library owns the device
@@ -878,15 +958,20 @@ def Lambda_voronoi_host(eps_conv: float, maxiter: int, sites: VoronoiSites, case
 
 
 def Lambda_voronoi(eps_conv: float, maxiter: int, sites: VoronoiSites, case: LineCase, quadrature: str,
-                   n_sweeps: int = 3):
+                   n_sweeps: int = 3, native: bool = False):
     """Λ_voronoi (src/lambda_iteration.jl:205-300) with everything between two convergence checks on
     the device, over the device-pointer entry points: per iteration `vrt_line_terms_dev` (γ and the line
     strength of the current populations, :72-75), `vrt_line_opacity_dev` (α_tot of every angle, :72-96),
     `vrt_plan_execute_dev` (J_λ, :84-111), `vrt_lambda_update_dev` (S_new and the criterion's scalar, :261-263,
     :325-349) and `vrt_rates_populations_dev` (:269, :274); only that scalar crosses PCIe inside the loop.
     Starts in LTE with S = B_0 like the reference.
+    native=True: S and J stay in the sweep's own per-direction plane sets between the steps
+    (`vrt_plan_execute_native_dev`, `vrt_lambda_update_native_dev`, `vrt_rates_populations_native_dev`): no layout
+    change inside the loop, the same results bit for bit.
     Returns (J, S_new, populations (3, n), history of the criterion's differences) as numpy arrays."""
     import torch
+    if native:
+        return _Lambda_voronoi_native(eps_conv, maxiter, sites, case, quadrature, n_sweeps)
     w, th, ph, nq = read_quadrature(quadrature)
     dev = torch.device("cuda", sites.device)
     n, nlam = sites.n, int(np.asarray(case.lam).size)

@@ -1601,6 +1601,30 @@ int vrt_lambda_update_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *d
     return VRT_OK;
 }
 
+int vrt_lambda_update_native_dev(vrt_grid *g, int64_t nlam, const double *dJ_up, const double *dJ_down, const double *dB_up,
+                                 const double *deps, double *dS_up, double *dS_down, double *max_rel_change, void *stream)
+{
+    DeviceScope scope;
+    if (!g || (!dJ_up && !dJ_down) || !dB_up || !deps || !dS_up || !dS_down || !max_rel_change)
+        return fail(VRT_EINVAL, "NULL argument");
+    if (nlam < 1) return fail(VRT_EINVAL, "need nlam >= 1");
+    int rc = use_device(g->device);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g->mu);
+    if (!g->d_scalars) VRT_HIP_TRY(hipMalloc((void **)&g->d_scalars, 2 * sizeof(unsigned long long)));
+    unsigned long long *d_res = g->d_scalars;
+    rc = launch_lambda_update_native(g, nlam, dJ_up, dJ_down, dB_up, deps, dS_up, dS_down, d_res, st);
+    unsigned long long h[2] = {0, 0};
+    if (!rc && hipMemcpyAsync(h, d_res, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) rc = VRT_ENODEVICE;
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = VRT_ENODEVICE;
+    if (rc) return rc == VRT_ENODEVICE ? fail(rc, "HIP error in vrt_lambda_update_native_dev") : rc;
+    double d;
+    std::memcpy(&d, &h[0], sizeof(double));
+    *max_rel_change = h[1] ? std::nan("") : d;
+    return VRT_OK;
+}
+
 // wavelength-sized host arrays -> the grid's device scratch (caller holds g->mu).  The scratch is
 // shared by successive calls, possibly on different streams: the copy first waits for the kernel of
 // the previous call that read it (small_ev, recorded by small_done after that launch).  The values
@@ -1685,8 +1709,8 @@ int vrt_line_opacity_dev_f32(vrt_plan *p, int64_t nlam, const double *lambda, do
                              d_alpha_cont, d_alpha_native, stream, true);
 }
 
-int vrt_rates_populations_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *lambda,
-                              const int64_t blocks[6], const double *dJ, const double *planck2,
+static int rates_populations_impl(vrt_grid *g, int64_t nlam, int64_t ld, const double *lambda,
+                              const int64_t blocks[6], const double *dJ, const double *dJ_up, const double *dJ_down, const double *planck2,
                               double lambda0, double c0, const double *d_doppler_width, const double *d_gamma,
                               double sigma_bb_const, const double *sigma_bf1, const double *sigma_bf2,
                               const double *d_temperature, const double *d_lte_populations, double hc_over_kB,
@@ -1694,7 +1718,7 @@ int vrt_rates_populations_dev(vrt_grid *g, int64_t nlam, int64_t ld, const doubl
                               double *d_R, double *d_populations, void *stream)
 {
     DeviceScope scope;
-    if (!g || !lambda || !blocks || !dJ || !planck2 || !d_doppler_width || !d_gamma || !sigma_bf1 || !sigma_bf2 ||
+    if (!g || !lambda || !blocks || (!dJ && !dJ_up && !dJ_down) || !planck2 || !d_doppler_width || !d_gamma || !sigma_bf1 || !sigma_bf2 ||
         !d_temperature || !d_lte_populations || !d_C || !d_atom_density || !d_R || !d_populations)
         return fail(VRT_EINVAL, "NULL argument");
     if (nlam < 2 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 2 and ld >= nlam");
@@ -1714,13 +1738,41 @@ int vrt_rates_populations_dev(vrt_grid *g, int64_t nlam, int64_t ld, const doubl
         rc = launch_rates_populations(g, nlam, ld, blocks, g->d_small, dJ, lambda0, c0, d_doppler_width,
                                       d_gamma, sigma_bb_const, d_temperature, d_lte_populations, hc_over_kB,
                                       pref_ij, pref_ji, d_C, d_atom_density, d_R, d_populations,
-                                      (hipStream_t)stream);
+                                      (hipStream_t)stream, dJ_up, dJ_down);
         return rc ? rc : small_done(g, (hipStream_t)stream);
     } catch (const std::bad_alloc &) {
         return fail(VRT_ENOMEM, "out of host memory");
     } catch (...) {
         return fail(VRT_EINVAL, "unexpected exception");
     }
+}
+
+int vrt_rates_populations_dev(vrt_grid *g, int64_t nlam, int64_t ld, const double *lambda,
+                              const int64_t blocks[6], const double *dJ, const double *planck2,
+                              double lambda0, double c0, const double *d_doppler_width, const double *d_gamma,
+                              double sigma_bb_const, const double *sigma_bf1, const double *sigma_bf2,
+                              const double *d_temperature, const double *d_lte_populations, double hc_over_kB,
+                              double pref_ij, double pref_ji, const double *d_C, const double *d_atom_density,
+                              double *d_R, double *d_populations, void *stream)
+{
+    if (!dJ) return fail(VRT_EINVAL, "NULL argument");
+    return rates_populations_impl(g, nlam, ld, lambda, blocks, dJ, nullptr, nullptr, planck2, lambda0, c0, d_doppler_width, d_gamma,
+                                  sigma_bb_const, sigma_bf1, sigma_bf2, d_temperature, d_lte_populations, hc_over_kB, pref_ij, pref_ji,
+                                  d_C, d_atom_density, d_R, d_populations, stream);
+}
+
+int vrt_rates_populations_native_dev(vrt_grid *g, int64_t nlam, const double *lambda, const int64_t blocks[6],
+                                     const double *dJ_up, const double *dJ_down, const double *planck2,
+                                     double lambda0, double c0, const double *d_doppler_width, const double *d_gamma,
+                                     double sigma_bb_const, const double *sigma_bf1, const double *sigma_bf2,
+                                     const double *d_temperature, const double *d_lte_populations, double hc_over_kB,
+                                     double pref_ij, double pref_ji, const double *d_C, const double *d_atom_density,
+                                     double *d_R, double *d_populations, void *stream)
+{
+    if (!dJ_up && !dJ_down) return fail(VRT_EINVAL, "NULL argument");
+    return rates_populations_impl(g, nlam, nlam, lambda, blocks, nullptr, dJ_up, dJ_down, planck2, lambda0, c0, d_doppler_width, d_gamma,
+                                  sigma_bb_const, sigma_bf1, sigma_bf2, d_temperature, d_lte_populations, hc_over_kB, pref_ij, pref_ji,
+                                  d_C, d_atom_density, d_R, d_populations, stream);
 }
 
 static int single_solve(vrt_grid *g, int dir, const double k[3], const double *S, const double *I0,

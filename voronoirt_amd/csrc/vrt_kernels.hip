@@ -490,37 +490,54 @@ k_lambda_update_native(int64_t n, int npair, int nlam, const int32_t *__restrict
                        const double *__restrict__ eps, double2 *__restrict__ Su, double2 *__restrict__ Sd,
                        unsigned long long *__restrict__ result)
 {
+    // one thread per UP position, walking the wavelength pairs: the site, its down position and its ε are looked up once; per
+    // pair four loads and two stores, independent from pair to pair (several in flight).  Neighbouring lanes are neighbouring
+    // up positions: J_up, B, S_up are contiguous, the down-order accesses piecewise contiguous (a layer is a layer in both orders)
     __shared__ double wmax[4];
     __shared__ int wnan[4];
-    const int64_t total = (int64_t)npair * n;
     double d = 0.0;
     bool isnan_ = false;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t q = t / n, pos = t - q * n;
+    for (int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < n; pos += (int64_t)gridDim.x * blockDim.x) {
         const int32_t site = store_up[pos];
-        const int32_t pd = rank_down[site];
-        double2 J = make_double2(0.0, 0.0);
-        if (Ju) J = Ju[t];
-        if (Jd) {
-            const double2 u = Jd[(size_t)q * (size_t)n + (size_t)pd];
-            J.x = J.x + u.x; J.y = J.y + u.y;
-        }
+        const size_t pd = (size_t)rank_down[site];
         const double e = eps[site];
-        const double2 B = Bu[t], So = Su[t];
-        double2 Sn;
-        Sn.x = (1.0 - e) * J.x + e * B.x;
-        Sn.y = (1.0 - e) * J.y + e * B.y;
-        const bool second = 2 * q + 1 < nlam;                  // (an odd count: the padding wavelength is carried as zeros)
-        if (!second) Sn.y = 0.0;
-        Su[t] = Sn;
-        Sd[(size_t)q * (size_t)n + (size_t)pd] = Sn;
-        const double dx = fabs(1.0 - So.x / Sn.x);
-        if (!(dx == dx)) isnan_ = true;
-        else d = fmax(d, dx);
-        if (second) {
-            const double dy = fabs(1.0 - So.y / Sn.y);
-            if (!(dy == dy)) isnan_ = true;
-            else d = fmax(d, dy);
+        constexpr int U = 4;
+        for (int q0 = 0; q0 < npair; q0 += U) {
+            double2 J[U], B[U], So[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int q = q0 + u < npair ? q0 + u : npair - 1;
+                const size_t t = (size_t)q * (size_t)n + (size_t)pos;
+                J[u] = make_double2(0.0, 0.0);
+                if (Ju) J[u] = Ju[t];
+                if (Jd) {
+                    const double2 v = Jd[(size_t)q * (size_t)n + pd];
+                    J[u].x = J[u].x + v.x; J[u].y = J[u].y + v.y;
+                }
+                B[u] = Bu[t];
+                So[u] = Su[t];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int q = q0 + u;
+                if (q >= npair) break;
+                const size_t t = (size_t)q * (size_t)n + (size_t)pos;
+                double2 Sn;
+                Sn.x = (1.0 - e) * J[u].x + e * B[u].x;
+                Sn.y = (1.0 - e) * J[u].y + e * B[u].y;
+                const bool second = 2 * q + 1 < nlam;              // (an odd count: the padding wavelength is carried as zeros)
+                if (!second) Sn.y = 0.0;
+                Su[t] = Sn;
+                Sd[(size_t)q * (size_t)n + pd] = Sn;
+                const double dx = fabs(1.0 - So[u].x / Sn.x);
+                if (!(dx == dx)) isnan_ = true;
+                else d = fmax(d, dx);
+                if (second) {
+                    const double dy = fabs(1.0 - So[u].y / Sn.y);
+                    if (!(dy == dy)) isnan_ = true;
+                    else d = fmax(d, dy);
+                }
+            }
         }
     }
 #pragma unroll
@@ -541,8 +558,7 @@ int launch_lambda_update_native(vrt_grid *g, int64_t nlam, const double *dJ_up, 
 {
     VRT_HIP_TRY(hipMemsetAsync(d_result, 0, 2 * sizeof(unsigned long long), st));
     const int npair = (int)((nlam + 1) / 2);
-    const int64_t total = (int64_t)npair * g->n;
-    const int64_t blocks = std::min<int64_t>((total + 255) / 256, 256 * 16);
+    const int64_t blocks = std::min<int64_t>((g->n + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(k_lambda_update_native, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), 0, st, g->n, npair, (int)nlam,
                        g->up.d_store, g->down.d_srank, reinterpret_cast<const double2 *>(dJ_up), reinterpret_cast<const double2 *>(dJ_down),
                        reinterpret_cast<const double2 *>(dB_up), deps, reinterpret_cast<double2 *>(dS_up),

@@ -353,13 +353,23 @@ k_rates_populations(RatesArgs ra)
     const int64_t slot = valid ? site0 + tid : n - 1;               // (a thread past the end works on the last site and stores nothing)
     const int64_t i = NATIVE ? (int64_t)ra.store_up[slot] : slot;
     const int64_t pdn = NATIVE ? (int64_t)ra.rank_down[i] : 0;
+    int64_t pair_have = -1;
+    double2 pair_J = make_double2(0.0, 0.0);
     auto J_native = [&](int64_t l) -> double {
-        // J = J_up + J_down as k_combine_J forms it
-        const size_t o = (size_t)(l >> 1) * (size_t)n;
-        double v = 0.0;
-        if (ra.J_up) v = ra.J_up[(o + (size_t)slot) * 2 + (size_t)(l & 1)];
-        if (ra.J_down) v = v + ra.J_down[(o + (size_t)pdn) * 2 + (size_t)(l & 1)];
-        return v;
+        // J = J_up + J_down as k_combine_J forms it; the two wavelengths of a pair come with one 16-byte load per direction
+        const int64_t q = l >> 1;
+        if (q != pair_have) {
+            const size_t o = (size_t)q * (size_t)n;
+            double2 v = make_double2(0.0, 0.0);
+            if (ra.J_up) v = reinterpret_cast<const double2 *>(ra.J_up)[o + (size_t)slot];
+            if (ra.J_down) {
+                const double2 u = reinterpret_cast<const double2 *>(ra.J_down)[o + (size_t)pdn];
+                v.x = v.x + u.x; v.y = v.y + u.y;
+            }
+            pair_J = v;
+            pair_have = q;
+        }
+        return (l & 1) ? pair_J.y : pair_J.x;
     };
     // J is (n, ld) with the wavelength fastest: a thread walking its own row makes every load of the wave touch 64
     // different lines.  The block's 256 rows are staged through LDS 16 wavelengths at a time instead (a site's 128
