@@ -258,6 +258,8 @@ static void free_plan(vrt_plan *p)
     dev_free(p->d_level_map);
     dev_free(p->d_patch_rec); dev_free(p->d_patch_rec2); dev_free(p->d_patch_work);
     dev_free(p->d_chain_items); dev_free(p->d_chain_deps); dev_free(p->d_chain_progress); dev_free(p->d_chain_ctrl);
+    for (auto &cs : p->chain_cache) { dev_free(cs.items); dev_free(cs.deps); }
+    p->chain_cache.clear();
     if (p->h_chain_status) { (void)hipHostFree(p->h_chain_status); p->h_chain_status = nullptr; }
     if (p->d_chain_dev) { (void)hipFree(p->d_chain_dev); p->d_chain_dev = nullptr; }
     if (p->h_chain_dev_pinned) { (void)hipHostFree(p->h_chain_dev_pinned); p->h_chain_dev_pinned = nullptr; }

@@ -291,6 +291,16 @@ struct vrt_plan {
     int chain_q_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int chain_npair = -1, chain_lgB = -1, chain_nsplit = -1, chain_reduce = -1;
     int64_t chain_items = 0;
+    // item sets of other (pair count, block, split, reduce) combinations this plan has run: a caller that alternates
+    // wavelength counts, or J and no J, switches between them instead of rebuilding (and freeing: a device synchronisation)
+    struct ChainSet {
+        int npair = -1, lgB = -1, nsplit = -1, reduce = -1;
+        int4 *items = nullptr;
+        int32_t *deps = nullptr;
+        int q_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t n_items = 0;
+    };
+    std::vector<ChainSet> chain_cache;
     uint32_t chain_epoch = 0;
     int32_t *d_patch_work = nullptr;     // work lists of the launches (ensure_patch_work)
     std::vector<int64_t> patch_work_off; //   [group][layer] offsets into it

@@ -1654,6 +1654,38 @@ static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool 
     if (p->d_chain_items && p->chain_npair == npair && p->chain_lgB == lgB && p->chain_nsplit == nsplit &&
         p->chain_reduce == (with_reduce ? 1 : 0))
         return VRT_OK;
+    {
+        // the set in use goes to the plan's small cache, a cached set of this combination comes back (no rebuild, no free)
+        auto stash = [&]() {
+            if (!p->d_chain_items) return;
+            vrt_plan::ChainSet cs;
+            cs.npair = p->chain_npair; cs.lgB = p->chain_lgB; cs.nsplit = p->chain_nsplit; cs.reduce = p->chain_reduce;
+            cs.items = p->d_chain_items; cs.deps = p->d_chain_deps; cs.n_items = p->chain_items;
+            for (int x = 0; x <= 8; x++) cs.q_off[x] = p->chain_q_off[x];
+            p->d_chain_items = nullptr; p->d_chain_deps = nullptr;
+            p->chain_npair = -1;
+            p->chain_cache.push_back(cs);
+            if (p->chain_cache.size() > 3) {                  // (the oldest goes: hipFree waits for the device)
+                (void)hipFree(p->chain_cache.front().items);
+                (void)hipFree(p->chain_cache.front().deps);
+                p->chain_cache.erase(p->chain_cache.begin());
+            }
+        };
+        for (size_t c = 0; c < p->chain_cache.size(); c++) {
+            const vrt_plan::ChainSet cs = p->chain_cache[c];
+            if (cs.npair == npair && cs.lgB == lgB && cs.nsplit == nsplit && cs.reduce == (with_reduce ? 1 : 0)) {
+                p->chain_cache.erase(p->chain_cache.begin() + (long)c);
+                stash();
+                p->d_chain_items = cs.items; p->d_chain_deps = cs.deps; p->chain_items = cs.n_items;
+                for (int x = 0; x <= 8; x++) p->chain_q_off[x] = cs.q_off[x];
+                p->chain_npair = npair; p->chain_lgB = lgB; p->chain_nsplit = nsplit; p->chain_reduce = with_reduce ? 1 : 0;
+                const size_t words = (size_t)nsplit * (size_t)std::max<int64_t>(p->n_patches, 1);
+                if (words <= p->chain_progress_cap) return VRT_OK;
+                break;                                       // (cannot happen: the progress words only grow; rebuild below)
+            }
+        }
+        stash();
+    }
     const vrt_grid *g = p->g;
     const int maxL = p->tile_max_layers, A = p->A;
     const int64_t n = g->n, n_patches = p->n_patches;
@@ -1768,7 +1800,7 @@ static int ensure_patch_chain(vrt_plan *p, int npair, int lgB, int nsplit, bool 
     if (all.size() / 3 >= (size_t)INT32_MAX) return fail(VRT_EINVAL, "too many items for the chained launch");
     std::vector<int32_t> deps(p->h_patch_deps);
     deps.insert(deps.end(), rdeps.begin(), rdeps.end());
-    if (p->d_chain_items) { (void)hipFree(p->d_chain_items); p->d_chain_items = nullptr; }
+    if (p->d_chain_items) { (void)hipFree(p->d_chain_items); p->d_chain_items = nullptr; }     // (stashed above: NULL here)
     if (p->d_chain_deps) { (void)hipFree(p->d_chain_deps); p->d_chain_deps = nullptr; }
     VRT_HIP_TRY(hipMalloc((void **)&p->d_chain_items, sizeof(int4) * std::max<size_t>(all.size(), 1)));
     VRT_HIP_TRY(hipMalloc((void **)&p->d_chain_deps, sizeof(int32_t) * std::max<size_t>(deps.size(), 1)));
