@@ -128,7 +128,8 @@ def pmc_traffic_per_step(workload, path, nlam, world, alpha_layout, sj_layout="c
             return None
         total = 0.0
         for name, c in prof["pmc_one_step"].items():
-            if name.startswith(("vrt::", "void vrt::")) and not any(k in name for k in ONE_TIME_KERNELS):
+            if name.startswith(("vrt::", "void vrt::")) and not any(k in name for k in ONE_TIME_KERNELS) \
+                    and "note_not_part_of_a_step" not in c:
                 total += (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0
         return total if total > 0 else None
     except Exception:
@@ -408,6 +409,8 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         torch.cuda.synchronize()
         floor_ms = plan.last_sweep_timing()[0]
         step()                     # restore J of the full problem (parity check below)
+        if sj_native:              # (the native step leaves J in its plane sets)
+            plan.J_from_native_dev(nlam, nlam, J_nat[0].data_ptr(), J_nat[1].data_ptr(), J.data_ptr(), stream=stream)
         torch.cuda.synchronize()
     # practical ceiling of this box beside the vendor peak: a device triad b = a + b
     # over 2 x 1 GB (2 reads + 1 write per element), measured live
