@@ -435,7 +435,8 @@ int launch_rates_populations(vrt_grid *g, int64_t nlam, int64_t ld, const int64_
 int launch_rates_partial(vrt_grid *g, int64_t nlam, int64_t l0, int64_t l1, int64_t ld, const int64_t blocks[6],
                          const double *d_small, const double *dJ, double lambda0, double c0, const double *d_doppler,
                          const double *d_gamma, double sigma_bb_const, const double *d_temperature, const double *d_lte,
-                         double hc_over_kB, double pref_ij, double pref_ji, double *d_shares, hipStream_t st);
+                         double hc_over_kB, double pref_ij, double pref_ji, double *d_shares, hipStream_t st,
+                         const double *dJ_up = nullptr, const double *dJ_down = nullptr);   // this device's columns as sweep-order planes
 int launch_populations_from_shares(vrt_grid *g, const double *d_shares, const double *d_C, const double *d_atom_density,
                                    double *d_R, double *d_populations, hipStream_t st);
 

@@ -486,6 +486,8 @@ struct LambdaMember {
     double *d_gamma = nullptr, *d_strength = nullptr, *d_pops = nullptr, *d_R = nullptr, *d_shares = nullptr;
     unsigned long long *d_scalars = nullptr;
     hipEvent_t ev = nullptr;
+    // the block's S and J in sweep order between the steps (as the one-device session keeps them: vrt_lambda.cpp)
+    double *d_S_nat[2] = {nullptr, nullptr}, *d_J_nat[2] = {nullptr, nullptr}, *d_B_up = nullptr;
 };
 
 struct vrt_multi_lambda {
@@ -497,6 +499,7 @@ struct vrt_multi_lambda {
     std::vector<double> weights;
     std::vector<LambdaMember> lm;
     int iterations = 0;
+    bool native = false;                // every member keeps its block in sweep order (VRT_LAMBDA_NATIVE, all plans fit)
 };
 
 static void multi_lambda_free(vrt_multi_lambda *s)
@@ -507,7 +510,7 @@ static void multi_lambda_free(vrt_multi_lambda *s)
         (void)hipSetDevice(l.device);                        // (its own copy: the vrt_multi may be gone already)
         for (double *q : {l.d_small, l.d_velocity, l.d_doppler, l.d_gamma_static, l.d_gamma_unsold, l.d_alpha_cont, l.d_eps,
                           l.d_temperature, l.d_atom, l.d_lte, l.d_C, l.d_B0, l.d_S_old, l.d_S_new, l.d_J, l.d_I0, l.d_native,
-                          l.d_gamma, l.d_strength, l.d_pops, l.d_R, l.d_shares})
+                          l.d_gamma, l.d_strength, l.d_pops, l.d_R, l.d_shares, l.d_S_nat[0], l.d_S_nat[1], l.d_J_nat[0], l.d_J_nat[1], l.d_B_up})
             if (q) (void)hipFree(q);
         if (l.d_scalars) (void)hipFree(l.d_scalars);
         if (l.ev) (void)hipEventDestroy(l.ev);
@@ -584,6 +587,10 @@ int vrt_multi_lambda_create(vrt_multi *mm, const vrt_line_case *lc, const double
         s->sigma_bb_const = lc->sigma_bb_const; s->hc_over_kB = lc->hc_over_kB; s->pref_ij = lc->pref_ij; s->pref_ji = lc->pref_ji;
         s->weights.assign(weights, weights + mm->n_angles);
         s->lm.resize((size_t)W);
+        s->native = true;
+        for (const Member &me : mm->m)
+            s->native = s->native && me.plan_all->tune.lambda_native != 0 && native_planes_ok(me.plan_all) == VRT_OK &&
+                        me.plan_all->tune.path != 1 && me.plan_all->tune.path != 2;
         const size_t n = (size_t)mm->n, nl = (size_t)nlam;
         const size_t nb1 = (size_t)(lc->blocks[3] - lc->blocks[2]), nb2 = (size_t)(lc->blocks[5] - lc->blocks[4]);
         std::vector<double> small;
@@ -632,6 +639,17 @@ int vrt_multi_lambda_create(vrt_multi *mm, const vrt_line_case *lc, const double
                               hipMemsetAsync(l.d_J, 0, sizeof(double) * n * nb, st) != hipSuccess))
                 rc = fail(VRT_ENODEVICE, "hipMemsetAsync failed");
             if (!rc && nb) VRT_S(launch_gather_rows(g->up.n1, (int64_t)nb, (int64_t)nb, g->up.d_order, l.d_B0, l.d_I0, st));   // I_0 = B_λ of the bottom layer, :99-101
+            if (s->native && nb) {
+                const size_t np = (size_t)vrt_plan_native_plane_count(me.plan_all, (int64_t)nb);
+                for (int dd = 0; dd < 2; dd++) {
+                    VRT_S(dmalloc(&l.d_S_nat[dd], np));
+                    VRT_S(dmalloc(&l.d_J_nat[dd], np));
+                    if (!rc && hipMemsetAsync(l.d_J_nat[dd], 0, sizeof(double) * np, st) != hipSuccess) rc = fail(VRT_ENODEVICE, "hipMemsetAsync failed");
+                }
+                VRT_S(dmalloc(&l.d_B_up, np));
+                VRT_S(planes_to_native(me.plan_all, (int64_t)nb, (int64_t)nb, l.d_B0, l.d_S_nat[0], l.d_S_nat[1], st));     // S_new = B_0
+                VRT_S(planes_to_native(me.plan_all, (int64_t)nb, (int64_t)nb, l.d_B0, l.d_B_up, nullptr, st));
+            }
 #undef VRT_S
             if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(VRT_ENODEVICE, "uploading the line case failed");
             if (rc) { rcs[(size_t)d] = rc; errs[(size_t)d] = vrt_last_error(); }
@@ -674,7 +692,14 @@ int vrt_multi_lambda_iterate(vrt_multi_lambda *s, double *max_rel_change)
             vrt_grid *g = me.grid;
             std::lock_guard<std::mutex> plock(p->mu);
             int rc = VRT_OK;
-            if (nb > 0) {
+            if (nb > 0 && s->native) {
+                // the block's S and J stay in sweep order: no layout change, no copy of S (the update reads the old S where it writes the new)
+                rc = launch_line_terms(n, l.d_gamma_static, l.d_gamma_unsold, l.d_pops, s->strength_const, s->Bij, s->Bji, l.d_gamma, l.d_strength, st);
+                if (!rc) rc = launch_line_opacity(p, nb, l.d_small + l.l0, s->lambda0, s->c0, l.d_velocity, l.d_doppler, l.d_gamma, l.d_strength, l.d_alpha_cont, l.d_native, st);
+                if (!rc) rc = execute_native_locked(p, nb, l.d_S_nat[0], l.d_S_nat[1], l.d_native, VRT_ALPHA_ANGLE_NATIVE, l.d_I0, nullptr, s->weights.data(),
+                                                    l.d_J_nat[0], l.d_J_nat[1], st);
+                if (!rc) rc = launch_lambda_update_native(g, nb, l.d_J_nat[0], l.d_J_nat[1], l.d_B_up, l.d_eps, l.d_S_nat[0], l.d_S_nat[1], l.d_scalars, st);
+            } else if (nb > 0) {
                 if (hipMemcpyAsync(l.d_S_old, l.d_S_new, sizeof(double) * (size_t)n * (size_t)nb, hipMemcpyDeviceToDevice, st) != hipSuccess)
                     rc = fail(VRT_ENODEVICE, "hipMemcpyAsync");                                                  // S_old = copy(S_new), :258
                 // γ and the line strength of the current populations (:72-75, line.jl:219-225), α_tot of every angle (:89-96)
@@ -689,8 +714,10 @@ int vrt_multi_lambda_iterate(vrt_multi_lambda *s, double *max_rel_change)
                 if (!rc) rc = launch_line_terms(n, l.d_gamma_static, l.d_gamma_unsold, l.d_pops, s->strength_const, s->Bij, s->Bji, l.d_gamma, l.d_strength, st);
             }
             // this block's share of the six rate integrals (rates.jl:154-201)
+            const bool natJ = s->native && nb > 0;
             if (!rc) rc = launch_rates_partial(g, nlam, l.l0, l.l1, std::max<int64_t>(nb, 1), s->blocks, l.d_small, l.d_J, s->lambda0, s->c0, l.d_doppler,
-                                               l.d_gamma, s->sigma_bb_const, l.d_temperature, l.d_lte, s->hc_over_kB, s->pref_ij, s->pref_ji, l.d_shares, st);
+                                               l.d_gamma, s->sigma_bb_const, l.d_temperature, l.d_lte, s->hc_over_kB, s->pref_ij, s->pref_ji, l.d_shares, st,
+                                               natJ ? l.d_J_nat[0] : nullptr, natJ ? l.d_J_nat[1] : nullptr);
             if (rc) { me.rc = rc; me.err = vrt_last_error(); }
         };
         if (!run_workers(W, work)) return fail(VRT_ENOMEM, "out of host memory in a device worker");
@@ -768,8 +795,24 @@ int vrt_multi_lambda_get(vrt_multi_lambda *s, double *J, double *S, double *popu
         const LambdaMember &l = s->lm[d];
         const size_t nb = (size_t)(l.l1 - l.l0);
         VRT_HIP_TRY(hipSetDevice(mm->m[d].device));
+        if (s->native && nb && (J || S)) {
+            // the caller's layout is formed here, on request (d_J / d_S_old of the block serve as scratch)
+            vrt_plan *p = mm->m[d].plan_all;
+            hipStream_t st = mm->m[d].stream;
+            std::lock_guard<std::mutex> plock(p->mu);
+            if (J) {
+                if (int rc = J_from_native(p, (int64_t)nb, (int64_t)nb, l.d_J_nat[0], l.d_J_nat[1], l.d_J, st)) return rc;
+                VRT_HIP_TRY(hipMemcpy2DAsync(J + l.l0, w8 * nl, l.d_J, w8 * nb, w8 * nb, n, hipMemcpyDeviceToHost, st));
+            }
+            if (S) {
+                if (int rc = plane_from_native(p, 0, (int64_t)nb, (int64_t)nb, l.d_S_nat[0], l.d_S_old, st)) return rc;
+                VRT_HIP_TRY(hipMemcpy2DAsync(S + l.l0, w8 * nl, l.d_S_old, w8 * nb, w8 * nb, n, hipMemcpyDeviceToHost, st));
+            }
+            VRT_HIP_TRY(hipStreamSynchronize(st));
+        } else {
         if (nb && J) VRT_HIP_TRY(hipMemcpy2D(J + l.l0, w8 * nl, l.d_J, w8 * nb, w8 * nb, n, hipMemcpyDeviceToHost));
         if (nb && S) VRT_HIP_TRY(hipMemcpy2D(S + l.l0, w8 * nl, l.d_S_new, w8 * nb, w8 * nb, n, hipMemcpyDeviceToHost));
+        }
         if (d == 0) {
             if (populations) VRT_HIP_TRY(hipMemcpy(populations, l.d_pops, w8 * 3 * n, hipMemcpyDeviceToHost));
             if (R) VRT_HIP_TRY(hipMemcpy(R, l.d_R, w8 * 9 * n, hipMemcpyDeviceToHost));

@@ -26,6 +26,15 @@
 
 namespace vrt {
 
+// ---- timing diagnostics of the -DVRT_DIAG build (tools/gather_flags.sh, chain_flags.sh, traffic_split.sh; WRONG results) ----
+// Every switch in the kernels below goes through diag(): in the product build kDiag is false, diag() is the constant
+// `false` and the switched statement is gone -- the hot loops read as what runs when every `diag(...)` is read as `false`.
+enum : int {
+    kDiagNoLevels = 1, kDiagCentreGathers = 2, kDiagNoWeights = 4, kDiagNoStores = 8, kDiagNoGatherI = 16, kDiagNoGatherAlpha = 32,
+    kDiagNoGatherS = 64, kDiagNoReduce = 128, kDiagNoWait = 256, kDiagPlainLoadI = 512, kDiagPlainStoreI = 1024, kDiagNoPairLoop = 2048,
+};
+__host__ __device__ __forceinline__ constexpr bool diag(int dbg, int flag) { return kDiag && (dbg & flag) != 0; }
+
 struct PatchArgs {
     TileArgs ta;              // n, nlam, alpha_mode, angle_dir, lay, nlayers, S, alpha, alpha_angle, I (pair planes)
     int npair;                // ceil(nlam / 2)
@@ -257,7 +266,7 @@ __device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
     int b = blockIdx.x, r = 0;
     if (b >= pa.red.nblk[0]) { b -= pa.red.nblk[0]; r = 1; }
     if (b >= pa.red.nblk[r]) return;                         // padding to a multiple of 8
-    if (kDiag && (pa.dbg & 128)) return;
+    if (diag(pa.dbg, kDiagNoReduce)) return;
     // the range's pair elements of a pair block [k0, k0 + 2^lw) are one contiguous run of the plane,
     // (hi - lo) << lw long: blocks are dealt per pair block (size_reduce counts them the same way)
     const int len = pa.red.hi[r] - pa.red.lo[r];
@@ -335,7 +344,7 @@ k_patch_solve(PatchArgs pa)
     const int2 rec2 = pa.rec2[item];
     const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
     const int dbg = kDiag ? pa.dbg : 0;
-    const int nlev = (dbg & 1) ? 0 : rec2.x, a = rec2.y;
+    const int nlev = diag(dbg, kDiagNoLevels) ? 0 : rec2.x, a = rec2.y;
     const int d = ta.angle_dir[a];
     const int lo = ta.lay[d][pa.layer - 1], hi = ta.lay[d][pa.layer];
     const int64_t n = ta.n;
@@ -393,14 +402,14 @@ k_patch_solve(PatchArgs pa)
             const int i = tid + k * NT;
             const int p = s_pos[i];
             int v1 = s_u1[i], v2 = s_u2[i];
-            if (dbg & 2) { v1 = p; v2 = p; }
+            if (diag(dbg, kDiagCentreGathers)) { v1 = p; v2 = p; }
             // the intensity of an upwind counts when it lies in an EARLIER layer (final); an upwind in this
             // layer enters through the tile, one in a later layer reads 0 (:23): those gather the never-visited
             // site perm[n] at storage position n - 1, whose intensity is 0 in every plane
             int i1 = v1 < lo ? v1 : (int)n - 1, i2 = v2 < lo ? v2 : (int)n - 1;
-            if (dbg & 16) { i1 = (int)n - 1; i2 = (int)n - 1; }
-            const int av1 = (dbg & 32) ? p : v1, av2 = (dbg & 32) ? p : v2;       // traffic split (diagnostic build)
-            const int sv1 = (dbg & 64) ? p : v1, sv2 = (dbg & 64) ? p : v2;
+            if (diag(dbg, kDiagNoGatherI)) { i1 = (int)n - 1; i2 = (int)n - 1; }
+            const int av1 = diag(dbg, kDiagNoGatherAlpha) ? p : v1, av2 = diag(dbg, kDiagNoGatherAlpha) ? p : v2;       // traffic split (diagnostic build)
+            const int sv1 = diag(dbg, kDiagNoGatherS) ? p : v1, sv2 = diag(dbg, kDiagNoGatherS) ? p : v2;
             const bool in1 = (v1 >= lo) & (v1 < hi), in2 = (v2 >= lo) & (v2 < hi);
 #pragma unroll
             for (int qi = 0; qi < Q; qi++) {
@@ -426,7 +435,7 @@ k_patch_solve(PatchArgs pa)
                 const double w1 = s_w1[i], w2 = s_w2[i], r1 = s_r1[i], r2 = s_r2[i];
                 const double wg1 = in1 ? w1 : 0.0, wg2 = in2 ? w2 : 0.0;
                 const double rh1 = 0.5 * r1, rh2 = 0.5 * r2;               // exact: r (α_c + α_u) / 2 = (r / 2)(α_c + α_u)
-                if (dbg & 4) {
+                if (diag(dbg, kDiagNoWeights)) {
                     c[k][qi] = make_double2(a_c.x + S_c.x + I_1.x + a_1.x + S_1.x, a_c.y + S_c.y + I_2.y + a_2.y + S_2.y);
                     g1[k][qi] = make_double2(w1, w2); g2[k][qi] = make_double2(r1, r2);
                     continue;
@@ -476,7 +485,7 @@ k_patch_solve(PatchArgs pa)
             if (i < own_cnt) {
 #pragma unroll
                 for (int qi = 0; qi < Q; qi++) {
-                    if (qok[qi] && !((dbg & 8) && ptile[qi * stride + i].x != 1.2345e300)) {
+                    if (qok[qi] && !(diag(dbg, kDiagNoStores) && ptile[qi * stride + i].x != 1.2345e300)) {
                         T2 *I = reinterpret_cast<T2 *>(ta.I) + (size_t)a * pa.npair * (size_t)n + qbase[qi];
                         const unsigned off = (unsigned)(own_lo + i) << qsh[qi];
                         *reinterpret_cast<T2 *>(reinterpret_cast<char *>(I) + off) = from_d2<T>(ptile[qi * stride + i]);
@@ -859,11 +868,11 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
         {
             const int p = tab.pos[tid];
             int v1 = tab.u1[tid], v2 = tab.u2[tid];
-            if (kDiag && (dbg & 2)) { v1 = p; v2 = p; }          // diagnostics: gathers -> coalesced centre reads
+            if (diag(dbg, kDiagCentreGathers)) { v1 = p; v2 = p; }          // diagnostics: gathers -> coalesced centre reads
             // ---- the four optical depths: r (alpha_c + alpha_u) / 2 = (r / 2)(alpha_c + alpha_u) ----------------
             double d1x, d2x, d1y, d2y;
             {
-                const int av1 = (kDiag && (dbg & 32)) ? p : v1, av2 = (kDiag && (dbg & 32)) ? p : v2;
+                const int av1 = diag(dbg, kDiagNoGatherAlpha) ? p : v1, av2 = diag(dbg, kDiagNoGatherAlpha) ? p : v2;
                 double2 a_c, a_1, a_2;
                 if constexpr (AM == VRT_ALPHA_SITE) {
                     const T *__restrict__ A1 = reinterpret_cast<const T *>(pa.alpha);
@@ -883,17 +892,17 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
             // an upwind's intensity counts when it lies in an EARLIER layer (final); otherwise the gather reads the
             // never-visited site at storage position n - 1, whose intensity is 0 in every plane (:23)
             int i1 = v1 < it.lo ? v1 : (int)n - 1, i2 = v2 < it.lo ? v2 : (int)n - 1;
-            if (kDiag && (dbg & 16)) { i1 = (int)n - 1; i2 = (int)n - 1; }
-            const int sv1 = (kDiag && (dbg & 64)) ? p : v1, sv2 = (kDiag && (dbg & 64)) ? p : v2;
+            if (diag(dbg, kDiagNoGatherI)) { i1 = (int)n - 1; i2 = (int)n - 1; }
+            const int sv1 = diag(dbg, kDiagNoGatherS) ? p : v1, sv2 = diag(dbg, kDiagNoGatherS) ? p : v2;
             const T2 rS_c = at(Sd + qb, (unsigned)p << sh), rS_1 = at(Sd + qb, (unsigned)sv1 << sh), rS_2 = at(Sd + qb, (unsigned)sv2 << sh);
             T2 rI_1, rI_2;
             if constexpr (CHAIN) {
                 // the patches that store these intensities have published this pair (Guideline 16: poll, then sc1 loads)
                 if constexpr (CHAIN == 1) {
-                    if (!(kDiag && (dbg & 256))) chain_wait(s_dep, bk - it.b0 + 1, seen);
+                    if (!diag(dbg, kDiagNoWait)) chain_wait(s_dep, bk - it.b0 + 1, seen);
                 }
                 const __amdgpu_buffer_rsrc_t rsI = plane_rsrc(Ia + qb, n << sh);
-                if (kDiag && (dbg & 512)) {
+                if (diag(dbg, kDiagPlainLoadI)) {
                     rI_1 = at(Ia + qb, (unsigned)i1 << sh);
                     rI_2 = at(Ia + qb, (unsigned)i2 << sh);
                 } else {
@@ -905,16 +914,16 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
                 // what a layer of the chain waits for after its intensities arrive is 14 operations, not ~190
                 if constexpr (CHAIN == 2) {
                     const bool in1 = (v1 >= it.lo) & (v1 < it.hi), in2 = (v2 >= it.lo) & (v2 < it.hi);
-                    if (!(kDiag && (dbg & 4))) {
+                    if (!diag(dbg, kDiagNoWeights)) {
                         LateTerms Lx, Ly;
                         late_lambda(d1x, d2x, (double)rS_1.x, (double)rS_2.x, Lx, d1y);
                         double sink = 0.0;
                         late_lambda(d1y, d2y, (double)rS_1.y, (double)rS_2.y, Ly, sink);
-                        if (!(kDiag && (dbg & 256))) chain_data_wait<T2>(rsI, (unsigned)i1 << sh, (unsigned)i2 << sh, rI_1, rI_2, s_dep);
+                        if (!diag(dbg, kDiagNoWait)) chain_data_wait<T2>(rsI, (unsigned)i1 << sh, (unsigned)i2 << sh, rI_1, rI_2, s_dep);
                         late_apply(Lx, tab.w1 + tid, tab.w2 + tid, in1, in2, (double)rS_c.x, (double)rI_1.x, (double)rI_2.x, c.x, g1.x, g2.x);
                         late_apply(Ly, tab.w1 + tid, tab.w2 + tid, in1, in2, (double)rS_c.y, (double)rI_1.y, (double)rI_2.y, c.y, g1.y, g2.y);
                     } else {
-                        if (!(kDiag && (dbg & 256))) chain_data_wait<T2>(rsI, (unsigned)i1 << sh, (unsigned)i2 << sh, rI_1, rI_2, s_dep);
+                        if (!diag(dbg, kDiagNoWait)) chain_data_wait<T2>(rsI, (unsigned)i1 << sh, (unsigned)i2 << sh, rI_1, rI_2, s_dep);
                         c = make_double2(d1x + (double)rS_c.x + (double)rS_1.x + (double)rI_1.x, d2y + (double)rS_c.y + (double)rS_2.y + (double)rI_2.y);
                         g1 = make_double2(in1 ? d2x : 0.0, in1 ? d1y : 0.0);
                         g2 = make_double2(in2 ? d1x : 0.0, in2 ? d2y : 0.0);
@@ -927,7 +936,7 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
             const bool in1 = (v1 >= it.lo) & (v1 < it.hi), in2 = (v2 >= it.lo) & (v2 < it.hi);
             if constexpr (CHAIN == 2) {
                 // (done above, around the wait)
-            } else if (kDiag && (dbg & 4)) {                     // diagnostics: no weights arithmetic
+            } else if (diag(dbg, kDiagNoWeights)) {                     // diagnostics: no weights arithmetic
                 c = make_double2(d1x + (double)rS_c.x + (double)rS_1.x + (double)rI_1.x, d2y + (double)rS_c.y + (double)rS_2.y + (double)rI_2.y);
                 g1 = make_double2(in1 ? d2x : 0.0, in1 ? d1y : 0.0);
                 g2 = make_double2(in2 ? d1x : 0.0, in2 ? d2y : 0.0);
@@ -952,7 +961,7 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
         if constexpr (CHAIN == 1) {
             if (bk > it.b0 && tid == 0) chain_publish(s_dep, bk - it.b0);   // ... in every wave: pairs b0 .. bk-1 are published
         }
-        const int nlev = (kDiag && (dbg & 1)) ? 0 : it.nlev;
+        const int nlev = diag(dbg, kDiagNoLevels) ? 0 : it.nlev;
         __builtin_amdgcn_s_setprio(VRT_LEVEL_PRIO);
         for (int t = 1; t <= nlev; t++) {
             if ((vis & 0xFFu) == (uint32_t)t) {                          // a site's visits come at increasing levels
@@ -966,8 +975,8 @@ __device__ __forceinline__ void lean_pairs(const PairIO &pa, const PatchItem &it
             __syncthreads();
         }
         __builtin_amdgcn_s_setprio(0);
-        if (tid < it.own_cnt && !(kDiag && (dbg & 8) && ptile[tid].x != 1.2345e300)) {
-            if (CHAIN && !(kDiag && (dbg & 1024))) {
+        if (tid < it.own_cnt && !(diag(dbg, kDiagNoStores) && ptile[tid].x != 1.2345e300)) {
+            if (CHAIN && !diag(dbg, kDiagPlainStoreI)) {
                 const __amdgpu_buffer_rsrc_t rsI = plane_rsrc(Ia + qb, n << sh);
                 BufSc1<T2>::store(rsI, (unsigned)(it.own_lo + tid) << sh, from_d2<T>(ptile[tid]));
             } else {
@@ -1247,7 +1256,7 @@ __device__ __forceinline__ void chain_reduce(const ChainDev &cd, const ChainDev 
 {
     typedef typename Pair<T>::type T2;
     const int tid = threadIdx.x;
-    if (kDiag && (cd.dbg & 128)) return;
+    if (diag(cd.dbg, kDiagNoReduce)) return;
     const int64_t nn = cd.ta.n;
     const int npair = cd.npair;
     const size_t plane = (size_t)npair * (size_t)nn;
@@ -1268,7 +1277,7 @@ __device__ __forceinline__ void chain_reduce(const ChainDev &cd, const ChainDev 
                 T2 raw = BufSc1<T2>::load(rs, (unsigned)(f << lgT2));
                 if constexpr (MODE == 2) {                    // the value is its own flag: repeat while it holds the fill pattern
                     uint32_t spins = 0;
-                    while (chain_is_sentinel(raw) && !(kDiag && (cd.dbg & 256))) {
+                    while (chain_is_sentinel(raw) && !diag(cd.dbg, kDiagNoWait)) {
                         __builtin_amdgcn_s_sleep(2);
                         raw = BufSc1<T2>::load(rs, (unsigned)(f << lgT2));
                         if (++spins > kChainDataSpins) {
@@ -1393,7 +1402,7 @@ __device__ __forceinline__ void chain_item(const ChainDev &ca, const ChainDev *c
         if (QUAD) ptile[NT + 1 + it.n_ent] = make_double2(0.0, 0.0);
     }
     __syncthreads();                                         // the dependency list is in LDS
-    if (kDiag && (ca.dbg & 2048)) it.b1 = it.b0;             // diagnostics: the item's overhead alone
+    if (diag(ca.dbg, kDiagNoPairLoop)) it.b1 = it.b0;             // diagnostics: the item's overhead alone
     if constexpr (QUAD) quad_pairs<AM, NT, true>(pa, it, tab, ptile);
     else lean_pairs<T, AM, NT, MODE>(pa, it, tab, ptile);
     if constexpr (MODE == 2) {

@@ -444,15 +444,37 @@ k_rates_populations(RatesArgs ra)
 // summed across the devices (ONE all-reduce of 6 n doubles: no J travels), then every device solves
 // the statistical equilibrium of every site itself (k_populations_from_shares).
 // shares[q][i], q = (bf1 ij, bf1 ji, bf2 ij, bf2 ji, bb ij, bb ji); J: this device's columns, (l1 - l0) per site
+// NATIVE: this device's columns of J as sweep-order plane sets (local wavelength l - l0), threads on up positions
+template <bool NATIVE>
 __global__ void __launch_bounds__(256)
 k_rates_partial(RatesArgs ra, int64_t l0, int64_t l1, double *__restrict__ shares)
 {
     exp2_table_fill();
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = ra.n;
-    if (i >= n) return;
-    const double *__restrict__ Ji = ra.J + (size_t)i * (size_t)ra.ld - l0;      // indexed by the GLOBAL wavelength
+    if (slot >= n) return;
+    const int64_t i = NATIVE ? (int64_t)ra.store_up[slot] : slot;
+    const int64_t pdn = NATIVE ? (int64_t)ra.rank_down[i] : 0;
+    const double *__restrict__ Ji = NATIVE ? nullptr : ra.J + (size_t)i * (size_t)ra.ld - l0;      // indexed by the GLOBAL wavelength
+    int64_t pair_have = -1;
+    double2 pair_J = make_double2(0.0, 0.0);
+    auto J_at = [&](int64_t l) -> double {
+        if constexpr (!NATIVE) return Ji[l];
+        const int64_t ll = l - l0, q = ll >> 1;
+        if (q != pair_have) {                                   // J = J_up + J_down as k_combine_J forms it
+            const size_t o = (size_t)q * (size_t)n;
+            double2 v = make_double2(0.0, 0.0);
+            if (ra.J_up) v = reinterpret_cast<const double2 *>(ra.J_up)[o + (size_t)slot];
+            if (ra.J_down) {
+                const double2 u = reinterpret_cast<const double2 *>(ra.J_down)[o + (size_t)pdn];
+                v.x = v.x + u.x; v.y = v.y + u.y;
+            }
+            pair_J = v;
+            pair_have = q;
+        }
+        return (ll & 1) ? pair_J.y : pair_J.x;
+    };
     const double hT = ra.hc_over_kB / ra.temperature[i];
     for (int tr = 0; tr < 3; tr++) {                                              // bf level 1, bf level 2, bb
         const int64_t lo = ra.blocks[tr < 2 ? 2 * (tr + 1) : 0], hi = ra.blocks[tr < 2 ? 2 * (tr + 1) + 1 : 1];
@@ -462,7 +484,7 @@ k_rates_partial(RatesArgs ra, int64_t l0, int64_t l1, double *__restrict__ share
         const double r_dD = 1.0 / dD, r_a = 1.0 / (4.0 * kPi * ra.c0 * dD), r_prof = 1.0 / (sqrt(kPi) * dD);
         double rij = 0.0, rji = 0.0;
         for (int64_t l = lo > l0 ? lo : l0; l < (hi < l1 ? hi : l1); l++) {
-            const double lam = ra.lambda[l], Jl = Ji[l];
+            const double lam = ra.lambda[l], Jl = J_at(l);
             double s;
             if (tr < 2) s = sig[l - lo];
             else {
@@ -524,12 +546,18 @@ static void fill_rates_args(RatesArgs &ra, vrt_grid *g, int64_t nlam, int64_t ld
 int launch_rates_partial(vrt_grid *g, int64_t nlam, int64_t l0, int64_t l1, int64_t ld, const int64_t blocks[6],
                          const double *d_small, const double *dJ, double lambda0, double c0, const double *d_doppler,
                          const double *d_gamma, double sigma_bb_const, const double *d_temperature, const double *d_lte,
-                         double hc_over_kB, double pref_ij, double pref_ji, double *d_shares, hipStream_t st)
+                         double hc_over_kB, double pref_ij, double pref_ji, double *d_shares, hipStream_t st,
+                         const double *dJ_up, const double *dJ_down)
 {
     RatesArgs ra;
     fill_rates_args(ra, g, nlam, ld, blocks, d_small, dJ, lambda0, c0, d_doppler, d_gamma, sigma_bb_const, d_temperature, d_lte,
                     hc_over_kB, pref_ij, pref_ji, nullptr, nullptr, nullptr, nullptr);
-    hipLaunchKernelGGL(k_rates_partial, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, st, ra, l0, l1, d_shares);
+    if (dJ_up || dJ_down) {
+        ra.J_up = dJ_up; ra.J_down = dJ_down;
+        ra.store_up = g->up.d_store; ra.rank_down = g->down.d_srank;
+        hipLaunchKernelGGL(k_rates_partial<true>, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, st, ra, l0, l1, d_shares);
+    } else
+    hipLaunchKernelGGL(k_rates_partial<false>, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, st, ra, l0, l1, d_shares);
     VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
