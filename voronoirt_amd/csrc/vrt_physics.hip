@@ -29,6 +29,20 @@
 
 namespace vrt {
 
+// d = a b + c as ONE three-address instruction.  hipcc turns a Horner step whose addend is a constant kept in a vector
+// register into a copy of the constant plus a two-address v_fmac (the opacity kernel: 67 of its 583 vector instructions were
+// such copies, and its time is its vector-instruction count); the three-address form needs no copy.
+__device__ __forceinline__ double fma3(double a, double b, double c)
+{
+#ifdef VRT_NO_FMA3
+    return fma(a, b, c);
+#else
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
+}
+
 struct cplx { double re, im; };
 __device__ __forceinline__ cplx c_mul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cplx c_add(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
@@ -64,11 +78,11 @@ __device__ __forceinline__ double c_div_re(cplx a, cplx b)                // Re(
 __device__ __forceinline__ double cos_poly(double z2)
 {
     double p = -1.0 / 87178291200.0;
-    p = fma(p, z2, 1.0 / 479001600.0);
-    p = fma(p, z2, -1.0 / 3628800.0);
-    p = fma(p, z2, 1.0 / 40320.0);
-    p = fma(p, z2, -1.0 / 720.0);
-    p = fma(p, z2, 1.0 / 24.0);
+    p = fma3(p, z2, 1.0 / 479001600.0);
+    p = fma3(p, z2, -1.0 / 3628800.0);
+    p = fma3(p, z2, 1.0 / 40320.0);
+    p = fma3(p, z2, -1.0 / 720.0);
+    p = fma3(p, z2, 1.0 / 24.0);
     p = fma(p, z2, -0.5);
     return fma(p, z2, 1.0);
 }
@@ -101,7 +115,7 @@ __device__ __forceinline__ void zp_step(double &a, double &b, double r, double m
 {
     const double a0 = a;
     a = fma(r, a0, b);
-    b = fma(ms, a0, c);
+    b = fma3(ms, a0, c);
 }
 __device__ __forceinline__ cplx zp_value(cplx z, double a, double b) { return {fma(z.re, a, b), z.im * a}; }
 
