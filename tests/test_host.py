@@ -869,3 +869,26 @@ def test_host_sanitizer_screen_still_builds():
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "asan_host.sh"), "check"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "loads with every symbol resolved" in r.stdout
+
+
+def test_gloo_world_of_one_runs_the_collectives(tmp_path):
+    """distributed.init_process_group(force=True): a process group also for ONE rank, so that the collectives of the
+    N > 1 modes execute on a single member (what bench.py's VRT_BENCH_FORCE_DIST=1 uses on a one-GPU box, there with
+    the nccl backend); here with gloo on the CPU."""
+    script = tmp_path / "w1.py"
+    script.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, sys.argv[1])\n"
+        "import torch, torch.distributed as dist\n"
+        "from voronoirt_amd import distributed as D\n"
+        "rank, world = D.init_process_group('gloo', force=True)\n"
+        "assert (rank, world) == (0, 1) and dist.is_initialized()\n"
+        "J = torch.arange(12, dtype=torch.float64).reshape(4, 3)\n"
+        "assert torch.equal(D.allreduce_J(J.clone()), J)\n"
+        "buf, sizes = D.allgather_J_blocks(J, 3)\n"
+        "assert sizes == [(0, 3)] and torch.equal(D.assemble_J_blocks(buf, sizes), J)\n"
+        "dist.destroy_process_group()\n"
+        "print('ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
