@@ -27,6 +27,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--a", type=int, default=59)
 ap.add_argument("--c", type=int, default=143)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--velocity", default="noise", choices=["noise", "smooth"],
+                help="noise: independent normal 8 km/s per SITE (the field of every earlier round: neighbouring sites of a wave fall into "
+                     "different regions of the Voigt function's four-region form); smooth: 8 km/s of large-scale flow (a few Fourier modes of "
+                     "the box) + 0.5 km/s of noise, as a simulated atmosphere's velocity field is")
 args = ap.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -48,6 +52,13 @@ T = (5e3 + 1.5e4 * (z - bounds[0]) / (bounds[1] - bounds[0])) * (1 + 0.05 * rng.
 doppler = lambda0 / C0 * np.sqrt(2 * K_B * T / 1.6735575e-27)
 gamma = 4.702e8 + 10 ** rng.uniform(6, 10, n)
 velocity = rng.normal(0, 8e3, (n, 3))
+if args.velocity == "smooth":
+    xyz = (pos - np.array([bounds[0], bounds[2], bounds[4]])) / np.array([bounds[1] - bounds[0], bounds[3] - bounds[2], bounds[5] - bounds[4]])
+    velocity = rng.normal(0, 0.5e3, (n, 3))
+    for comp in range(3):
+        for _ in range(4):
+            kvec = rng.integers(1, 4, 3)
+            velocity[:, comp] += 4e3 * np.sin(2 * np.pi * (xyz @ kvec) + rng.uniform(0, 2 * np.pi))
 strat = np.exp(-(z - bounds[0]) / 0.7e6)
 strength = 3e-2 * strat * doppler.mean() * (1 + 0.1 * rng.random(n))     # Δτ between neighbours spans the branches
 alpha_cont = 1e-4 * strat
