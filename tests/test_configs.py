@@ -179,6 +179,18 @@ def test_C4_1M_per_angle_alpha_51_wavelengths(grid_1m):
                      dJ=Jn.data_ptr(), dI0_up=I0.data_ptr(), stream=st)
     torch.cuda.synchronize()
     assert torch.equal(J, Jn)
+    # ... and with S and J in the sweep's own order (vrt_plan_execute_native_dev: what the device-resident Λ-iteration and
+    # bench.py's headline step run): J_up + J_down is the same J bit for bit at full size
+    cnt = plan.native_plane_count(nlam)
+    S_up, S_dn, J_up, J_dn = (torch.empty(cnt, dtype=torch.float64, device=dev) for _ in range(4))
+    plan.to_native_dev(nlam, nlam, S.data_ptr(), S_up.data_ptr(), S_dn.data_ptr(), stream=st)
+    plan.execute_native_dev(nlam, S_up.data_ptr(), S_dn.data_ptr(), native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE, w,
+                            dJ_up=J_up.data_ptr(), dJ_down=J_dn.data_ptr(), dI0_up=I0.data_ptr(), stream=st)
+    plan.J_from_native_dev(nlam, nlam, J_up.data_ptr(), J_dn.data_ptr(), Jn.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    plan.check()
+    assert plan.last_path == "patches" and torch.equal(J, Jn)
+    del S_up, S_dn, J_up, J_dn
     # the native layout is what the header says: pair q = l/2 of the block [q0, q0 + w) it falls in, at storage
     # position pos of angle a, is pair element q0 n + pos w + (q - q0) (26 pairs in blocks of B = 8: 8, 8, 8, 2)
     B = plan.native_pair_block
