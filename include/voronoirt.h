@@ -147,7 +147,8 @@ int vrt_plan_execute_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dS
                          double *dI_out, void *stream);
 /* ---- native layout of per-angle alpha (VRT_ALPHA_ANGLE_NATIVE) ------------------------------
  * storage order of a direction: out[pos] = 1-based site id at storage position pos (layers
- * contiguous like perm_up / perm_down, sites of a layer along a Morton curve over (x, y)). */
+ * contiguous like perm_up / perm_down; inside a layer strips of lattice columns, rows of y inside a strip, a row by x --
+ * neighbouring positions are neighbouring sites of a row; VRT_STORE_ORDER=morton at grid creation: a Morton curve over (x, y)). */
 int vrt_grid_get_storage_order(const vrt_grid *g, int dir, int64_t *out);
 /* number of doubles of the native per-angle alpha buffer for nlam wavelengths */
 int64_t vrt_plan_native_alpha_count(const vrt_plan *p, int64_t nlam);
@@ -275,7 +276,7 @@ void vrt_schedule_destroy(vrt_schedule *s);
 int vrt_layer_schedule(const vrt_grid *g, int dir, const int64_t *up, int n_sweeps, uint32_t *vis,
                        int32_t *nlev, int64_t *n_visits);
 /* Thread assignment of the layer-step level kernel for such a `vis` (introspection, host only):
- * store[n] = 1-based site id at each storage position (layers contiguous, Morton order inside);
+ * store[n] = 1-based site id at each storage position (layers contiguous, the storage order inside);
  * self[n] = 0-based storage position held by each sorted index: inside every layer the
  * positions are sorted (stably) by visit pattern -- first, then second, ... visit level. */
 int vrt_layer_sorted_slots(const vrt_grid *g, int dir, const uint32_t *vis, int64_t *store, int64_t *self);

@@ -8,9 +8,11 @@
 // 109-119) also for asymmetric neighbour lists, and detects unreachable cells (where the
 // reference loops forever) instead of hanging.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "vrt_internal.h"
 
@@ -125,7 +127,17 @@ static int layer_direction(const vrt_grid *g, int64_t wall, const std::vector<in
     d.reduced[(size_t)L] = n;
     d.n1 = d.reduced[1] - 1;
 
-    // storage order for the layer-tile kernel: (layer, Morton(x, y)), perm[n] kept last
+    // Storage order of the layer paths: layers contiguous, perm[n] kept last; inside a layer
+    //   strips (default): the (x, y) plane cut into strips of `W` lattice columns along x; inside a strip rows -- bands of y
+    //     half a site spacing high -- from low to high y, the sites of a row by x.  A patch (consecutive positions) is a piece of
+    //     a strip, W columns wide and as many rows high as its dependency cone allows: compact, and NEIGHBOURING LANES of
+    //     its workgroup hold neighbouring sites of a row.  On a lattice-like grid their upwind neighbours are neighbouring sites
+    //     of a row too, so a wave's gather is a handful of contiguous runs for the address unit and the L1 instead of 64 separate
+    //     16-byte requests -- the per-lane request, not the byte or the line, is what the patch kernel's gathers cost (DESIGN.md
+    //     section 5).  The spacing is taken from the layer's own site count (a = sqrt(2 area / sites): two sites per a x a cell as
+    //     on the body-centred lattice of the benchmark grids; on an irregular tessellation it only sets the band height).
+    //   morton (VRT_STORE_ORDER=morton): a Morton curve over (x, y) -- rounds 1 to 4.
+    // VRT_STORE_ORDER = strips[:W] | morton, read when a grid is created (results do not depend on it).
     {
         auto spread = [](uint32_t v) {            // 16 bits -> every other bit of 32
             v &= 0xFFFFu;
@@ -135,8 +147,23 @@ static int layer_direction(const vrt_grid *g, int64_t wall, const std::vector<in
             v = (v | (v << 1)) & 0x55555555u;
             return v;
         };
+        int strip_w = 20;                          // columns per strip: C4 7.55 -> 7.01 ms at 20 (16: 7.05, 24: 7.07, 12: 7.18, 30: 7.25)
+        if (const char *e = std::getenv("VRT_STORE_ORDER")) {
+            const std::string v(e);
+            if (v == "morton") strip_w = 0;
+            else if (v.rfind("strips", 0) == 0) {
+                const size_t c = v.find(':');
+                if (c != std::string::npos) strip_w = std::max(1, std::min(4096, std::atoi(v.c_str() + c + 1)));
+            }
+        }
         const double x0 = g->bounds[2], xs = g->bounds[3] - g->bounds[2];
         const double y0 = g->bounds[4], ys = g->bounds[5] - g->bounds[4];
+        std::vector<double> cell((size_t)L + 2, 1.0);           // lattice constant a of every layer (physical units)
+        if (strip_w > 0 && xs > 0 && ys > 0)
+            for (int64_t l = 1; l <= L; l++) {
+                const double m = (double)(start[(size_t)l + 1] - start[(size_t)l]);
+                cell[(size_t)l] = std::sqrt(2.0 * xs * ys / std::max(m, 1.0));
+            }
         std::vector<uint64_t> key((size_t)n);
         const int64_t last_site = d.perm[(size_t)n - 1] - 1;
         for (int64_t i = 0; i < n; i++) {
@@ -144,9 +171,19 @@ static int layer_direction(const vrt_grid *g, int64_t wall, const std::vector<in
             double fy = ys > 0 ? (g->pos[3 * (size_t)i + 2] - y0) / ys : 0.0;
             fx = fx < 0 ? 0 : (fx > 1 ? 1 : fx);
             fy = fy < 0 ? 0 : (fy > 1 ? 1 : fy);
-            const uint32_t m = spread((uint32_t)(fx * 65535.0)) | (spread((uint32_t)(fy * 65535.0)) << 1);
-            key[(size_t)i] = ((uint64_t)(uint32_t)d.layer_of[(size_t)i] << 32) | m;
-            if (i == last_site) key[(size_t)i] = ((uint64_t)(uint32_t)d.layer_of[(size_t)i] << 32) | 0xFFFFFFFFull;
+            const uint64_t layer = (uint64_t)(uint32_t)d.layer_of[(size_t)i];
+            if (strip_w > 0 && xs > 0 && ys > 0) {
+                // layer 22 bits | strip 14 | row 14 | x 14; (+ 0.25: a jittered lattice row stays inside its band)
+                const double a = cell[(size_t)d.layer_of[(size_t)i]];
+                const uint64_t row = std::min<uint64_t>(0x3FFFu, (uint64_t)(fy * ys / (0.5 * a) + 0.25));
+                const uint64_t strip = std::min<uint64_t>(0x3FFFu, (uint64_t)(fx * xs / a) / (uint64_t)strip_w);
+                key[(size_t)i] = (layer << 42) | (strip << 28) | (row << 14) | (uint64_t)(fx * 16383.0);
+                if (i == last_site) key[(size_t)i] = (layer << 42) | 0x3FFFFFFFFFFull;
+            } else {
+                const uint32_t m = spread((uint32_t)(fx * 65535.0)) | (spread((uint32_t)(fy * 65535.0)) << 1);
+                key[(size_t)i] = (layer << 32) | m;
+                if (i == last_site) key[(size_t)i] = (layer << 32) | 0xFFFFFFFFull;
+            }
         }
         d.store.resize((size_t)n);
         for (int64_t i = 0; i < n; i++) d.store[(size_t)i] = (int32_t)i;

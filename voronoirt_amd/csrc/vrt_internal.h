@@ -85,7 +85,7 @@ struct Direction {
     int32_t *d_rank = nullptr;       // inverse: site -> sweep position
     int32_t *d_lay = nullptr;        // 0-based layer boundaries: layer l = [lay[l-1], lay[l]), L+1 entries
     // STORAGE order of the layer-tile path: layers contiguous exactly like the sweep order, but
-    // inside a layer the sites are sorted along a Morton curve over (x, y) so that spatial
+    // inside a layer the sites are sorted in strips of rows (vrt_grid.cpp; VRT_STORE_ORDER=morton: along a Morton curve over (x, y)) so that spatial
     // neighbours (and therefore upwind gathers) share cache lines; the never-visited last site
     // perm[n] stays at position n-1.  The Gauss-Seidel ORDER is unaffected (it lives in the schedule).
     std::vector<int32_t> store;      // storage position -> site (0-based)

@@ -194,7 +194,7 @@ k_boundary_sweep_order(int64_t n, int nlam, int lb, int64_t n1, const int32_t *_
     T *Ia = I + (size_t)a * (size_t)nl_pad * (size_t)n;
     for (int c = ty; c < 64; c += 4) {
         const int l = l0 + c;
-        // I_0 is ordered like perm[1:n1] (irregular_ray_tracing.jl:33); storage is Morton order
+        // I_0 is ordered like perm[1:n1] (irregular_ray_tracing.jl:33); storage has its own order inside a layer
         if (l < nlam && p0 + tx < n1) {
             const int32_t pos = srank[order[p0 + tx]];
             Ia[sw_index(l, pos, n, lb, npair)] = tile[tx][c];

@@ -1,5 +1,5 @@
 // Patch schedule of the fused layer kernel (vrt_patch.hip): a BFS layer is cut into PATCHES of
-// consecutive storage positions (Morton order: compact in x, y) and every patch is solved by its
+// consecutive storage positions (a piece of a strip of the storage order, vrt_grid.cpp: compact in x, y) and every patch is solved by its
 // own workgroup, with no communication between workgroups.
 //
 // The reference's serial sweep (src/irregular_ray_tracing.jl:37-80, :118-161) couples the sites of a

@@ -1,4 +1,4 @@
-// Plan-time tables of the layer paths in STORAGE order (layers contiguous, Morton order inside): the upwind
+// Plan-time tables of the layer paths in STORAGE order (layers contiguous, strips of rows inside: vrt_grid.cpp): the upwind
 // table of an angle permuted from site order, the sorted thread assignment of the layer-step level kernels and
 // the compact list of in-layer couplings.  One-time work per (plan, angle), launched by vrt_plan_create.
 #include <hip/hip_runtime.h>
