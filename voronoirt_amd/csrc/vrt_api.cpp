@@ -256,7 +256,7 @@ static void free_plan(vrt_plan *p)
     for (int i = 0; i < 2; i++) dev_free(p->ws_cg[i]);
     dev_free(p->d_step_angles);
     dev_free(p->d_level_map);
-    dev_free(p->d_patch_rec); dev_free(p->d_patch_rec2); dev_free(p->d_patch_work);
+    dev_free(p->d_patch_work);
     dev_free(p->d_chain_items); dev_free(p->d_chain_deps); dev_free(p->d_chain_progress); dev_free(p->d_chain_ctrl);
     for (auto &cs : p->chain_cache) { dev_free(cs.items); dev_free(cs.deps); }
     p->chain_cache.clear();
@@ -600,8 +600,6 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
                 VRT_TRY_FREE(dev_alloc(&p->e_w2, ne));
                 VRT_TRY_FREE(dev_alloc(&p->e_r1, ne));
                 VRT_TRY_FREE(dev_alloc(&p->e_r2, ne));
-                VRT_TRY_FREE(dev_alloc(&p->d_patch_rec, (size_t)n_patches));
-                VRT_TRY_FREE(dev_alloc(&p->d_patch_rec2, (size_t)n_patches));
                 p->h_patch_first.assign((size_t)A * (size_t)(maxL + 2), 0);
                 p->h_patch_rec.reserve((size_t)n_patches);
                 p->n_patches = n_patches;
@@ -670,10 +668,6 @@ static int plan_create_impl(vrt_grid *g, int64_t n_angles, const double *k, cons
             if (patch_ok) {
                 p->h_patch_dep_off.push_back((int64_t)p->h_patch_deps.size());
                 p->h_patch_rec2 = rec2;
-            }
-            if (patch_ok && n_patches) {
-                VRT_HIP_TRY_FREE(hipMemcpy(p->d_patch_rec, p->h_patch_rec.data(), sizeof(int4) * (size_t)n_patches, hipMemcpyHostToDevice));
-                VRT_HIP_TRY_FREE(hipMemcpy(p->d_patch_rec2, rec2.data(), sizeof(int2) * (size_t)n_patches, hipMemcpyHostToDevice));
             }
         }
     }

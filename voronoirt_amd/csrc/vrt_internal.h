@@ -269,8 +269,6 @@ struct vrt_plan {
     int64_t n_patches = 0, n_patch_entries = 0, n_patch_visits = 0;
     std::vector<int32_t> h_patch_first;  // [A][tile_max_layers + 2]: index of the first patch of (angle, layer)
     std::vector<int4> h_patch_rec;       // per patch: first entry, entries, first owned position, owned sites
-    int4 *d_patch_rec = nullptr;
-    int2 *d_patch_rec2 = nullptr;        // per patch: levels, active angle
     int32_t *e_pos = nullptr, *e_u1 = nullptr, *e_u2 = nullptr;
     uint32_t *e_vis = nullptr, *e_loc = nullptr;
     double *e_w1 = nullptr, *e_w2 = nullptr, *e_r1 = nullptr, *e_r2 = nullptr;
@@ -302,7 +300,7 @@ struct vrt_plan {
     };
     std::vector<ChainSet> chain_cache;
     uint32_t chain_epoch = 0;
-    int32_t *d_patch_work = nullptr;     // work lists of the launches (ensure_patch_work)
+    int4 *d_patch_work = nullptr;        // work lists of the launches: two int4 per slot (ensure_patch_work, PatchArgs::wrec)
     std::vector<int64_t> patch_work_off; //   [group][layer] offsets into it
     int patch_work_groups = 0;
     hipStream_t step_stream[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -53,9 +53,10 @@ struct PatchArgs {
     // but form J_dir = Σ_a w_a I_a (reference's angle order inside the direction) over storage positions
     // [red_lo, red_hi) of up to two directions -- layers the stream's previous launch has made final
     PatchReduce red;
-    const int32_t *work;      // this launch's work list: patch index per (slot, XCD), -1 = padding
-    const int4 *rec;          // per patch: first entry, entries, first owned storage position, owned sites
-    const int2 *rec2;         // per patch: in-layer levels, active angle
+    // this launch's work list, two int4 per (slot, XCD) -- everything a workgroup needs to know about its item in ONE
+    // round trip: {first entry, entries (0: a padding slot), first owned storage position, owned sites},
+    // {in-layer levels, active angle | direction << 16, the layer's first storage position, the next layer's}
+    const int4 *wrec;
     const int32_t *e_pos, *e_u1, *e_u2;     // per entry: storage position of the site and of its two upwinds
     const uint32_t *e_vis, *e_loc;           //   packed visit levels; patch-local tile slots of the upwinds
     const double *e_w1, *e_w2, *e_r1, *e_r2; //   weights and path lengths (irregular_ray_tracing.jl:51,66)
@@ -257,13 +258,26 @@ __host__ __device__ __forceinline__ void split_blocks(const PatchArgs &pa, int s
 }
 
 // ---- reduction role of a patch launch: J_dir of a finished layer (NT x ppb pair elements per block) --------------
+// which blocks of the launch take it: the first nred (VRT_REDUCE_LAST=0) or the last nred -- behind the patches, whose
+// slowest workgroup ends the launch, the short reduction blocks fill the slots the fast patches leave
+#ifndef VRT_REDUCE_LAST
+#define VRT_REDUCE_LAST 1
+#endif
+__device__ __forceinline__ int reduce_block_index(const PatchArgs &pa)      // >= 0: this block reduces
+{
+    return VRT_REDUCE_LAST ? (int)blockIdx.x - ((int)gridDim.x - pa.red.nred) : ((int)blockIdx.x < pa.red.nred ? (int)blockIdx.x : -1);
+}
+__device__ __forceinline__ int patch_block_index(const PatchArgs &pa)
+{
+    return VRT_REDUCE_LAST ? (int)blockIdx.x : (int)blockIdx.x - pa.red.nred;
+}
 template <typename T, int NT>
 __device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
 {
     typedef typename Pair<T>::type T2;
     const TileArgs &ta = pa.ta;
     const int tid = threadIdx.x;
-    int b = blockIdx.x, r = 0;
+    int b = reduce_block_index(pa), r = 0;
     if (b >= pa.red.nblk[0]) { b -= pa.red.nblk[0]; r = 1; }
     if (b >= pa.red.nblk[r]) return;                         // padding to a multiple of 8
     if (diag(pa.dbg, kDiagNoReduce)) return;
@@ -319,15 +333,15 @@ k_patch_solve(PatchArgs pa)
     // block -> (work item, pair group): blocks b, b + 8, ... share an XCD (MI355X_MICROARCH.md, speed
     // only); the pair groups of an item follow each other on ONE XCD and read its entry tables
     // through that L2, and consecutive items of an XCD are neighbouring patches / angles of a patch
-    if ((int)blockIdx.x < pa.red.nred) {
+    if (reduce_block_index(pa) >= 0) {
         patch_reduce_role<T, NT>(pa);
         return;
     }
-    const int bid = (int)blockIdx.x - pa.red.nred;
+    const int bid = patch_block_index(pa);
     const int x = bid & 7, rr = bid >> 3;
     const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
-    const int item = pa.work[sj * 8 + x];
-    if (item < 0) return;
+    const int4 rec = pa.wrec[2 * (sj * 8 + x)], rec2 = pa.wrec[2 * (sj * 8 + x) + 1];
+    if (rec.y <= 0) return;
     // sibling sib solves pair k0 + sib of every block [k0, k0 + 2^lw) with 2^lw > sib among blocks b0 .. b1-1: the
     // 2^lgB siblings of an item run side by side on one XCD and use a gathered line (one site's pairs) whole
     const int sib = grp & ((1 << pa.lgB) - 1);
@@ -340,13 +354,11 @@ k_patch_solve(PatchArgs pa)
         pair_block_of(b0, pa.npair, pa.lgB, k0, lw);
         if (sib >= (1 << lw)) return;                           // block widths only shrink: nothing for this sibling
     }
-    const int4 rec = pa.rec[item];
-    const int2 rec2 = pa.rec2[item];
     const int ent_off = rec.x, n_ent = rec.y, own_lo = rec.z, own_cnt = rec.w;
     const int dbg = kDiag ? pa.dbg : 0;
-    const int nlev = diag(dbg, kDiagNoLevels) ? 0 : rec2.x, a = rec2.y;
-    const int d = ta.angle_dir[a];
-    const int lo = ta.lay[d][pa.layer - 1], hi = ta.lay[d][pa.layer];
+    const int nlev = diag(dbg, kDiagNoLevels) ? 0 : rec2.x, a = rec2.y & 0xFFFF;
+    const int d = rec2.y >> 16;
+    const int lo = rec2.z, hi = rec2.w;
     const int64_t n = ta.n;
     const int stride = pa.stride;
 
@@ -507,21 +519,19 @@ struct PatchItem {
 // false: a padding slot, or nothing of the item for this workgroup
 __device__ __forceinline__ bool patch_item(const PatchArgs &pa, int lgS, PatchItem &it)
 {
-    const int bid = (int)blockIdx.x - pa.red.nred;
+    const int bid = patch_block_index(pa);
     const int x = bid & 7, rr = bid >> 3;
     const int grp = rr % pa.ngrp, sj = rr / pa.ngrp;
-    const int item = pa.work[sj * 8 + x];
-    if (item < 0) return false;
+    const int4 rec = pa.wrec[2 * (sj * 8 + x)], rec2 = pa.wrec[2 * (sj * 8 + x) + 1];
+    if (rec.y <= 0) return false;
     it.sib = grp & ((1 << lgS) - 1);
     split_blocks(pa, grp >> lgS, pair_block_count(pa.npair, pa.lgB), it.b0, it.b1);
     if (it.b0 >= it.b1) return false;
-    const int4 rec = pa.rec[item];
-    const int2 rec2 = pa.rec2[item];
     it.ent_off = rec.x; it.n_ent = rec.y; it.own_lo = rec.z; it.own_cnt = rec.w;
-    it.nlev = rec2.x; it.a = rec2.y;
-    it.d = pa.ta.angle_dir[it.a];
-    it.lo = pa.ta.lay[it.d][pa.layer - 1];
-    it.hi = pa.ta.lay[it.d][pa.layer];
+    it.nlev = rec2.x; it.a = rec2.y & 0xFFFF;
+    it.d = rec2.y >> 16;
+    it.lo = rec2.z;
+    it.hi = rec2.w;
     return true;
 }
 // the patch's entry table in LDS behind `planes` tile planes of CAP + 1 slots: every thread parks the entry it owns
@@ -994,7 +1004,7 @@ k_patch_lean(PatchArgs pa)
 {
     extern __shared__ __attribute__((aligned(16))) double2 ptile[];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < pa.red.nred) {
+    if (reduce_block_index(pa) >= 0) {
         patch_reduce_role<T, NT>(pa);
         return;
     }
@@ -1151,7 +1161,7 @@ k_patch_quad(PatchArgs pa)
 {
     extern __shared__ __attribute__((aligned(16))) double2 ptile[];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < pa.red.nred) {
+    if (reduce_block_index(pa) >= 0) {
         patch_reduce_role<float, NT>(pa);
         return;
     }
@@ -1501,12 +1511,12 @@ int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angl
     if (p->d_patch_work && p->patch_work_groups == G) return VRT_OK;
     if (p->d_patch_work) { (void)hipFree(p->d_patch_work); p->d_patch_work = nullptr; }
     const int maxL = p->tile_max_layers;
-    std::vector<int32_t> work;
+    std::vector<int4> work;           // two per slot (PatchArgs::wrec)
     p->patch_work_off.assign((size_t)G * (size_t)(maxL + 2) + 1, 0);
     std::vector<std::pair<int64_t, int32_t>> items;
     for (int gi = 0; gi < G; gi++)
         for (int layer = 0; layer <= maxL + 1; layer++) {
-            p->patch_work_off[(size_t)gi * (size_t)(maxL + 2) + (size_t)layer] = (int64_t)work.size();
+            p->patch_work_off[(size_t)gi * (size_t)(maxL + 2) + (size_t)layer] = (int64_t)(work.size() / 2);
             if (layer < 2 || layer > maxL) continue;
             items.clear();
             for (int j = group_off[(size_t)gi]; j < group_off[(size_t)gi + 1]; j++) {
@@ -1520,15 +1530,23 @@ int ensure_patch_work(vrt_plan *p, int G, const std::vector<int32_t> &group_angl
             if (m == 0) continue;
             const size_t slots = (m + 7) / 8;
             const size_t base = work.size();
-            work.resize(base + slots * 8, -1);
+            work.resize(base + slots * 8 * 2, make_int4(0, 0, 0, 0));      // (entries = 0: padding)
             for (int x = 0; x < 8; x++) {
                 const size_t b0 = m * (size_t)x / 8, b1 = m * (size_t)(x + 1) / 8;
-                for (size_t t = b0; t < b1; t++) work[base + (t - b0) * 8 + (size_t)x] = items[t].second;
+                for (size_t t = b0; t < b1; t++) {
+                    const int32_t q = items[t].second;
+                    const int2 r2 = p->h_patch_rec2[(size_t)q];
+                    const int d = p->dir_of_active[(size_t)r2.y] > 0 ? 0 : 1;
+                    const Direction &dir = d == 0 ? p->g->up : p->g->down;
+                    const size_t slot = base + 2 * ((t - b0) * 8 + (size_t)x);
+                    work[slot] = p->h_patch_rec[(size_t)q];
+                    work[slot + 1] = make_int4(r2.x, r2.y | (d << 16), (int)(dir.reduced[(size_t)layer - 1] - 1), (int)(dir.reduced[(size_t)layer] - 1));
+                }
             }
         }
-    p->patch_work_off.back() = (int64_t)work.size();
-    VRT_HIP_TRY(hipMalloc((void **)&p->d_patch_work, sizeof(int32_t) * std::max<size_t>(work.size(), 1)));
-    VRT_HIP_TRY(hipMemcpy(p->d_patch_work, work.data(), sizeof(int32_t) * work.size(), hipMemcpyHostToDevice));
+    p->patch_work_off.back() = (int64_t)(work.size() / 2);
+    VRT_HIP_TRY(hipMalloc((void **)&p->d_patch_work, sizeof(int4) * std::max<size_t>(work.size(), 1)));
+    VRT_HIP_TRY(hipMemcpy(p->d_patch_work, work.data(), sizeof(int4) * work.size(), hipMemcpyHostToDevice));
     p->patch_work_groups = G;
     return VRT_OK;
 }
@@ -1599,9 +1617,7 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
     pa.stride = p->patch_cap + 1;
     pa.cap = p->patch_cap;
     pa.dbg = kDiag ? p->tune.debug_flags : 0;
-    pa.work = p->d_patch_work + w0;
-    pa.rec = p->d_patch_rec;
-    pa.rec2 = p->d_patch_rec2;
+    pa.wrec = p->d_patch_work + 2 * w0;
     pa.e_pos = p->e_pos; pa.e_u1 = p->e_u1; pa.e_u2 = p->e_u2;
     pa.e_vis = p->e_vis; pa.e_loc = p->e_loc;
     pa.e_w1 = p->e_w1; pa.e_w2 = p->e_w2; pa.e_r1 = p->e_r1; pa.e_r2 = p->e_r2;
