@@ -250,9 +250,18 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
 
     # S and J in the sweep's own layout (vrt_plan_execute_native_dev): the device-resident Λ-iteration produces S and
     # consumes J in this form (vrt_lambda_iterate), so its sweep step has no layout change; converted once, untimed
-    sj_native = (args.sj_layout == "native" or (args.sj_layout == "auto" and per_angle)) and alpha_native is not None \
+    # (alpha per (site, wavelength) -- the continuum's, fixed over the iterations -- then goes along in sweep order too:
+    # VRT_ALPHA_SITE_LAM_NATIVE, both directions' plane sets one behind the other, converted once, untimed)
+    shared_native = not per_angle and alpha_mode == _lib.ALPHA_SITE_LAM and args.alpha_layout == "native"
+    sj_native = (args.sj_layout == "native" or (args.sj_layout == "auto" and per_angle)) and (alpha_native is not None or shared_native) \
         and not f32 and groups is None and not dist_on
     S_nat = J_nat = None
+    native_alpha_mode = _lib.ALPHA_ANGLE_NATIVE
+    if sj_native and alpha_native is None:
+        cnt = plan.native_plane_count(nlam)
+        alpha_native = torch.empty(2 * cnt, device=dev, dtype=torch.float64)
+        plan.to_native_dev(nlam, nlam, alpha.data_ptr(), alpha_native.data_ptr(), alpha_native.data_ptr() + 8 * cnt, stream=stream)
+        native_alpha_mode = _lib.ALPHA_SITE_LAM_NATIVE
     if sj_native:
         cnt = plan.native_plane_count(nlam)
         S_nat = [torch.empty(cnt, device=dev, dtype=torch.float64) for _ in range(2)]
@@ -283,9 +292,9 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
             return
         if sj_native:
             plan.execute_native_dev(nlam, S_nat[0].data_ptr(), S_nat[1].data_ptr(), alpha_native.data_ptr(),
-                                    _lib.ALPHA_ANGLE_NATIVE, w_mine, dJ_up=J_nat[0].data_ptr(), dJ_down=J_nat[1].data_ptr(),
+                                    native_alpha_mode, w_mine, dJ_up=J_nat[0].data_ptr(), dJ_down=J_nat[1].data_ptr(),
                                     dI0_up=I0_up.data_ptr(), stream=stream)
-        elif alpha_native is not None:
+        elif alpha_native is not None and native_alpha_mode == _lib.ALPHA_ANGLE_NATIVE:
             plan.execute_dev(nlam, nlam, S.data_ptr(), alpha_native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE,
                              w_mine, dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
         else:
@@ -384,7 +393,8 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
                         f"alpha per {'angle,site,lambda' if per_angle else 'site,lambda'}"
                         f"{' (native storage-pair layout)' if alpha_native is not None else ''}, n_sweeps=3",
             "sites": n, "angles": n_angles, "nlam_per_rank": nlam, "shard": shard,
-            "alpha_layout": "native" if alpha_native is not None else "caller",
+            "alpha_layout": ("native" if native_alpha_mode == _lib.ALPHA_ANGLE_NATIVE else "sweep order, both directions (VRT_ALPHA_SITE_LAM_NATIVE)")
+                            if alpha_native is not None else "caller",
             "sj_layout": "sweep order per direction (vrt_plan_execute_native_dev: what vrt_lambda_iterate keeps between its steps)"
                          if sj_native else "caller (n, nlam)",
         },

@@ -56,6 +56,12 @@ typedef struct vrt_plan vrt_plan;   /* per-(grid, angle set) upwind tables + swe
  * or vrt_line_opacity_dev -- callers need not know the layout; it saves the 2 x 8 B per (site,
  * angle, wavelength) of the layout change on every execute. */
 #define VRT_ALPHA_ANGLE_NATIVE 3
+/* alpha per (site, wavelength), the same for every angle (VRT_ALPHA_SITE_LAM: the continuum of
+ * src/lambda_continuum.jl:27-56, where it does not change from one Λ-iteration to the next), handed over in SWEEP ORDER:
+ * two plane sets of vrt_plan_native_plane_count(p, nlam) doubles one behind the other -- the up directions' order, then
+ * the down directions' -- as vrt_plan_to_native_dev(p, nlam, ld, alpha, buf, buf + count, ...) writes them, once.
+ * Accepted by vrt_plan_execute_native_dev only: no layout change of any kind is then left inside a step. */
+#define VRT_ALPHA_SITE_LAM_NATIVE 4
 
 const char *vrt_last_error(void);
 int vrt_version(void);
@@ -185,7 +191,7 @@ int vrt_plan_from_native_dev(vrt_plan *p, int dir, int64_t nlam, int64_t ld, con
 int vrt_plan_j_from_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const double *dJ_up, const double *dJ_down,
                                double *dJ, void *stream);
 /* vrt_plan_execute_dev with S read from and J reduced into sweep-order plane sets, in place.  alpha_mode:
- * VRT_ALPHA_SITE or VRT_ALPHA_ANGLE_NATIVE.  dJ_up / dJ_down: both or neither; the plane set of a direction without
+ * VRT_ALPHA_SITE, VRT_ALPHA_ANGLE_NATIVE or VRT_ALPHA_SITE_LAM_NATIVE.  dJ_up / dJ_down: both or neither; the plane set of a direction without
  * angles comes back zeroed.  The results are those of vrt_plan_execute_dev bit for bit (J = J_up + J_down). */
 int vrt_plan_execute_native_dev(vrt_plan *p, int64_t nlam, const double *dS_up, const double *dS_down,
                                 const double *dalpha, int alpha_mode, const double *dI0_up, const double *dI0_down,

@@ -1174,7 +1174,7 @@ def test_sweep_order_S_and_J_are_the_caller_layout_results_bit_for_bit(grids, mo
     """vrt_plan_execute_native_dev: S read from and J reduced into the sweep's own per-direction plane sets -- what a
     device-resident Λ-iteration keeps between its steps (lambda_iteration.jl:261-263 produces S, rates.jl:154-201 consume J).
     J_up + J_down equals the J of vrt_plan_execute_dev bit for bit (chained launch, per-layer launches, the steps
-    path; odd and even wavelength counts; per-site and native per-angle alpha), the layout helpers round-trip, an
+    path; odd and even wavelength counts; per-site, sweep-order per-(site, wavelength) and native per-angle alpha), the layout helpers round-trip, an
     up-only plan hands back a zero J_down, and the J itself is checked against the oracle."""
     import torch
     monkeypatch.delenv("VRT_PATH", raising=False)
@@ -1208,10 +1208,19 @@ def test_sweep_order_S_and_J_are_the_caller_layout_results_bit_for_bit(grids, mo
         back = torch.zeros((n, nlam), dtype=torch.float64, device=dev)
         plan.from_native_dev(d, nlam, nlam, buf.data_ptr(), back.data_ptr(), stream=st)
         assert torch.equal(back, dS)
-    for mode in ("site", "native"):
+    for mode in ("site", "site_lam", "native"):
+        dal_caller = None
         if mode == "site":
             dal, am = dA1, _lib.ALPHA_SITE
             al_ref = np.repeat(al1[:, None], nlam, axis=1)
+        elif mode == "site_lam":
+            # alpha per (site, wavelength) -- the continuum's, lambda_continuum.jl:27-56 -- laid out ONCE in sweep order
+            # (both directions' plane sets one behind the other) against the caller-layout array of vrt_plan_execute_dev
+            al_ref = al1[:, None] * (1 + 0.02 * np.arange(nlam)[None, :])
+            dal_caller = t(al_ref)
+            dal = torch.full((2 * np_,), 5.0, dtype=torch.float64, device=dev)
+            plan.to_native_dev(nlam, nlam, dal_caller.data_ptr(), dal.data_ptr(), dal.data_ptr() + 8 * np_, stream=st)
+            am = _lib.ALPHA_SITE_LAM_NATIVE
         else:
             al3 = np.stack([np.repeat(al1[:, None], nlam, axis=1) * (1 + 0.03 * i + 0.01 * np.arange(nlam)[None, :]) for i in range(nq)])
             d3 = t(al3)
@@ -1220,7 +1229,12 @@ def test_sweep_order_S_and_J_are_the_caller_layout_results_bit_for_bit(grids, mo
             am = _lib.ALPHA_ANGLE_NATIVE
             al_ref = al3
         J = torch.zeros((n, nlam), dtype=torch.float64, device=dev)
-        plan.execute_dev(nlam, nlam, dS.data_ptr(), dal.data_ptr(), am, w, dJ=J.data_ptr(), dI0_up=dI0.data_ptr(), stream=st)
+        if dal_caller is not None:
+            plan.execute_dev(nlam, nlam, dS.data_ptr(), dal_caller.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=J.data_ptr(), dI0_up=dI0.data_ptr(), stream=st)
+            with pytest.raises(vrt.VrtError):       # the sweep-order alpha goes with sweep-order S and J only
+                plan.execute_dev(nlam, nlam, dS.data_ptr(), dal.data_ptr(), am, w, dJ=J.data_ptr(), dI0_up=dI0.data_ptr(), stream=st)
+        else:
+            plan.execute_dev(nlam, nlam, dS.data_ptr(), dal.data_ptr(), am, w, dJ=J.data_ptr(), dI0_up=dI0.data_ptr(), stream=st)
         path_a = plan.last_path
         J_up, J_dn = (torch.full((np_,), -3.0, dtype=torch.float64, device=dev) for _ in range(2))
         plan.execute_native_dev(nlam, S_up.data_ptr(), S_dn.data_ptr(), dal.data_ptr(), am, w, dJ_up=J_up.data_ptr(),
@@ -1231,7 +1245,7 @@ def test_sweep_order_S_and_J_are_the_caller_layout_results_bit_for_bit(grids, mo
         torch.cuda.synchronize()
         plan.check()
         assert torch.equal(J, Jn)
-        if mode == "site" or nlam <= 7:
+        if mode != "native" or nlam <= 7:
             ref = orc.J_voronoi(w, th, ph, S, al_ref, so, I0_up=I0, nthreads=8)
             assert _rel(Jn.cpu().numpy(), ref) < RTOL
     # the caller-layout alphas carry the caller's leading dimension: refused with sweep-order S

@@ -22,7 +22,7 @@ p_int = ctypes.POINTER(ctypes.c_int)
 vp = ctypes.c_void_p
 
 VRT_OK, VRT_EINVAL, VRT_EGRID, VRT_ENODEVICE, VRT_ENOMEM, VRT_EIO = 0, -1, -2, -3, -4, -5
-ALPHA_SITE, ALPHA_SITE_LAM, ALPHA_ANGLE_SITE_LAM, ALPHA_ANGLE_NATIVE = 0, 1, 2, 3
+ALPHA_SITE, ALPHA_SITE_LAM, ALPHA_ANGLE_SITE_LAM, ALPHA_ANGLE_NATIVE, ALPHA_SITE_LAM_NATIVE = 0, 1, 2, 3, 4
 
 class LineCaseStruct(ctypes.Structure):
     """vrt_line_case of include/voronoirt.h"""

@@ -744,7 +744,9 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_, c
     vrt_grid *g = p->g;
     if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
     if (!dS || !dalpha) return fail(VRT_EINVAL, "S and alpha must not be NULL");
-    if (alpha_mode < 0 || alpha_mode > VRT_ALPHA_ANGLE_NATIVE) return fail(VRT_EINVAL, "bad alpha_mode");
+    if (alpha_mode < 0 || alpha_mode > VRT_ALPHA_SITE_LAM_NATIVE) return fail(VRT_EINVAL, "bad alpha_mode");
+    if (alpha_mode == VRT_ALPHA_SITE_LAM_NATIVE && (!p->nat_mode || f32))
+        return fail(VRT_EINVAL, "alpha per (site, wavelength) in sweep order goes with sweep-order S and J (vrt_plan_execute_native_dev)");
     if (dJ && !weights) return fail(VRT_EINVAL, "weights must be given when J is requested");
     int rc = use_device(g->device);
     if (rc) return rc;
@@ -864,8 +866,8 @@ int execute_native_locked(vrt_plan *p, int64_t nlam, const double *dS_up, const 
     if (rc) return rc;
     if ((p->n_up > 0 && !dS_up) || (p->n_down > 0 && !dS_down)) return fail(VRT_EINVAL, "S of a direction with angles must not be NULL");
     if (!dJ_up != !dJ_down) return fail(VRT_EINVAL, "J_up and J_down must be given together (or both NULL)");
-    if (alpha_mode != VRT_ALPHA_SITE && alpha_mode != VRT_ALPHA_ANGLE_NATIVE)
-        return fail(VRT_EINVAL, "sweep-order S goes with alpha per site (0) or native per angle (3): the other layouts carry the caller's leading dimension");
+    if (alpha_mode != VRT_ALPHA_SITE && alpha_mode != VRT_ALPHA_ANGLE_NATIVE && alpha_mode != VRT_ALPHA_SITE_LAM_NATIVE)
+        return fail(VRT_EINVAL, "sweep-order S goes with alpha per site (0), native per angle (3) or per (site, wavelength) in sweep order (4): the other layouts carry the caller's leading dimension");
     // (the level path -- grids whose schedule does not fit the layer kernels -- keeps the caller's layout)
     const int keep = p->tune.path;
     if (keep == 1 || keep == 2) p->tune.path = 0;

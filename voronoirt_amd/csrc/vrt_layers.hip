@@ -413,6 +413,9 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             hipLaunchKernelGGL(k_to_sweep_order<T>, dim3(tgrid.x, tgrid.y, inB ? 2 : 1), dim3(256), 0, st, n, (int)nlam, ld, lb,
                                dir.d_store, inS, outS, inB, outB);
         ta.S[d] = nat ? reinterpret_cast<const double *>(p->nat_S[d]) : p->ws_S[d];
+        // alpha per (site, wavelength) already in sweep order: the direction's plane set, read in place
+        if (alpha_mode == VRT_ALPHA_SITE_LAM_NATIVE)
+            ta.alpha[d] = reinterpret_cast<const double *>(dalpha) + (size_t)d * dcount(plane);
         if (alpha_mode == VRT_ALPHA_SITE) {
             if ((rc = ensure_dev(p->ws_A[d], p->ws_A_cap[d], dcount((size_t)n)))) return rc;
             hipLaunchKernelGGL(k_gather_vec<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n,
@@ -443,6 +446,7 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
             hipLaunchKernelGGL(k_chain_prepare, dim3(blocks), dim3(256), 0, st, cp);
         }
     }
+    if (alpha_mode == VRT_ALPHA_SITE_LAM_NATIVE) ta.alpha_mode = VRT_ALPHA_SITE_LAM;
     if (alpha_mode == VRT_ALPHA_ANGLE_NATIVE) {
         // already in storage-pair order per active angle (vrt_plan_alpha_to_native_dev or the
         // opacity prologue wrote it): no transposed copy, the kernels read the caller's buffer
