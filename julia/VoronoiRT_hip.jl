@@ -52,6 +52,8 @@ check(rc::Cint) = rc == 0 ? nothing : error("libvrt_hip error $rc: $(vrt_error()
 const VRT_ALPHA_SITE = Cint(0)            # α[n]
 const VRT_ALPHA_SITE_LAM = Cint(1)        # α[nλ, n]
 const VRT_ALPHA_ANGLE_SITE_LAM = Cint(2)  # α[nλ, n, n_angles]
+const VRT_ALPHA_ANGLE_NATIVE = Cint(3)    # per angle in the library's own layout (vrt_line_opacity_dev writes it)
+const VRT_ALPHA_SITE_LAM_NATIVE = Cint(4) # α[nλ, n] in sweep order, both directions (vrt_plan_to_native_dev), with vrt_plan_execute_native_dev
 
 # ---- one device-resident grid handle per VoronoiSites object -----------------------------------
 const GRIDS = IdDict{Any,Ptr{Cvoid}}()
