@@ -299,6 +299,37 @@ __device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
     T2 *Jd = reinterpret_cast<T2 *>(pa.red.Jd[r]);
     const T2 *I0 = reinterpret_cast<const T2 *>(ta.I);
     const size_t plane = (size_t)pa.npair * (size_t)nn;
+    if (pa.red.ppb == 4) {
+        // four elements of a thread side by side: their loads of an angle's plane are in flight together (one element
+        // after the other the block is four dependent round trips long -- and the launch ends with its last block);
+        // per element the same sum in the same order
+        size_t e[4];
+        bool ok[4];
+        double ax[4], ay[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const size_t f = ((size_t)b * 4 + i) * NT + tid;
+            ok[i] = f < run;
+            e[i] = base + (ok[i] ? f : 0);
+            ax[i] = 0.0; ay[i] = 0.0;
+        }
+        for (int j = 0; j < pa.red.count[r]; j++) {          // the reference's angle order (lambda_iteration.jl:84,102,107)
+            const int a = pa.red.angles[r][j];
+            const T2 *Ia = I0 + (size_t)a * plane;
+            double2 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = to_d2(Ia[e[i]]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ax[i] += pa.red.w[a] * v[i].x;
+                ay[i] += pa.red.w[a] * v[i].y;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (ok[i]) Jd[e[i]] = from_d2<T>(make_double2(ax[i], ay[i]));
+        return;
+    }
     for (int i = 0; i < pa.red.ppb; i++) {
         const size_t f = ((size_t)b * pa.red.ppb + i) * NT + tid;
         if (f >= run) break;
@@ -1010,6 +1041,7 @@ k_patch_lean(PatchArgs pa)
     }
     PatchItem it;
     if (!patch_item(pa, pa.lgB, it)) return;
+    if (diag(pa.dbg, kDiagNoPairLoop)) it.b1 = it.b0;           // diagnostics: the item's overhead alone
     const EntryTable<NT> tab(ptile, 1);
     tab.park(pa, it, tid);
     if (tid == 0) ptile[it.n_ent] = make_double2(0.0, 0.0);  // the zero slot
