@@ -86,8 +86,9 @@ def parse_args(argv=None):
                     help="S and J of the timed step: 'native' = the sweep's own per-direction plane sets, what the "
                          "device-resident Λ-iteration (vrt_lambda_iterate) keeps between its steps -- no layout change "
                          "in the step; 'caller' = (n, nlam) arrays in, J (n, nlam) out (two layout changes per step); "
-                         "auto: native for the per-angle-alpha (line) workloads on one GPU, the caller-layout time is "
-                         "reported beside it")
+                         "auto: native on one GPU wherever the library offers it (per-angle alpha in its native layout; "
+                         "alpha per (site, wavelength) -- the continuum's, fixed over the iterations -- laid out once in sweep "
+                         "order), the caller-layout time is reported beside it")
     ap.add_argument("--no-caller-layout", action="store_true",
                     help="with --sj-layout native: do not time the caller-layout step beside it (profiling runs: the process "
                          "then executes the headline step only)")
@@ -253,20 +254,22 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     # (alpha per (site, wavelength) -- the continuum's, fixed over the iterations -- then goes along in sweep order too:
     # VRT_ALPHA_SITE_LAM_NATIVE, both directions' plane sets one behind the other, converted once, untimed)
     shared_native = not per_angle and alpha_mode == _lib.ALPHA_SITE_LAM and args.alpha_layout == "native"
-    sj_native = (args.sj_layout == "native" or (args.sj_layout == "auto" and per_angle)) and (alpha_native is not None or shared_native) \
-        and not f32 and groups is None and not dist_on
+    sj_native = args.sj_layout in ("native", "auto") and (alpha_native is not None or shared_native) \
+        and groups is None and not dist_on
     S_nat = J_nat = None
     native_alpha_mode = _lib.ALPHA_ANGLE_NATIVE
+    vdt = torch.float32 if f32 else torch.float64
     if sj_native and alpha_native is None:
         cnt = plan.native_plane_count(nlam)
-        alpha_native = torch.empty(2 * cnt, device=dev, dtype=torch.float64)
-        plan.to_native_dev(nlam, nlam, alpha.data_ptr(), alpha_native.data_ptr(), alpha_native.data_ptr() + 8 * cnt, stream=stream)
+        alpha_native = torch.empty(2 * cnt, device=dev, dtype=vdt)
+        plan.to_native_dev(nlam, nlam, alpha.data_ptr(), alpha_native.data_ptr(), alpha_native.data_ptr() + alpha_native.element_size() * cnt,
+                           stream=stream, f32=f32)
         native_alpha_mode = _lib.ALPHA_SITE_LAM_NATIVE
     if sj_native:
         cnt = plan.native_plane_count(nlam)
-        S_nat = [torch.empty(cnt, device=dev, dtype=torch.float64) for _ in range(2)]
-        J_nat = [torch.zeros(cnt, device=dev, dtype=torch.float64) for _ in range(2)]
-        plan.to_native_dev(nlam, nlam, S.data_ptr(), S_nat[0].data_ptr(), S_nat[1].data_ptr(), stream=stream)
+        S_nat = [torch.empty(cnt, device=dev, dtype=vdt) for _ in range(2)]
+        J_nat = [torch.zeros(cnt, device=dev, dtype=vdt) for _ in range(2)]
+        plan.to_native_dev(nlam, nlam, S.data_ptr(), S_nat[0].data_ptr(), S_nat[1].data_ptr(), stream=stream, f32=f32)
         torch.cuda.synchronize()
 
     gathered = {}     # lambda-strong: the gathered (n, nlam_total) J of the last step
@@ -293,7 +296,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         if sj_native:
             plan.execute_native_dev(nlam, S_nat[0].data_ptr(), S_nat[1].data_ptr(), alpha_native.data_ptr(),
                                     native_alpha_mode, w_mine, dJ_up=J_nat[0].data_ptr(), dJ_down=J_nat[1].data_ptr(),
-                                    dI0_up=I0_up.data_ptr(), stream=stream)
+                                    dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
         elif alpha_native is not None and native_alpha_mode == _lib.ALPHA_ANGLE_NATIVE:
             plan.execute_dev(nlam, nlam, S.data_ptr(), alpha_native.data_ptr(), _lib.ALPHA_ANGLE_NATIVE,
                              w_mine, dJ=J.data_ptr(), dI0_up=I0_up.data_ptr(), stream=stream, f32=f32)
@@ -336,7 +339,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
     caller_layout = None
     if sj_native:
         # J in the caller's layout for the checks below; and the same step over the caller's layout, timed beside it
-        plan.J_from_native_dev(nlam, nlam, J_nat[0].data_ptr(), J_nat[1].data_ptr(), J.data_ptr(), stream=stream)
+        plan.J_from_native_dev(nlam, nlam, J_nat[0].data_ptr(), J_nat[1].data_ptr(), J.data_ptr(), stream=stream, f32=f32)
         torch.cuda.synchronize()
     if sj_native and not args.no_caller_layout:
         J_keep = J.clone()
@@ -395,7 +398,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
             "sites": n, "angles": n_angles, "nlam_per_rank": nlam, "shard": shard,
             "alpha_layout": ("native" if native_alpha_mode == _lib.ALPHA_ANGLE_NATIVE else "sweep order, both directions (VRT_ALPHA_SITE_LAM_NATIVE)")
                             if alpha_native is not None else "caller",
-            "sj_layout": "sweep order per direction (vrt_plan_execute_native_dev: what vrt_lambda_iterate keeps between its steps)"
+            "sj_layout": "sweep order per direction (vrt_plan_execute_native_dev%s: what vrt_lambda_iterate keeps between its steps)" % ("_f32" if f32 else "")
                          if sj_native else "caller (n, nlam)",
         },
         "setup_s": {"grid_generate": t_gen, "grid_create": t_grid, "plan_create": t_plan},
@@ -420,7 +423,7 @@ def measure(args, workload, torch, dist, vrt, _lib, distributed, synth, rank, wo
         floor_ms = plan.last_sweep_timing()[0]
         step()                     # restore J of the full problem (parity check below)
         if sj_native:              # (the native step leaves J in its plane sets)
-            plan.J_from_native_dev(nlam, nlam, J_nat[0].data_ptr(), J_nat[1].data_ptr(), J.data_ptr(), stream=stream)
+            plan.J_from_native_dev(nlam, nlam, J_nat[0].data_ptr(), J_nat[1].data_ptr(), J.data_ptr(), stream=stream, f32=f32)
         torch.cuda.synchronize()
     # practical ceiling of this box beside the vendor peak: a device triad b = a + b
     # over 2 x 1 GB (2 reads + 1 write per element), measured live

@@ -196,6 +196,19 @@ int vrt_plan_j_from_native_dev(vrt_plan *p, int64_t nlam, int64_t ld, const doub
 int vrt_plan_execute_native_dev(vrt_plan *p, int64_t nlam, const double *dS_up, const double *dS_down,
                                 const double *dalpha, int alpha_mode, const double *dI0_up, const double *dI0_down,
                                 const double *weights_host, double *dJ_up, double *dJ_down, void *stream);
+/* The same four with FLOAT storage (vrt_plan_execute_dev_f32's values; arithmetic in double): the plane sets hold
+ * vrt_plan_native_plane_count(p, nlam) floats per direction, wavelength pairs in blocks of
+ * vrt_plan_native_pair_block_f32(p) as in the float native alpha; the patch path only.  J_up + J_down (vrt_plan_j_from_native_dev_f32)
+ * equals the J of vrt_plan_execute_dev_f32 bit for bit. */
+int vrt_plan_to_native_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *d_in, float *d_up, float *d_down,
+                               void *stream);
+int vrt_plan_from_native_dev_f32(vrt_plan *p, int dir, int64_t nlam, int64_t ld, const float *d_native, float *d_out,
+                                 void *stream);
+int vrt_plan_j_from_native_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dJ_up, const float *dJ_down,
+                                   float *dJ, void *stream);
+int vrt_plan_execute_native_dev_f32(vrt_plan *p, int64_t nlam, const float *dS_up, const float *dS_down,
+                                    const float *dalpha, int alpha_mode, const float *dI0_up, const float *dI0_down,
+                                    const double *weights_host, float *dJ_up, float *dJ_down, void *stream);
 
 /* The two steps either side of the sweep in a device-resident Λ-iteration, on the same sweep-order plane sets (what
  * vrt_lambda_iterate runs internally): vrt_lambda_update_dev -- S_new = (1 - ε) J + ε B and the criterion's maximum

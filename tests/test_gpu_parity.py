@@ -1169,6 +1169,73 @@ def test_closing_the_grid_closes_its_plans(bcc_small):
 
 
 @pytest.mark.parametrize("grid", ["bcc", "voronoi"])
+@pytest.mark.parametrize("nlam, chain", [(6, 1), (12, 0), (13, 0), (20, 0)])
+def test_sweep_order_float_S_and_J_are_the_caller_layout_results_bit_for_bit(grids, monkeypatch, grid, nlam, chain):
+    """The float forms (vrt_plan_execute_native_dev_f32 and its three layout helpers): S read from and J reduced into
+    float plane sets in the plan's float pair blocks.  J_up + J_down equals vrt_plan_execute_dev_f32's J bit for bit --
+    per-site, sweep-order per-(site, wavelength) and native per-angle alpha, the four-wavelength kernel (even pair counts)
+    and the pair kernel (13 wavelengths: 7 pairs), chained and per-layer launches -- and stays within 5e-6 of the fp64
+    oracle; the helpers round-trip."""
+    import torch
+    monkeypatch.delenv("VRT_PATH", raising=False)
+    hs, so = grids[grid]
+    n = so.n
+    rng = np.random.default_rng(100 + nlam)
+    r32 = lambda a: np.asarray(a, dtype=np.float32)
+    S = r32(1.0 + rng.random((n, nlam)))
+    al1 = r32(10.0 ** rng.uniform(-3, 1, n))
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    n1 = int(so.layers_up[1] - 1)
+    I0 = S[so.perm_up[:n1] - 1].copy()
+    plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+    plan.set_option("VRT_PATCH_CHAIN", chain)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    dS, dA1, dI0 = t(S), t(al1), t(I0)
+    np_ = plan.native_plane_count(nlam)
+    S_up, S_dn = (torch.full((np_,), 7.0, dtype=torch.float32, device=dev) for _ in range(2))
+    plan.to_native_dev(nlam, nlam, dS.data_ptr(), S_up.data_ptr(), S_dn.data_ptr(), stream=st, f32=True)
+    for d, buf in ((1, S_up), (-1, S_dn)):
+        back = torch.zeros((n, nlam), dtype=torch.float32, device=dev)
+        plan.from_native_dev(d, nlam, nlam, buf.data_ptr(), back.data_ptr(), stream=st, f32=True)
+        assert torch.equal(back, dS)
+    for mode in ("site", "site_lam", "native"):
+        if mode == "site":
+            dal, am, dal_c, am_c = dA1, _lib.ALPHA_SITE, dA1, _lib.ALPHA_SITE
+            al_ref = np.repeat(al1[:, None], nlam, axis=1)
+        elif mode == "site_lam":
+            al_ref = r32(al1[:, None] * (1 + 0.02 * np.arange(nlam)[None, :]))
+            dal_c, am_c = t(al_ref), _lib.ALPHA_SITE_LAM
+            dal = torch.full((2 * np_,), 5.0, dtype=torch.float32, device=dev)
+            plan.to_native_dev(nlam, nlam, dal_c.data_ptr(), dal.data_ptr(), dal.data_ptr() + 4 * np_, stream=st, f32=True)
+            am = _lib.ALPHA_SITE_LAM_NATIVE
+        else:
+            al_ref = r32(np.stack([np.repeat(al1[:, None], nlam, axis=1) * (1 + 0.03 * i + 0.01 * np.arange(nlam)[None, :]) for i in range(nq)]))
+            d3 = t(al_ref)
+            dal = torch.empty(plan.native_alpha_count(nlam), dtype=torch.float32, device=dev)
+            plan.alpha_to_native_dev(nlam, nlam, d3.data_ptr(), dal.data_ptr(), stream=st, f32=True)
+            am = _lib.ALPHA_ANGLE_NATIVE
+            dal_c, am_c = dal, am
+        J = torch.zeros((n, nlam), dtype=torch.float32, device=dev)
+        plan.execute_dev(nlam, nlam, dS.data_ptr(), dal_c.data_ptr(), am_c, w, dJ=J.data_ptr(), dI0_up=dI0.data_ptr(), stream=st, f32=True)
+        launches = plan.last_launches
+        J_up, J_dn = (torch.full((np_,), -3.0, dtype=torch.float32, device=dev) for _ in range(2))
+        plan.execute_native_dev(nlam, S_up.data_ptr(), S_dn.data_ptr(), dal.data_ptr(), am, w, dJ_up=J_up.data_ptr(),
+                                dJ_down=J_dn.data_ptr(), dI0_up=dI0.data_ptr(), stream=st, f32=True)
+        assert plan.last_path == "patches" and plan.last_launches == launches
+        Jn = torch.zeros((n, nlam), dtype=torch.float32, device=dev)
+        plan.J_from_native_dev(nlam, nlam, J_up.data_ptr(), J_dn.data_ptr(), Jn.data_ptr(), stream=st, f32=True)
+        torch.cuda.synchronize()
+        plan.check()
+        assert torch.equal(J, Jn), mode
+        if mode != "native" or nlam <= 6:
+            ref = orc.J_voronoi(w, th, ph, S.astype(np.float64), al_ref.astype(np.float64), so, I0_up=I0.astype(np.float64), nthreads=8)
+            assert _rel(Jn.cpu().numpy().astype(np.float64), ref) < 5e-6
+    plan.close()
+
+
+@pytest.mark.parametrize("grid", ["bcc", "voronoi"])
 @pytest.mark.parametrize("nlam, pathopt", [(3, "auto"), (7, "auto"), (22, "auto"), (5, "steps"), (22, "patches-launches")])
 def test_sweep_order_S_and_J_are_the_caller_layout_results_bit_for_bit(grids, monkeypatch, grid, nlam, pathopt):
     """vrt_plan_execute_native_dev: S read from and J reduced into the sweep's own per-direction plane sets -- what a

@@ -71,6 +71,10 @@ PROTOTYPES = {
     "vrt_plan_from_native_dev": (ctypes.c_int, [vp, ctypes.c_int, c_i64, c_i64, vp, vp, vp]),
     "vrt_plan_j_from_native_dev": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp, vp]),
     "vrt_plan_execute_native_dev": (ctypes.c_int, [vp, c_i64, vp, vp, vp, ctypes.c_int, vp, vp, p_dbl, vp, vp, vp]),
+    "vrt_plan_to_native_dev_f32": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp, vp]),
+    "vrt_plan_from_native_dev_f32": (ctypes.c_int, [vp, ctypes.c_int, c_i64, c_i64, vp, vp, vp]),
+    "vrt_plan_j_from_native_dev_f32": (ctypes.c_int, [vp, c_i64, c_i64, vp, vp, vp, vp]),
+    "vrt_plan_execute_native_dev_f32": (ctypes.c_int, [vp, c_i64, vp, vp, vp, ctypes.c_int, vp, vp, p_dbl, vp, vp, vp]),
     "vrt_plan_check": (ctypes.c_int, [vp]),
     "vrt_lambda_update_native_dev": (ctypes.c_int, [vp, c_i64, vp, vp, vp, vp, vp, vp, p_dbl, vp]),
     "vrt_rates_populations_native_dev": (ctypes.c_int, [vp, c_i64, p_dbl, p_i64, vp, vp, p_dbl, c_dbl, c_dbl, vp, vp,

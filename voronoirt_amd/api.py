@@ -294,28 +294,32 @@ class FormalPlan:
 
     # ---- S and J in sweep order (include/voronoirt.h: vrt_plan_execute_native_dev) ----
     def native_plane_count(self, nlam: int) -> int:
-        """float64 values of ONE direction's sweep-order plane set of S or J."""
+        """values (float64, or float32 with the f32 entry points) of ONE direction's sweep-order plane set of S or J."""
         return int(_lib.load().vrt_plan_native_plane_count(self._h, nlam))
 
-    def to_native_dev(self, nlam: int, ld: int, d_in: int, d_up: int = 0, d_down: int = 0, stream: int = 0) -> None:
+    def to_native_dev(self, nlam: int, ld: int, d_in: int, d_up: int = 0, d_down: int = 0, stream: int = 0, f32: bool = False) -> None:
         """Device (n, ld) array -> the sweep-order plane sets of both directions (either may be 0)."""
-        check(_lib.load().vrt_plan_to_native_dev(self._h, nlam, ld, d_in, d_up or None, d_down or None, stream or None))
+        fn = _lib.load().vrt_plan_to_native_dev_f32 if f32 else _lib.load().vrt_plan_to_native_dev
+        check(fn(self._h, nlam, ld, d_in, d_up or None, d_down or None, stream or None))
 
-    def from_native_dev(self, d: int, nlam: int, ld: int, d_native: int, d_out: int, stream: int = 0) -> None:
+    def from_native_dev(self, d: int, nlam: int, ld: int, d_native: int, d_out: int, stream: int = 0, f32: bool = False) -> None:
         """The sweep-order plane set of direction d (> 0: up) -> a device (n, ld) array."""
-        check(_lib.load().vrt_plan_from_native_dev(self._h, int(d), nlam, ld, d_native, d_out, stream or None))
+        fn = _lib.load().vrt_plan_from_native_dev_f32 if f32 else _lib.load().vrt_plan_from_native_dev
+        check(fn(self._h, int(d), nlam, ld, d_native, d_out, stream or None))
 
-    def J_from_native_dev(self, nlam: int, ld: int, dJ_up: int, dJ_down: int, dJ: int, stream: int = 0) -> None:
+    def J_from_native_dev(self, nlam: int, ld: int, dJ_up: int, dJ_down: int, dJ: int, stream: int = 0, f32: bool = False) -> None:
         """J = J_up + J_down in the caller's (n, ld) layout."""
-        check(_lib.load().vrt_plan_j_from_native_dev(self._h, nlam, ld, dJ_up or None, dJ_down or None, dJ, stream or None))
+        fn = _lib.load().vrt_plan_j_from_native_dev_f32 if f32 else _lib.load().vrt_plan_j_from_native_dev
+        check(fn(self._h, nlam, ld, dJ_up or None, dJ_down or None, dJ, stream or None))
 
     def execute_native_dev(self, nlam: int, dS_up: int, dS_down: int, dalpha: int, alpha_mode: int, weights,
-                           dJ_up: int = 0, dJ_down: int = 0, dI0_up: int = 0, dI0_down: int = 0, stream: int = 0) -> None:
+                           dJ_up: int = 0, dJ_down: int = 0, dI0_up: int = 0, dI0_down: int = 0, stream: int = 0,
+                           f32: bool = False) -> None:
         """`execute_dev` with S read from and J reduced into sweep-order plane sets, in place (no layout change)."""
         w = _f64(weights)
-        check(_lib.load().vrt_plan_execute_native_dev(self._h, nlam, dS_up or None, dS_down or None, dalpha, alpha_mode,
-                                                      dI0_up or None, dI0_down or None, _d(w), dJ_up or None,
-                                                      dJ_down or None, stream or None))
+        fn = _lib.load().vrt_plan_execute_native_dev_f32 if f32 else _lib.load().vrt_plan_execute_native_dev
+        check(fn(self._h, nlam, dS_up or None, dS_down or None, dalpha, alpha_mode, dI0_up or None, dI0_down or None, _d(w),
+                 dJ_up or None, dJ_down or None, stream or None))
 
     def check(self) -> None:
         """Raises if a chained launch of an earlier ASYNCHRONOUS execute gave up (call after synchronising)."""

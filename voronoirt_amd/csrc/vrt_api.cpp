@@ -745,7 +745,7 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_, c
     if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
     if (!dS || !dalpha) return fail(VRT_EINVAL, "S and alpha must not be NULL");
     if (alpha_mode < 0 || alpha_mode > VRT_ALPHA_SITE_LAM_NATIVE) return fail(VRT_EINVAL, "bad alpha_mode");
-    if (alpha_mode == VRT_ALPHA_SITE_LAM_NATIVE && (!p->nat_mode || f32))
+    if (alpha_mode == VRT_ALPHA_SITE_LAM_NATIVE && !p->nat_mode)
         return fail(VRT_EINVAL, "alpha per (site, wavelength) in sweep order goes with sweep-order S and J (vrt_plan_execute_native_dev)");
     if (dJ && !weights) return fail(VRT_EINVAL, "weights must be given when J is requested");
     int rc = use_device(g->device);
@@ -858,11 +858,11 @@ int execute_dev_locked(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS_, c
     return VRT_OK;
 }
 
-int execute_native_locked(vrt_plan *p, int64_t nlam, const double *dS_up, const double *dS_down, const void *dalpha, int alpha_mode,
-                          const double *dI0_up, const double *dI0_down, const double *weights, double *dJ_up, double *dJ_down,
-                          hipStream_t st)
+int execute_native_locked(vrt_plan *p, int64_t nlam, const void *dS_up, const void *dS_down, const void *dalpha, int alpha_mode,
+                          const void *dI0_up, const void *dI0_down, const double *weights, void *dJ_up, void *dJ_down,
+                          hipStream_t st, bool f32)
 {
-    int rc = native_planes_ok(p);
+    int rc = native_planes_ok(p, f32);
     if (rc) return rc;
     if ((p->n_up > 0 && !dS_up) || (p->n_down > 0 && !dS_down)) return fail(VRT_EINVAL, "S of a direction with angles must not be NULL");
     if (!dJ_up != !dJ_down) return fail(VRT_EINVAL, "J_up and J_down must be given together (or both NULL)");
@@ -870,18 +870,36 @@ int execute_native_locked(vrt_plan *p, int64_t nlam, const double *dS_up, const 
         return fail(VRT_EINVAL, "sweep-order S goes with alpha per site (0), native per angle (3) or per (site, wavelength) in sweep order (4): the other layouts carry the caller's leading dimension");
     // (the level path -- grids whose schedule does not fit the layer kernels -- keeps the caller's layout)
     const int keep = p->tune.path;
-    if (keep == 1 || keep == 2) p->tune.path = 0;
+    if (keep == 1 || keep == 2 || (f32 && keep == 3)) p->tune.path = 0;
     p->nat_S[0] = dS_up; p->nat_S[1] = dS_down;
     p->nat_J[0] = dJ_up; p->nat_J[1] = dJ_down;
     p->nat_mode = true;
-    const double *anyS = dS_up ? dS_up : dS_down;
-    rc = execute_dev_locked(p, nlam, (nlam + 1) / 2 * 2, anyS, dalpha, alpha_mode, dI0_up, dI0_down, weights, dJ_up, nullptr, st);
+    const void *anyS = dS_up ? dS_up : dS_down;
+    rc = execute_dev_locked(p, nlam, (nlam + 1) / 2 * 2, anyS, dalpha, alpha_mode, dI0_up, dI0_down, weights, dJ_up, nullptr, st, f32);
     p->nat_mode = false;
     p->nat_S[0] = p->nat_S[1] = nullptr;
     p->nat_J[0] = p->nat_J[1] = nullptr;
     p->tune.path = keep;
     if (!rc && p->last_path != 3 && p->last_path != 4) return fail(VRT_EINVAL, "sweep-order S and J: the plan did not run on a layer path");
     return rc;
+}
+
+// the float forms of the sweep-order entry points share this: lock, device, layout check, then `fn`
+template <typename F>
+static int native_f32_call(vrt_plan *p, int64_t nlam, int64_t ld, bool args_ok, F fn)
+{
+    DeviceScope scope;
+    if (!p || !args_ok) return fail(VRT_EINVAL, "NULL argument");
+    if (nlam < 1 || ld < nlam) return fail(VRT_EINVAL, "need nlam >= 1 and ld >= nlam");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        int rc = use_device(p->g->device);
+        if (!rc) rc = native_planes_ok(p, true);
+        if (rc) return rc;
+        return fn();
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
 }
 
 }  // namespace vrt
@@ -1441,6 +1459,42 @@ int vrt_plan_execute_native_dev(vrt_plan *p, int64_t nlam, const double *dS_up, 
         std::lock_guard<std::mutex> lock(p->mu);
         return execute_native_locked(p, nlam, dS_up, dS_down, dalpha, alpha_mode, dI0_up, dI0_down, weights_host, dJ_up, dJ_down,
                                      (hipStream_t)stream);
+    } catch (const std::bad_alloc &) {
+        return fail(VRT_ENOMEM, "out of host memory");
+    } catch (...) {
+        return fail(VRT_EINVAL, "unexpected exception");
+    }
+}
+
+int vrt_plan_to_native_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *d_in, float *d_up, float *d_down, void *stream)
+{
+    return native_f32_call(p, nlam, ld, d_in && (d_up || d_down),
+                           [&] { return planes_to_native_f32(p, nlam, ld, d_in, d_up, d_down, (hipStream_t)stream); });
+}
+
+int vrt_plan_from_native_dev_f32(vrt_plan *p, int dir, int64_t nlam, int64_t ld, const float *d_native, float *d_out, void *stream)
+{
+    return native_f32_call(p, nlam, ld, d_native && d_out,
+                           [&] { return plane_from_native_f32(p, dir > 0 ? 0 : 1, nlam, ld, d_native, d_out, (hipStream_t)stream); });
+}
+
+int vrt_plan_j_from_native_dev_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dJ_up, const float *dJ_down, float *dJ,
+                                   void *stream)
+{
+    return native_f32_call(p, nlam, ld, dJ && (dJ_up || dJ_down),
+                           [&] { return J_from_native_f32(p, nlam, ld, dJ_up, dJ_down, dJ, (hipStream_t)stream); });
+}
+
+int vrt_plan_execute_native_dev_f32(vrt_plan *p, int64_t nlam, const float *dS_up, const float *dS_down, const float *dalpha,
+                                    int alpha_mode, const float *dI0_up, const float *dI0_down, const double *weights_host,
+                                    float *dJ_up, float *dJ_down, void *stream)
+{
+    DeviceScope scope;
+    if (!p) return fail(VRT_EINVAL, "NULL plan");
+    try {
+        std::lock_guard<std::mutex> lock(p->mu);
+        return execute_native_locked(p, nlam, dS_up, dS_down, dalpha, alpha_mode, dI0_up, dI0_down, weights_host, dJ_up, dJ_down,
+                                     (hipStream_t)stream, /*f32=*/true);
     } catch (const std::bad_alloc &) {
         return fail(VRT_ENOMEM, "out of host memory");
     } catch (...) {

@@ -458,14 +458,17 @@ inline int native_lg(const vrt_plan *p, bool f32)
 }
 int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const void *dalpha, void *out, hipStream_t st, bool f32);
 // sweep-order S and J (per direction [pairs][n][2] in that direction's storage order)
-int native_planes_ok(const vrt_plan *p);
+int native_planes_ok(const vrt_plan *p, bool f32 = false);
+int planes_to_native_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *din, float *out_up, float *out_down, hipStream_t st);
+int plane_from_native_f32(vrt_plan *p, int dir_index, int64_t nlam, int64_t ld, const float *din, float *dout, hipStream_t st);
+int J_from_native_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dJ_up, const float *dJ_down, float *dJ, hipStream_t st);
 int planes_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *din, double *out_up, double *out_down, hipStream_t st);
 int plane_from_native(vrt_plan *p, int dir_index, int64_t nlam, int64_t ld, const double *din, double *dout, hipStream_t st);
 int J_from_native(vrt_plan *p, int64_t nlam, int64_t ld, const double *dJ_up, const double *dJ_down, double *dJ, hipStream_t st);
 // the sweep with S read from / J reduced into the caller's sweep-order planes (caller holds p->mu)
-int execute_native_locked(vrt_plan *p, int64_t nlam, const double *dS_up, const double *dS_down, const void *dalpha, int alpha_mode,
-                          const double *dI0_up, const double *dI0_down, const double *weights, double *dJ_up, double *dJ_down,
-                          hipStream_t st);
+int execute_native_locked(vrt_plan *p, int64_t nlam, const void *dS_up, const void *dS_down, const void *dalpha, int alpha_mode,
+                          const void *dI0_up, const void *dI0_down, const double *weights, void *dJ_up, void *dJ_down,
+                          hipStream_t st, bool f32 = false);
 int execute_tiles(vrt_plan *p, int64_t nlam, int64_t ld, const void *dS, const void *dalpha,
                   int alpha_mode, const void *dI0_up, const void *dI0_down,
                   const double *weights_user, void *dJ, void *dI_out, hipStream_t st, bool f32);

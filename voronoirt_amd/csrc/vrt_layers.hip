@@ -119,10 +119,51 @@ int alpha_to_native(vrt_plan *p, int64_t nlam, int64_t ld, const void *dalpha, v
 
 // ---- sweep-order ("native") S and J: per sweep direction a plane set [pairs][n][2] in that direction's storage order ------
 // (the layout the layer paths read S from and reduce J into; what vrt_plan_execute_native_dev takes and returns in place)
-int native_planes_ok(const vrt_plan *p)
+int native_planes_ok(const vrt_plan *p, bool f32)
 {
+    if (f32) {          // float planes: the patch path only, in its pair blocks (vrt_plan_native_pair_block_f32)
+        if (!p->patch_ok) return fail(VRT_EINVAL, "sweep-order float S and J need the patch path (at most 4 visits per site, 255 levels per layer, 512 entries per cone)");
+        return VRT_OK;
+    }
     if (!(p->patch_ok || p->tile_ok)) return fail(VRT_EINVAL, "sweep-order S and J need a layer path (at most 4 visits per site and 255 levels per layer)");
     if (native_lg(p, false) != 0) return fail(VRT_EINVAL, "sweep-order S and J need one wavelength pair per block (VRT_PAIR_BLOCK=1)");
+    return VRT_OK;
+}
+
+// the float forms of the three layout helpers below (pair blocks of the plan's float layout)
+int planes_to_native_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *din, float *out_up, float *out_down, hipStream_t st)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const int lb = 2 << native_lg(p, true);
+    const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
+    for (int d = 0; d < 2; d++) {
+        float *out = d == 0 ? out_up : out_down;
+        if (!out) continue;
+        const Direction &dir = d == 0 ? g->up : g->down;
+        hipLaunchKernelGGL(k_to_sweep_order<float>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, lb, dir.d_store, din, out,
+                           (const float *)nullptr, (float *)nullptr);
+    }
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+int plane_from_native_f32(vrt_plan *p, int dir_index, int64_t nlam, int64_t ld, const float *din, float *dout, hipStream_t st)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
+    const Direction &dir = dir_index == 0 ? g->up : g->down;
+    hipLaunchKernelGGL(k_from_sweep_order<float>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2 << native_lg(p, true), dir.d_store, din, dout);
+    VRT_HIP_TRY(hipGetLastError());
+    return VRT_OK;
+}
+int J_from_native_f32(vrt_plan *p, int64_t nlam, int64_t ld, const float *dJ_up, const float *dJ_down, float *dJ, hipStream_t st)
+{
+    vrt_grid *g = p->g;
+    const int64_t n = g->n;
+    const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));
+    hipLaunchKernelGGL(k_combine_J<float>, tgrid, dim3(256), 0, st, n, (int)nlam, ld, 2 << native_lg(p, true), g->up.d_store, g->down.d_srank, dJ_up, dJ_down, dJ);
+    VRT_HIP_TRY(hipGetLastError());
     return VRT_OK;
 }
 
@@ -323,7 +364,8 @@ static int execute_tiles_t(vrt_plan *p, int64_t nlam, int64_t ld, const T *dS, c
     const bool use_dir[2] = {p->n_up > 0, p->n_down > 0};
     // sweep-order S and J handed over by the caller (vrt_plan_execute_native_dev): the layer paths read / write them in place
     const bool nat = p->nat_mode;
-    if (nat && (!steps || lb != 2)) return fail(VRT_EINVAL, "sweep-order S and J need a layer path with one wavelength pair per block");
+    if (nat && (!steps || (kF32 ? !patches : lb != 2)))
+        return fail(VRT_EINVAL, "sweep-order S and J need a layer path with one wavelength pair per block (float planes: the patch path)");
     for (int d = 0; d < 2; d++)
         if (use_dir[d] && !nat && (rc = ensure_dev(p->ws_S[d], p->ws_S_cap[d], dcount(plane)))) return rc;
     const dim3 tgrid((unsigned)((n + 63) / 64), (unsigned)((nlam + 63) / 64));

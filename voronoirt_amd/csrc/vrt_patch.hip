@@ -303,22 +303,19 @@ __device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
         // four elements of a thread side by side: their loads of an angle's plane are in flight together (one element
         // after the other the block is four dependent round trips long -- and the launch ends with its last block);
         // per element the same sum in the same order
-        size_t e[4];
-        bool ok[4];
+        // (elements of a block are NT apart: one 32-bit offset from a wave-uniform base; a plane set holds < 2^31 pairs)
+        const size_t f0 = (size_t)b * 4 * NT + tid;
+        const unsigned left = f0 < run ? (unsigned)min((size_t)(run - f0 + NT - 1) / NT, (size_t)4) : 0u;   // elements of this thread
+        const size_t e0 = base + (left ? f0 : 0);
         double ax[4], ay[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const size_t f = ((size_t)b * 4 + i) * NT + tid;
-            ok[i] = f < run;
-            e[i] = base + (ok[i] ? f : 0);
-            ax[i] = 0.0; ay[i] = 0.0;
-        }
+        for (int i = 0; i < 4; i++) { ax[i] = 0.0; ay[i] = 0.0; }
         for (int j = 0; j < pa.red.count[r]; j++) {          // the reference's angle order (lambda_iteration.jl:84,102,107)
             const int a = pa.red.angles[r][j];
-            const T2 *Ia = I0 + (size_t)a * plane;
+            const T2 *Ia = I0 + (size_t)a * plane + e0;
             double2 v[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = to_d2(Ia[e[i]]);
+            for (int i = 0; i < 4; i++) v[i] = to_d2(Ia[(unsigned)i < left ? i * NT : 0]);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 ax[i] += pa.red.w[a] * v[i].x;
@@ -327,7 +324,7 @@ __device__ __forceinline__ void patch_reduce_role(const PatchArgs &pa)
         }
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            if (ok[i]) Jd[e[i]] = from_d2<T>(make_double2(ax[i], ay[i]));
+            if ((unsigned)i < left) Jd[e0 + (size_t)i * NT] = from_d2<T>(make_double2(ax[i], ay[i]));
         return;
     }
     for (int i = 0; i < pa.red.ppb; i++) {
