@@ -271,6 +271,20 @@ def test_C5_4M_sites_fp32_storage_100_wavelengths():
     assert J1.min().item() >= 0.0 and J1.max().item() <= float(Sd.max().item()) * (1 + 1e-5)
     J3, _ = solve(Sd * 2.0, I0d * 2.0)
     assert ((J3 - 2.0 * J1).abs().max() / J3.abs().max()).item() < 1e-5
+    del J2, J3
+    # ... and the same step with S, alpha and J in sweep order (vrt_plan_execute_native_dev_f32: no layout change inside): bit for bit
+    cnt = plan.native_plane_count(nlam)
+    S_nat = [torch.empty(cnt, dtype=torch.float32, device=dev) for _ in range(2)]
+    J_nat = [torch.full((cnt,), -1.0, dtype=torch.float32, device=dev) for _ in range(2)]
+    A_nat = torch.empty(2 * cnt, dtype=torch.float32, device=dev)
+    plan.to_native_dev(nlam, nlam, Sd.data_ptr(), S_nat[0].data_ptr(), S_nat[1].data_ptr(), stream=st, f32=True)
+    plan.to_native_dev(nlam, nlam, Ad.data_ptr(), A_nat.data_ptr(), A_nat.data_ptr() + 4 * cnt, stream=st, f32=True)
+    plan.execute_native_dev(nlam, S_nat[0].data_ptr(), S_nat[1].data_ptr(), A_nat.data_ptr(), _lib.ALPHA_SITE_LAM_NATIVE, w,
+                            dJ_up=J_nat[0].data_ptr(), dJ_down=J_nat[1].data_ptr(), dI0_up=I0d.data_ptr(), stream=st, f32=True)
+    Jn = torch.empty((n, nlam), dtype=torch.float32, device=dev)
+    plan.J_from_native_dev(nlam, nlam, J_nat[0].data_ptr(), J_nat[1].data_ptr(), Jn.data_ptr(), stream=st, f32=True)
+    torch.cuda.synchronize()
+    assert torch.equal(Jn, J1)
     plan.close()
     hs.close()
 
