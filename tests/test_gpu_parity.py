@@ -1169,6 +1169,49 @@ def test_closing_the_grid_closes_its_plans(bcc_small):
 
 
 @pytest.mark.parametrize("grid", ["bcc", "voronoi"])
+def test_results_do_not_depend_on_the_storage_order(grid, bcc_small, voro_small, monkeypatch):
+    """VRT_STORE_ORDER (strips of rows, default; other strip widths; the Morton curve of rounds 1-4) decides where a site's
+    values LIVE in the planes, not the order of the Gauss-Seidel visits (that is the schedule's): J and the per-angle
+    intensities are bit for bit the same, on the chained launch and on the per-layer launches."""
+    import torch
+    pos, nbr, bounds = bcc_small if grid == "bcc" else voro_small
+    so = orc.make_sites(pos, nbr, bounds)
+    n, nlam = so.n, 6
+    rng = np.random.default_rng(77)
+    S = 1.0 + rng.random((n, nlam))
+    al = 10.0 ** rng.uniform(-3, 1, (n, nlam))
+    w, th, ph, nq = vrt.read_quadrature("ul7n12.dat")
+    n1 = int(so.layers_up[1] - 1)
+    I0 = S[so.perm_up[:n1] - 1].copy()
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    dS, dA, dI0 = t(S), t(al), t(I0)
+    got = {}
+    for order in ("strips", "strips:7", "morton"):
+        monkeypatch.setenv("VRT_STORE_ORDER", order)
+        hs = vrt.VoronoiSites(pos, nbr, bounds, device=0)
+        for chain in (1, 0):
+            plan = vrt.FormalPlan(hs, vrt.quadrature_directions(th, ph), 3)
+            plan.set_option("VRT_PATH", "patches")
+            plan.set_option("VRT_PATCH_CHAIN", chain)
+            J = torch.zeros((n, nlam), dtype=torch.float64, device=dev)
+            Io = torch.zeros((nq, n, nlam), dtype=torch.float64, device=dev)
+            plan.execute_dev(nlam, nlam, dS.data_ptr(), dA.data_ptr(), _lib.ALPHA_SITE_LAM, w, dJ=J.data_ptr(), dI0_up=dI0.data_ptr(),
+                             dI_out=Io.data_ptr(), stream=st)
+            torch.cuda.synchronize()
+            assert plan.last_path == "patches"
+            got[(order, chain)] = (J.cpu().numpy(), Io.cpu().numpy())
+            plan.close()
+        hs.close()
+    ref = got[("strips", 1)]
+    for key, val in got.items():
+        assert np.array_equal(val[0], ref[0]) and np.array_equal(val[1], ref[1]), key
+    oracle = orc.J_voronoi(w, th, ph, S, al, so, I0_up=I0, nthreads=8)
+    assert _rel(ref[0], oracle) < RTOL
+
+
+@pytest.mark.parametrize("grid", ["bcc", "voronoi"])
 @pytest.mark.parametrize("nlam, chain", [(6, 1), (12, 0), (13, 0), (20, 0)])
 def test_sweep_order_float_S_and_J_are_the_caller_layout_results_bit_for_bit(grids, monkeypatch, grid, nlam, chain):
     """The float forms (vrt_plan_execute_native_dev_f32 and its three layout helpers): S read from and J reduced into

@@ -826,14 +826,30 @@ def test_native_tessellation_errors():
     assert rc == _lib.VRT_EGRID
 
 
+@pytest.mark.parametrize("order", [None, "strips:3", "strips:4096", "morton"])
 @pytest.mark.parametrize("grid", ["bcc", "voronoi"])
-def test_storage_order_keeps_the_layers_contiguous(grid, bcc_small, voro_small):
+def test_storage_order_keeps_the_layers_contiguous(grid, order, bcc_small, voro_small, monkeypatch):
     """The storage order permutes sites only INSIDE a layer: layer l occupies the same positions as in the sweep order
     (so the boundary layer is storage positions [0, n1) -- what k_chain_prepare relies on when it writes I_0 there by
-    position, vrt_layout_kernels.h), and the never-visited last site of the order stays at position n - 1."""
+    position, vrt_layout_kernels.h), and the never-visited last site of the order stays at position n - 1.  For the
+    default order (strips of 20 lattice columns, rows inside, vrt_grid.cpp), other strip widths and the Morton curve of
+    rounds 1-4 (VRT_STORE_ORDER, read at grid creation); in the strip order a row's sites are stored by increasing x."""
     pos, nbr, bounds = bcc_small if grid == "bcc" else voro_small
     so = orc.make_sites(pos, nbr, bounds)
+    if order is None:
+        monkeypatch.delenv("VRT_STORE_ORDER", raising=False)
+    else:
+        monkeypatch.setenv("VRT_STORE_ORDER", order)
     hs = vrt.VoronoiSites(pos, nbr, bounds, device=-1)
+    if order == "strips:4096":           # one strip: inside a layer the sites come row by row, x increasing along a row
+        store = hs.storage_order(+1) - 1
+        lo, hi = int(so.layers_up[1]) - 1, int(so.layers_up[2]) - 1      # the second layer
+        x = pos[store[lo:hi], 1]
+        a = np.sqrt(2.0 * (bounds[3] - bounds[2]) * (bounds[5] - bounds[4]) / (hi - lo))
+        row = np.minimum(0x3FFF, ((pos[store[lo:hi], 2] - bounds[4]) / (0.5 * a) + 0.25).astype(np.int64))
+        assert np.all(np.diff(row) >= 0)
+        same = np.diff(row) == 0
+        assert np.all(np.diff(x)[same] >= -1e-9 * (bounds[3] - bounds[2]))
     for dirn, perm, lay in ((+1, so.perm_up, so.layers_up), (-1, so.perm_down, so.layers_down)):
         store = hs.storage_order(dirn)
         assert sorted(store) == list(range(1, so.n + 1))

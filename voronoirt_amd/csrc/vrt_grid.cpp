@@ -156,6 +156,7 @@ static int layer_direction(const vrt_grid *g, int64_t wall, const std::vector<in
                 if (c != std::string::npos) strip_w = std::max(1, std::min(4096, std::atoi(v.c_str() + c + 1)));
             }
         }
+        if (L >= ((int64_t)1 << 22)) strip_w = 0;     // (the strip key keeps 22 bits for the layer; the Morton key 32)
         const double x0 = g->bounds[2], xs = g->bounds[3] - g->bounds[2];
         const double y0 = g->bounds[4], ys = g->bounds[5] - g->bounds[4];
         std::vector<double> cell((size_t)L + 2, 1.0);           // lattice constant a of every layer (physical units)
