@@ -27,7 +27,7 @@ void tuning_from_env(Tuning &t)
     static const char *names[] = {"VRT_PATH", "VRT_STEP_K", "VRT_STEP_SINGLE", "VRT_STEP_PAIRS", "VRT_STEP_XCD",
                                   "VRT_STEP_STREAMS", "VRT_STEP_LEVEL_MAP", "VRT_STEP_GROUP_DIR", "VRT_TILE_WIDE",
                                   "VRT_TILE_PRE", "VRT_GRAPH", "VRT_PATCH_K", "VRT_PATCH_NT", "VRT_PATCH_OWN",
-                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PAIR_BLOCK", "VRT_PATCH_QUAD", "VRT_PATCH_LEAN", "VRT_PATCH_CHAIN", "VRT_CHAIN_PAIRS", "VRT_CHAIN_SPIN", "VRT_CHAIN_DATAFLAG", "VRT_CHAIN_STATIC", "VRT_LAMBDA_NATIVE", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
+                                  "VRT_PATCH_Q", "VRT_PATCH_TARGET", "VRT_PATCH_SPLIT", "VRT_PAIR_BLOCK", "VRT_PATCH_QUAD", "VRT_PATCH_LEAN", "VRT_PATCH_CHAIN", "VRT_CHAIN_PAIRS", "VRT_CHAIN_SPIN", "VRT_CHAIN_DATAFLAG", "VRT_CHAIN_STATIC", "VRT_LAMBDA_NATIVE", "VRT_DEBUG_FLAGS", "VRT_DEBUG_SKIP_LEVELS",
                                   "VRT_TILE_DEBUG"};
     for (const char *nm : names) {
         const char *e = std::getenv(nm);
@@ -67,7 +67,7 @@ int tuning_set(Tuning &t, const char *name, const char *value, bool created)
         {"VRT_TILE_PRE", &t.tile_pre, 0, 1, false}, {"VRT_GRAPH", &t.graph, 0, 1, false},
         {"VRT_PATCH_K", &t.patch_K, 1, 8, true}, {"VRT_PATCH_NT", &t.patch_NT, 64, 1024, true},
         {"VRT_PATCH_OWN", &t.patch_own, 0, 65535, true}, {"VRT_PATCH_Q", &t.patch_Q, 1, 4, false},
-        {"VRT_PATCH_TARGET", &t.patch_target, 1, 1 << 20, false}, {"VRT_PAIR_BLOCK", &t.pair_block, 1, 16, true},
+        {"VRT_PATCH_TARGET", &t.patch_target, 0, 1 << 20, false}, {"VRT_PATCH_SPLIT", &t.patch_split, 0, 4096, false}, {"VRT_PAIR_BLOCK", &t.pair_block, 1, 16, true},
         {"VRT_PATCH_QUAD", &t.patch_quad, 0, 1, true}, {"VRT_PATCH_LEAN", &t.patch_lean, 0, 1, false},
         {"VRT_PATCH_CHAIN", &t.patch_chain, 0, 2, false}, {"VRT_CHAIN_PAIRS", &t.chain_pairs, 1, 256, false},
         {"VRT_CHAIN_SPIN", &t.chain_spin, 1, 1 << 20, false}, {"VRT_CHAIN_DATAFLAG", &t.chain_dataflag, 0, 2, false},

@@ -137,7 +137,9 @@ struct Tuning {
     int chain_spin = 2048;        // VRT_CHAIN_SPIN: polls (x 1024) after which a waiting workgroup gives up (~2 s)
     int chain_dataflag = 2;       // VRT_CHAIN_DATAFLAG: the chained launch's intensities as their own flags: 0 never, 1 wherever
                                   //   the kernel exists, 2 auto (one or two wavelength pairs: the planes are filled per step)
-    int patch_target = 768;       // VRT_PATCH_TARGET: workgroups per launch aimed at when splitting the wavelengths
+    int patch_split = 0;          // VRT_PATCH_SPLIT: workgroups per item of a per-layer launch, fixed (0: from VRT_PATCH_TARGET)
+    int patch_target = 0;         // VRT_PATCH_TARGET: workgroups per launch aimed at when the pair steps of an item are split
+                                  //   (0: a balanced split chosen per launch, launch_patch_layer)
     int chain_static = 1;         // VRT_CHAIN_STATIC: the progress-word form of the chained launch maps block -> item statically (0: tickets)
     int lambda_native = 1;        // VRT_LAMBDA_NATIVE: the Λ-iteration session keeps S and J in sweep order between its steps
                                   //   (read when a session is created; 0: the caller's layout, two layout changes per iteration)

@@ -1610,8 +1610,8 @@ static void size_reduce(PatchReduce &red, int npair, int lgB, int NT)
 int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, int group, int Q, hipStream_t st,
                        bool f32, const PatchReduce *reduce)
 {
-    // workgroups per launch: enough to fill the chip a few times over with both direction streams running
-    const int target_wgs = std::max(1, p->tune.patch_target);
+    // workgroups per launch when VRT_PATCH_TARGET fixes them (0: the split is chosen below)
+    const int target_wgs = p->tune.patch_target;
     const int maxL = p->tile_max_layers;
     const size_t wo = (size_t)group * (size_t)(maxL + 2) + (size_t)layer;
     const int64_t w0 = (layer >= 2 && layer <= maxL) ? p->patch_work_off[wo] : 0, w1 = (layer >= 2 && layer <= maxL) ? p->patch_work_off[wo + 1] : 0;
@@ -1639,7 +1639,33 @@ int launch_patch_layer(vrt_plan *p, const TileArgs &ta, int npair, int layer, in
         const int64_t items = (w1 - w0) << lgS;                // work-list slots (a few of them padding) x siblings
         const int nblock = pair_block_count(npair, pa.lgB);
         const int steps_all = (nblock + Q - 1) / Q;            // Q blocks at a time
-        const int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(steps_all, (target_wgs + items - 1) / items));
+        // Workgroups per item (each walks its share of the item's `steps_all` pair steps with one read of the entry table).
+        // Only BALANCED splits are candidates -- s = ceil(steps / c) for c = 1, 2, ...: a launch ends with its longest workgroup,
+        // so among the splits with the same longest share the one with the fewest workgroups is the cheapest (8 steps over 7
+        // workgroups last as long as over 4 and read the table 7 times).  Among those: the one whose launch comes closest to
+        // T = min(900, 460 + 4100 / steps) workgroups -- the longer an item (a pair step is ~ 9 us), the closer a launch should
+        // stay to ONE round on its stream's half of the chip (512 slots: a second, partly filled round costs a whole item's
+        // time); short items tolerate, and for the launch's tail want, more and smaller workgroups -- but never less than that
+        // one round.  Measured on C4's grid, 108 items per launch (profiles/r5/split_table.txt): 8 / 10 / 13 / 18 / 26 / 35 / 50
+        // steps are fastest at 8 / 10 / 7 / 6 / 6 / 5 / 5 workgroups per item, C3 (10 steps, 180 items) at 5: what this picks.
+        // VRT_PATCH_TARGET > 0: the fixed workgroup count per launch of rounds 3-5 (768); VRT_PATCH_SPLIT: s itself.
+        int nsplit;
+        if (p->tune.patch_split > 0) nsplit = std::min(steps_all, p->tune.patch_split);
+        else if (target_wgs > 0) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(steps_all, (target_wgs + items - 1) / items));
+        else {
+            const double T = std::min(900.0, 460.0 + 4100.0 / (double)steps_all);
+            const int s_min = (int)std::min<int64_t>(steps_all, std::max<int64_t>(1, (512 + items - 1) / items));
+            double dmin = 1e300;
+            for (int c = steps_all; c >= 1; c--) {
+                const int sc = (steps_all + c - 1) / c;
+                if (sc >= s_min) dmin = std::min(dmin, std::fabs(std::log((double)items * sc / T)));
+            }
+            nsplit = s_min;
+            for (int c = steps_all; c >= 1; c--) {          // (s grows along the loop: the largest within 3 % of the closest)
+                const int sc = (steps_all + c - 1) / c;
+                if (sc >= s_min && std::fabs(std::log((double)items * sc / T)) <= dmin + 0.03) nsplit = sc;
+            }
+        }
         pa.nsplit = nsplit;
         pa.ngrp = nsplit << lgS;
     }
