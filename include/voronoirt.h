@@ -60,7 +60,8 @@ typedef struct vrt_plan vrt_plan;   /* per-(grid, angle set) upwind tables + swe
  * src/lambda_continuum.jl:27-56, where it does not change from one Λ-iteration to the next), handed over in SWEEP ORDER:
  * two plane sets of vrt_plan_native_plane_count(p, nlam) doubles one behind the other -- the up directions' order, then
  * the down directions' -- as vrt_plan_to_native_dev(p, nlam, ld, alpha, buf, buf + count, ...) writes them, once.
- * Accepted by vrt_plan_execute_native_dev only: no layout change of any kind is then left inside a step. */
+ * Accepted by vrt_plan_execute_native_dev[_f32] only (floats and vrt_plan_to_native_dev_f32 with the float entry): no layout
+ * change of any kind is then left inside a step. */
 #define VRT_ALPHA_SITE_LAM_NATIVE 4
 
 const char *vrt_last_error(void);
