@@ -1699,10 +1699,11 @@ bool patch_chain_possible(const vrt_plan *p, int npair, bool f32)
     // per-layer launch (ticket, item record, the final drain before the progress word), which pays while the per-layer
     // launches are bound by their 286-launch chain (C2 0.85 -> 0.54 ms, 1 M sites x 7 wavelengths 2.10 -> 1.73 ms)
     // and not when the pair loops saturate the chip (C4 7.5 -> 8.4 ms).  Measured crossover:
-    // patches of a layer (both directions) x wavelength-pair blocks ~ 1500.  fp32 storage: on request only.
+    // patches of a layer (both directions) x wavelength-pair blocks ~ 1400 (C4's grid, 217 patches per layer: 6 pairs chained 2.30 ms
+    // against 2.36 on per-layer launches, 7 pairs 2.59 against 2.53: profiles/r5/chain_crossover.txt).  fp32 storage: on request only.
     if (f32) return false;
     const double per_layer = (double)p->n_patches / (double)std::max(1, p->tile_max_layers);
-    return per_layer * (double)pair_block_count(npair, lgB) <= 1536.0;
+    return per_layer * (double)pair_block_count(npair, lgB) <= 1400.0;
 }
 
 // the chained launch's hand-off by the data itself (chain_data_wait): fp64 pair kernel only; auto: one or two wavelength
